@@ -1,0 +1,222 @@
+/*
+ * jbonsai_amd.h -- C ABI of libjbonsai_amd.so: an MI355X (gfx950) drop-in for the
+ * parameter-generation + MLSA-vocoder hot path of the `jbonsai` crate (v0.4.2).
+ *
+ * The reference exposes a Rust library API, not an FFI; each entry point below
+ * names the reference item it stands in for (file:line under /root/reference).
+ * A Rust shim re-exporting `Engine` / `SpeechGenerator` over these symbols is in
+ * INTEGRATION.md.  All functions return 0 (JB_OK) or a negative jb_status; no
+ * exception or unwinding crosses this boundary; jb_last_error() gives the text
+ * for the calling thread.  No torch / HIP types appear in any signature.
+ *
+ * Two levels:
+ *   (1) state level  -- `jb_batch_*`, `jb_paramgen_vocode_batch`: the exact image
+ *       of `ModelStream` + `durations` (src/model/model_stream.rs:6-15,
+ *       src/engine.rs:321-357), batched over independent utterances.  This is
+ *       the seam the HIP kernels sit behind: MlpgAdjust::create x3
+ *       (src/mlpg_adjust/mod.rs:51-95) -> SpeechGenerator::generate_all
+ *       (src/speech.rs:87-96) -> Vocoder::synthesize (src/vocoder/mod.rs:72-141).
+ *   (2) engine level -- `jb_engine_*`, `jb_synthesize*`, `jb_generator_*`: mirrors
+ *       Engine::{load, load_from_bytes, synthesize, generator} (src/engine.rs:257-366)
+ *       and SpeechGenerator::{fperiod, synthesized_frames, generate_step}
+ *       (src/speech.rs:53-82); label parsing / tree search / durations run on
+ *       the host, everything from the state level down runs on the GPU.
+ */
+#ifndef JBONSAI_AMD_H
+#define JBONSAI_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JB_MAX_STREAM 3
+#define JB_MAX_WINDOW 8
+#define JB_NODATA (-1e10) /* src/constants.rs:13 */
+
+typedef enum jb_status {
+    JB_OK = 0,
+    JB_ERR_INVALID = -1,     /* bad argument / shape (reference: panics in src/speech.rs:32-40) */
+    JB_ERR_UNSUPPORTED = -2, /* Stage::NonZero (GAMMA!=0), beta>0, nlpf==0: not on any BASELINE config */
+    JB_ERR_DEVICE = -3,      /* HIP error or no gfx950 device: the product never falls back to CPU */
+    JB_ERR_MODEL = -4,       /* ModelError (src/model/mod.rs:31-46) */
+    JB_ERR_LABEL = -5,       /* LabelError (src/label.rs:8-23) */
+    JB_ERR_PARSE_OPTION = -6,/* EngineError::ParseOptionError (src/engine.rs:21-23) */
+    JB_ERR_WEIGHT = -7,      /* WeightError (src/model/interporation_weight.rs:7-14) */
+    JB_ERR_BUFFER = -8       /* output buffer too small (reference: panic, src/speech.rs:69-71) */
+} jb_status;
+
+/* ------------------------------------------------------------------------ */
+/* (1) state level                                                          */
+/* ------------------------------------------------------------------------ */
+
+/* Per-stream static description: StreamModelMetadata + Windows
+ * (src/model/voice/mod.rs, src/model/voice/window.rs:4-22). */
+typedef struct jb_stream_desc {
+    uint32_t vector_length;              /* L */
+    uint32_t num_windows;                /* W */
+    uint32_t is_msd;
+    uint32_t use_gv;
+    uint32_t win_width[JB_MAX_WINDOW];   /* odd widths */
+    const double *win_coef;              /* concatenated coefficients, sum(win_width) */
+} jb_stream_desc;
+
+/* Vocoder::new arguments (src/vocoder/mod.rs:45-55) + stream layout. */
+typedef struct jb_voice_desc {
+    uint32_t sampling_frequency;  /* rate */
+    uint32_t fperiod;
+    uint32_t nstream;             /* 3: MCP, LF0, LPF (src/engine.rs:303-313 needs stream 2) */
+    uint32_t stage;               /* 0 only */
+    uint32_t use_log_gain;        /* ignored when stage==0 */
+    double alpha, beta, volume;   /* beta must be 0 */
+    jb_stream_desc stream[JB_MAX_STREAM];
+} jb_voice_desc;
+
+/* State-level parameters of one stream of one utterance: StreamParameter +
+ * GvParameter (src/model/stream_parameter.rs:11, src/model/mod.rs:49). */
+typedef struct jb_stream_states {
+    const double *mean;        /* [S][W*L]; element L*w+m (src/mlpg_adjust/mod.rs:62) */
+    const double *var;         /* [S][W*L] */
+    const double *msd;         /* [S]; NULL => f64::MAX (non-MSD, src/model/mod.rs:113) */
+    const double *gv_mean;     /* [L] or NULL (no GV) */
+    const double *gv_var;      /* [L] */
+    const uint8_t *gv_switch;  /* [S] */
+    double gv_weight;          /* Condition::gv_weight[i]   (src/engine.rs:93) */
+    double msd_threshold;      /* Condition::msd_threshold[i] (src/engine.rs:92) */
+} jb_stream_states;
+
+typedef struct jb_state_utt {
+    uint32_t num_states;        /* S = labels * nstate */
+    const uint32_t *durations;  /* [S] frames per state (src/duration.rs) */
+    jb_stream_states stream[JB_MAX_STREAM];
+} jb_state_utt;
+
+typedef struct jb_batch_opts {
+    int32_t device;       /* HIP device ordinal; -1 = current */
+    uint32_t flags;       /* JB_BATCH_* */
+    uint32_t reserved[6];
+} jb_batch_opts;
+
+#define JB_BATCH_KEEP_TRACKS 1u /* keep MLPG parameter tracks readable (tests) */
+
+typedef struct jb_batch jb_batch;
+
+/* Upload a batch of utterances to HBM and allocate outputs/workspace.
+ * Utterances may alias each other's input arrays. */
+int jb_batch_create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
+                    const jb_batch_opts *opts, jb_batch **out);
+/* Enqueue the whole hot path (MLPG+GV x3 -> frame prologue -> pulse schedule ->
+ * excitation + MLSA) on the batch's HIP stream.  Inputs are already resident. */
+int jb_batch_run(jb_batch *b);
+int jb_batch_sync(jb_batch *b);
+/* run + sync, returning device time of the launch sequence in ms (HIP events on
+ * the batch's own stream); vocoder_ms = the MLSA kernel alone. */
+int jb_batch_run_timed(jb_batch *b, float *total_ms, float *vocoder_ms);
+size_t jb_batch_size(const jb_batch *b);
+size_t jb_batch_num_frames(const jb_batch *b, size_t utt);
+size_t jb_batch_num_samples(const jb_batch *b, size_t utt);
+size_t jb_batch_total_samples(const jb_batch *b);
+/* Copy utterance `utt`'s PCM (f64, un-clipped, as Vec<f64> of src/engine.rs:294). */
+int jb_batch_read_pcm(jb_batch *b, size_t utt, double *dst, size_t cap);
+/* Parameter track of stream s ([T][L], NODATA in unvoiced frames); needs KEEP_TRACKS. */
+int jb_batch_read_track(jb_batch *b, size_t utt, uint32_t stream, double *dst, size_t cap);
+/* Debug/parity taps: excitation before gain [N]; needs KEEP_TRACKS. */
+int jb_batch_read_excitation(jb_batch *b, size_t utt, double *dst, size_t cap);
+/* Device pointer + byte size of the batch's contiguous PCM slab (for an RCCL gather
+ * by the caller); utterance i starts at sample jb_batch_pcm_offset(b,i). */
+void *jb_batch_device_pcm(jb_batch *b, size_t *n_samples);
+size_t jb_batch_pcm_offset(const jb_batch *b, size_t utt);
+void jb_batch_free(jb_batch *b);
+
+/* One-shot convenience: create + run + read + free.  pcm[i] must hold
+ * n_samples[i] doubles; call with pcm==NULL to get n_samples only. */
+int jb_paramgen_vocode_batch(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
+                             const jb_batch_opts *opts, double *const *pcm, size_t *n_samples);
+
+/* ------------------------------------------------------------------------ */
+/* (2) engine level                                                         */
+/* ------------------------------------------------------------------------ */
+typedef struct jb_engine jb_engine;
+typedef struct jb_generator jb_generator;
+
+/* Engine::load (src/engine.rs:257) / load_from_bytes (:263). */
+int jb_engine_load(const char *const *paths, size_t n, jb_engine **out);
+int jb_engine_load_from_bytes(const uint8_t *const *bufs, const size_t *lens, size_t n,
+                              jb_engine **out);
+void jb_engine_free(jb_engine *e);
+
+/* Condition accessors (src/engine.rs:127-243); setters clamp like the reference. */
+int jb_engine_set_sampling_frequency(jb_engine *e, size_t v);
+size_t jb_engine_get_sampling_frequency(const jb_engine *e);
+int jb_engine_set_fperiod(jb_engine *e, size_t v);
+size_t jb_engine_get_fperiod(const jb_engine *e);
+int jb_engine_set_volume(jb_engine *e, double db);
+double jb_engine_get_volume(const jb_engine *e);
+int jb_engine_set_msd_threshold(jb_engine *e, size_t stream, double v);
+double jb_engine_get_msd_threshold(const jb_engine *e, size_t stream);
+int jb_engine_set_gv_weight(jb_engine *e, size_t stream, double v);
+double jb_engine_get_gv_weight(const jb_engine *e, size_t stream);
+int jb_engine_set_phoneme_alignment_flag(jb_engine *e, int flag);
+int jb_engine_get_phoneme_alignment_flag(const jb_engine *e);
+int jb_engine_set_speed(jb_engine *e, double v);
+double jb_engine_get_speed(const jb_engine *e);
+int jb_engine_set_alpha(jb_engine *e, double v);
+double jb_engine_get_alpha(const jb_engine *e);
+int jb_engine_set_beta(jb_engine *e, double v);
+double jb_engine_get_beta(const jb_engine *e);
+int jb_engine_set_additional_half_tone(jb_engine *e, double v);
+double jb_engine_get_additional_half_tone(const jb_engine *e);
+size_t jb_engine_num_voices(const jb_engine *e);
+size_t jb_engine_num_streams(const jb_engine *e);
+size_t jb_engine_num_states(const jb_engine *e);
+/* InterporationWeight setters (src/model/interporation_weight.rs:48-126);
+ * which: 0 duration, 1 parameter[stream], 2 gv[stream]. */
+int jb_engine_set_interpolation_weight(jb_engine *e, int which, size_t stream, const double *w,
+                                       size_t n);
+
+/* Engine::synthesize (src/engine.rs:294): label lines ("label" or "start end label").
+ * *pcm is library-owned; release with jb_pcm_free.  Zero labels => n_samples 0. */
+int jb_synthesize(const jb_engine *e, const char *const *label_lines, size_t n_lines,
+                  double **pcm, size_t *n_samples);
+void jb_pcm_free(double *pcm);
+
+/* Batched synthesize: utterance u has lines [line_off[u], line_off[u+1]).  New
+ * entry (the reference is single-utterance); a Rust `Engine::synthesize_batch`
+ * would sit on it.  pcm[u] library-owned (jb_pcm_free each). */
+int jb_synthesize_batch(const jb_engine *e, const char *const *label_lines,
+                        const size_t *line_off, size_t n_utts, int32_t device, double **pcm,
+                        size_t *n_samples);
+
+/* Host front half only (tree search + durations): fills a state-level utterance
+ * owned by the returned handle; used by tests and by jb_synthesize itself. */
+typedef struct jb_states jb_states;
+int jb_engine_states(const jb_engine *e, const char *const *label_lines, size_t n_lines,
+                     jb_states **out);
+const jb_state_utt *jb_states_utt(const jb_states *s);
+const jb_voice_desc *jb_engine_voice_desc(const jb_engine *e);
+void jb_states_free(jb_states *s);
+
+/* Engine::generator (src/engine.rs:301) + SpeechGenerator (src/speech.rs:25-96). */
+int jb_generator_new(const jb_engine *e, const char *const *label_lines, size_t n_lines,
+                     jb_generator **out);
+size_t jb_generator_fperiod(const jb_generator *g);
+size_t jb_generator_synthesized_frames(const jb_generator *g);
+size_t jb_generator_total_frames(const jb_generator *g);
+/* generate_step: writes fperiod samples to buf, returns fperiod, 0 when exhausted,
+ * or a negative jb_status (JB_ERR_BUFFER where the reference panics). */
+long jb_generator_step(jb_generator *g, double *buf, size_t buf_len);
+void jb_generator_free(jb_generator *g);
+
+/* ------------------------------------------------------------------------ */
+const char *jb_last_error(void);
+int jb_device_count(void);
+/* "gfx950" etc. of device `dev` into buf. */
+int jb_device_arch(int dev, char *buf, size_t cap);
+const char *jb_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JBONSAI_AMD_H */

@@ -1,0 +1,11 @@
+"""jbonsai_amd: MI355X (gfx950) implementation of jbonsai's parameter-generation +
+MLSA-vocoder hot path behind a C ABI (include/jbonsai_amd.h).
+
+The HIP shared library `libjbonsai_amd.so` is the product; this package is the
+thin host-side mirror of the reference's API used by tests and the benchmark.
+"""
+from ._ffi import JbError, LIB_PATH, NODATA, build, lib  # noqa: F401
+from .batch import Batch, StreamInfo, StreamStates, Utterance, VoiceInfo, paramgen_vocode_batch  # noqa: F401
+
+__all__ = ["JbError", "LIB_PATH", "NODATA", "build", "lib", "Batch", "StreamInfo", "StreamStates",
+           "Utterance", "VoiceInfo", "paramgen_vocode_batch"]

@@ -1,0 +1,188 @@
+"""State-level batch API: the image of ModelStream + durations for B utterances
+(reference: src/model/model_stream.rs:6-15, src/engine.rs:321-365)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi as F
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double)) if a is not None else None
+
+
+@dataclass
+class StreamInfo:
+    """Static stream description (vector length, MSD/GV flags, delta windows)."""
+    vector_length: int
+    is_msd: bool
+    use_gv: bool
+    windows: List[List[float]]
+
+
+@dataclass
+class VoiceInfo:
+    sampling_frequency: int
+    fperiod: int
+    alpha: float
+    streams: List[StreamInfo]
+    volume: float = 1.0
+    beta: float = 0.0
+    stage: int = 0
+    use_log_gain: bool = False
+
+    def c_struct(self):
+        v = F.VoiceDesc()
+        v.sampling_frequency, v.fperiod = self.sampling_frequency, self.fperiod
+        v.nstream, v.stage, v.use_log_gain = len(self.streams), self.stage, int(self.use_log_gain)
+        v.alpha, v.beta, v.volume = self.alpha, self.beta, self.volume
+        keep = []
+        for i, s in enumerate(self.streams):
+            d = v.stream[i]
+            d.vector_length, d.num_windows = s.vector_length, len(s.windows)
+            d.is_msd, d.use_gv = int(s.is_msd), int(s.use_gv)
+            coef = np.array([c for w in s.windows for c in w], dtype=np.float64)
+            for k, w in enumerate(s.windows):
+                d.win_width[k] = len(w)
+            d.win_coef = _dp(coef)
+            keep.append(coef)
+        return v, keep
+
+
+@dataclass
+class StreamStates:
+    mean: np.ndarray            # [S, W*L]
+    var: np.ndarray             # [S, W*L]
+    msd: Optional[np.ndarray] = None      # [S]
+    gv_mean: Optional[np.ndarray] = None  # [L]
+    gv_var: Optional[np.ndarray] = None
+    gv_switch: Optional[np.ndarray] = None  # [S] uint8
+    gv_weight: float = 1.0
+    msd_threshold: float = 0.5
+
+    def __post_init__(self):
+        f = lambda a, t: None if a is None else np.ascontiguousarray(a, dtype=t)
+        self.mean, self.var = f(self.mean, np.float64), f(self.var, np.float64)
+        self.msd, self.gv_mean, self.gv_var = f(self.msd, np.float64), f(self.gv_mean, np.float64), f(self.gv_var, np.float64)
+        self.gv_switch = f(self.gv_switch, np.uint8)
+
+
+@dataclass
+class Utterance:
+    durations: np.ndarray       # [S] uint32
+    streams: List[StreamStates] = field(default_factory=list)
+
+    def __post_init__(self):
+        self.durations = np.ascontiguousarray(self.durations, dtype=np.uint32)
+
+    def c_struct(self):
+        u = F.StateUtt()
+        u.num_states = len(self.durations)
+        u.durations = self.durations.ctypes.data_as(C.POINTER(C.c_uint32))
+        for i, s in enumerate(self.streams):
+            d = u.stream[i]
+            d.mean, d.var, d.msd = _dp(s.mean), _dp(s.var), _dp(s.msd)
+            d.gv_mean, d.gv_var = _dp(s.gv_mean), _dp(s.gv_var)
+            d.gv_switch = s.gv_switch.ctypes.data_as(C.POINTER(C.c_uint8)) if s.gv_switch is not None else None
+            d.gv_weight, d.msd_threshold = s.gv_weight, s.msd_threshold
+        return u
+
+
+class Batch:
+    """A batch of utterances resident in HBM (jb_batch_*)."""
+
+    def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
+                 keep_tracks: bool = False):
+        L = F.lib()
+        self._L = L
+        self.voice = voice
+        self._utts = list(utts)  # keep host arrays alive during create
+        vd, keep = voice.c_struct()
+        arr = (F.StateUtt * max(1, len(utts)))()
+        for i, u in enumerate(self._utts):
+            arr[i] = u.c_struct()
+        opts = F.BatchOpts()
+        opts.device, opts.flags = device, (F.BATCH_KEEP_TRACKS if keep_tracks else 0)
+        h = C.c_void_p()
+        F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
+        self._h = h
+        self._keep = keep
+
+    def __len__(self):
+        return self._L.jb_batch_size(self._h)
+
+    def run(self):
+        F.check(self._L.jb_batch_run(self._h))
+
+    def sync(self):
+        F.check(self._L.jb_batch_sync(self._h))
+
+    def run_timed(self):
+        t, v = C.c_float(), C.c_float()
+        F.check(self._L.jb_batch_run_timed(self._h, C.byref(t), C.byref(v)))
+        return t.value, v.value
+
+    def num_samples(self, i):
+        return self._L.jb_batch_num_samples(self._h, i)
+
+    def num_frames(self, i):
+        return self._L.jb_batch_num_frames(self._h, i)
+
+    @property
+    def total_samples(self):
+        return self._L.jb_batch_total_samples(self._h)
+
+    def pcm(self, i) -> np.ndarray:
+        n = self.num_samples(i)
+        out = np.empty(n, dtype=np.float64)
+        F.check(self._L.jb_batch_read_pcm(self._h, i, out.ctypes.data, n))
+        return out
+
+    def track(self, i, stream) -> np.ndarray:
+        T, Lv = self.num_frames(i), self.voice.streams[stream].vector_length
+        out = np.empty((T, Lv), dtype=np.float64)
+        F.check(self._L.jb_batch_read_track(self._h, i, stream, out.ctypes.data, out.size))
+        return out
+
+    def excitation(self, i) -> np.ndarray:
+        n = self.num_samples(i)
+        out = np.empty(n, dtype=np.float64)
+        F.check(self._L.jb_batch_read_excitation(self._h, i, out.ctypes.data, n))
+        return out
+
+    def device_pcm(self):
+        n = C.c_size_t()
+        p = self._L.jb_batch_device_pcm(self._h, C.byref(n))
+        return p, n.value
+
+    def pcm_offset(self, i):
+        return self._L.jb_batch_pcm_offset(self._h, i)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.jb_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def paramgen_vocode_batch(voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1):
+    """One-shot jb_paramgen_vocode_batch: returns a list of f64 PCM arrays."""
+    with Batch(voice, utts, device=device) as b:
+        b.run()
+        b.sync()
+        return [b.pcm(i) for i in range(len(utts))]

@@ -1,0 +1,663 @@
+// jb_batch.cpp -- state-level C ABI (include/jbonsai_amd.h, part 1): uploads a
+// batch of state-level utterances to HBM, runs the HIP hot path, reads PCM back.
+//
+// Stands in for   MlpgAdjust::create x3  (src/mlpg_adjust/mod.rs:51-95)
+//               + SpeechGenerator::new/generate_all (src/speech.rs:25-96)
+// as called by Engine::generator (src/engine.rs:333-365), batched over utterances.
+// There is NO CPU fallback: without a HIP device every entry returns JB_ERR_DEVICE.
+#include "jb_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+namespace jb {
+
+thread_local std::string g_err;
+
+void set_error(const std::string &s) { g_err = s; }
+
+int hip_fail(hipError_t e, const char *what)
+{
+    set_error(std::string(what) + ": " + hipGetErrorString(e));
+    return JB_ERR_DEVICE;
+}
+
+// ---- shared Gaussian noise stream ------------------------------------------
+// Random::nrandom (src/vocoder/excitation.rs:177-237): LCG + polar Box-Muller,
+// seed next=1, identical for every utterance => one table per device, grown on
+// demand.  Only bits 16..30 of the LCG state are used, so u32 state suffices.
+static void noise_fill(std::vector<double> &out, size_t n, uint32_t &next, size_t &have)
+{
+    // n and have are multiples of 64: whole fill_queue() refills only
+    out.resize(n);
+    auto rnd = [&]() {
+        next = next * 1103515245u + 12345u;
+        return (double)((next >> 16) & 32767u) / 32767.0;
+    };
+    double sv[32];
+    while (have < n) {
+        double *q = out.data() + have;
+        int k = 0;
+        while (k < 32) {
+            double r1 = 2.0 * rnd() - 1.0, r2 = 2.0 * rnd() - 1.0;
+            double s = r1 * r1 + r2 * r2;
+            if (0.0 < s && s < 1.0) {
+                q[2 * k] = r1;
+                q[2 * k + 1] = r2;
+                sv[k] = s;
+                k++;
+            }
+        }
+        for (k = 0; k < 32; k++) {
+            double m = std::sqrt(-2.0 * std::log(sv[k]) / sv[k]);
+            q[2 * k] *= m;
+            q[2 * k + 1] *= m;
+        }
+        have += 64;
+    }
+}
+
+struct NoiseCache {
+    std::mutex mu;
+    std::vector<double> host; // always a multiple of 64 long
+    uint32_t lcg = 1;
+    size_t have = 0;
+    std::map<int, std::pair<double *, size_t>> dev; // device -> (ptr, len)
+};
+static NoiseCache g_noise;
+
+int noise_table(int device, size_t need, const double **ptr, size_t *len)
+{
+    std::lock_guard<std::mutex> lk(g_noise.mu);
+    need = (need + 63) / 64 * 64;
+    if (need == 0)
+        need = 64;
+    auto it = g_noise.dev.find(device);
+    if (it != g_noise.dev.end() && it->second.second >= need) {
+        *ptr = it->second.first;
+        *len = it->second.second;
+        return JB_OK;
+    }
+    if (g_noise.have < need) {
+        // restart from the stored LCG state at a refill boundary
+        std::vector<double> &h = g_noise.host;
+        size_t have = g_noise.have;
+        noise_fill(h, need, g_noise.lcg, have);
+        g_noise.have = have;
+    }
+    double *d = nullptr;
+    hipError_t e = hipMalloc(&d, need * sizeof(double));
+    if (e != hipSuccess)
+        return hip_fail(e, "hipMalloc(noise)");
+    e = hipMemcpy(d, g_noise.host.data(), need * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipMemcpy(noise)");
+    if (it != g_noise.dev.end()) {
+        // older, shorter table: leave it alive (batches may still point at it)
+        g_noise.dev.erase(it);
+    }
+    g_noise.dev[device] = {d, need};
+    *ptr = d;
+    *len = need;
+    return JB_OK;
+}
+
+// ---- batch -----------------------------------------------------------------
+Batch::~Batch()
+{
+    if (device >= 0)
+        hipSetDevice(device);
+    for (void *p : allocs)
+        hipFree(p);
+    if (ev0)
+        hipEventDestroy(ev0);
+    if (ev1)
+        hipEventDestroy(ev1);
+    if (ev2)
+        hipEventDestroy(ev2);
+    if (ev3)
+        hipEventDestroy(ev3);
+    if (stream)
+        hipStreamDestroy(stream);
+}
+
+template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
+{
+    *p = nullptr;
+    if (n == 0)
+        n = 1;
+    void *v = nullptr;
+    hipError_t e = hipMalloc(&v, n * sizeof(T));
+    if (e != hipSuccess) {
+        char msg[128];
+        snprintf(msg, sizeof msg, "hipMalloc(%zu bytes)", n * sizeof(T));
+        return hip_fail(e, msg);
+    }
+    allocs.push_back(v);
+    bytes_alloc += n * sizeof(T);
+    if (zero) {
+        e = hipMemset(v, 0, n * sizeof(T));
+        if (e != hipSuccess)
+            return hip_fail(e, "hipMemset");
+    }
+    *p = (T *)v;
+    return JB_OK;
+}
+
+// upload with de-duplication on (host pointer, byte size)
+int Batch::upload(const void *host, size_t bytes, const void **dev)
+{
+    *dev = nullptr;
+    if (!host || bytes == 0)
+        return JB_OK;
+    auto key = std::make_pair(host, bytes);
+    auto it = uploaded.find(key);
+    if (it != uploaded.end()) {
+        *dev = it->second;
+        return JB_OK;
+    }
+    uint8_t *d;
+    int rc = dalloc(&d, bytes, false);
+    if (rc)
+        return rc;
+    hipError_t e = hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipMemcpy(H2D)");
+    uploaded[key] = d;
+    bytes_input += bytes;
+    *dev = d;
+    return JB_OK;
+}
+
+static int check_voice(const jb_voice_desc *v)
+{
+    if (!v)
+        return JB_ERR_INVALID;
+    if (v->stage != 0) {
+        set_error("Stage::NonZero (GAMMA != 0, LSP/MGLSA) is not supported");
+        return JB_ERR_UNSUPPORTED;
+    }
+    if (v->beta != 0.0) {
+        set_error("beta > 0 (postfilter_mcp) is not supported");
+        return JB_ERR_UNSUPPORTED;
+    }
+    if (v->nstream != 3) {
+        // Engine::generator indexes stream_metadata(2) unconditionally (src/engine.rs:305)
+        set_error("exactly 3 streams (MCP, LF0, LPF) are required");
+        return JB_ERR_UNSUPPORTED;
+    }
+    if (v->fperiod == 0 || v->sampling_frequency == 0) {
+        set_error("fperiod and sampling_frequency must be positive");
+        return JB_ERR_INVALID;
+    }
+    const jb_stream_desc &m = v->stream[0], &l = v->stream[1], &p = v->stream[2];
+    if (l.vector_length != 1) {
+        set_error("The size of lf0 static vector must be 1."); // src/speech.rs:35-37
+        return JB_ERR_INVALID;
+    }
+    if (p.vector_length == 0) {
+        set_error("nlpf == 0 is not supported");
+        return JB_ERR_UNSUPPORTED;
+    }
+    if (p.vector_length % 2 == 0) {
+        set_error("The number of low-pass filter coefficient must be odd numbers."); // speech.rs:38-40
+        return JB_ERR_INVALID;
+    }
+    if (p.vector_length > 63) {
+        set_error("nlpf > 63 is not supported");
+        return JB_ERR_UNSUPPORTED;
+    }
+    if (m.vector_length < 2 || m.vector_length - 1 > (uint32_t)(kGroups * kMaxTPL)) {
+        set_error("nmcp must be in [2, 61]");
+        return JB_ERR_UNSUPPORTED;
+    }
+    for (uint32_t i = 0; i < v->nstream; i++) {
+        const jb_stream_desc &s = v->stream[i];
+        if (s.num_windows == 0 || s.num_windows > JB_MAX_WINDOW || !s.win_coef) {
+            set_error("bad window description");
+            return JB_ERR_INVALID;
+        }
+        uint32_t tot = 0;
+        for (uint32_t w = 0; w < s.num_windows; w++) {
+            if (s.win_width[w] == 0 || s.win_width[w] > 5) {
+                set_error("window widths must be in 1..5");
+                return JB_ERR_UNSUPPORTED;
+            }
+            tot += s.win_width[w];
+        }
+        if (tot > (uint32_t)kMaxCoef)
+            return JB_ERR_UNSUPPORTED;
+    }
+    return JB_OK;
+}
+
+int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,
+                  const jb_batch_opts *opts, Batch **out)
+{
+    *out = nullptr;
+    int rc = check_voice(voice);
+    if (rc)
+        return rc;
+    if (n && !utts)
+        return JB_ERR_INVALID;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        set_error("no HIP device available (this library has no CPU path)");
+        return JB_ERR_DEVICE;
+    }
+    std::unique_ptr<Batch> b(new Batch());
+    int dev = opts ? opts->device : -1;
+    if (dev < 0) {
+        e = hipGetDevice(&dev);
+        if (e != hipSuccess)
+            return hip_fail(e, "hipGetDevice");
+    }
+    if (dev >= ndev) {
+        set_error("device ordinal out of range");
+        return JB_ERR_INVALID;
+    }
+    e = hipSetDevice(dev);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipSetDevice");
+    b->device = dev;
+    b->flags = opts ? opts->flags : 0;
+    b->voice = *voice;
+    e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipStreamCreate");
+    hipEventCreate(&b->ev0);
+    hipEventCreate(&b->ev1);
+    hipEventCreate(&b->ev2);
+    hipEventCreate(&b->ev3);
+
+    const int B = (int)n;
+    b->B = B;
+    b->T.resize(n);
+    b->frame_off.resize(n + 1);
+    std::vector<UttDev> hu(n);
+    uint64_t sumT = 0, sumS = 0;
+    uint32_t maxT = 0;
+    for (size_t i = 0; i < n; i++) {
+        const jb_state_utt &u = utts[i];
+        if (u.num_states && !u.durations)
+            return JB_ERR_INVALID;
+        uint64_t T = 0;
+        for (uint32_t s = 0; s < u.num_states; s++)
+            T += u.durations[s];
+        if (T > 0xffffffffull / voice->fperiod) {
+            set_error("utterance too long");
+            return JB_ERR_INVALID;
+        }
+        b->T[i] = (uint32_t)T;
+        b->frame_off[i] = sumT;
+        hu[i].S = u.num_states;
+        hu[i].T = (uint32_t)T;
+        hu[i].frame_off = sumT;
+        hu[i].state_off = sumS;
+        sumT += T;
+        sumS += u.num_states;
+        maxT = std::max(maxT, (uint32_t)T);
+        const void *dp;
+        if ((rc = b->upload(u.durations, sizeof(uint32_t) * u.num_states, &dp)))
+            return rc;
+        hu[i].dur = (const uint32_t *)dp;
+        for (uint32_t si = 0; si < voice->nstream; si++) {
+            const jb_stream_states &hs = u.stream[si];
+            const jb_stream_desc &sd = voice->stream[si];
+            const size_t WL = (size_t)sd.vector_length * sd.num_windows;
+            if (u.num_states && (!hs.mean || !hs.var)) {
+                set_error("stream mean/var missing");
+                return JB_ERR_INVALID;
+            }
+            StreamStatesDev &ds = hu[i].st[si];
+            if ((rc = b->upload(hs.mean, sizeof(double) * WL * u.num_states, &dp)))
+                return rc;
+            ds.mean = (const double *)dp;
+            if ((rc = b->upload(hs.var, sizeof(double) * WL * u.num_states, &dp)))
+                return rc;
+            ds.var = (const double *)dp;
+            if ((rc = b->upload(hs.msd, sizeof(double) * u.num_states, &dp)))
+                return rc;
+            ds.msd = (const double *)dp;
+            ds.gv_mean = ds.gv_var = nullptr;
+            ds.gv_switch = nullptr;
+            if (sd.use_gv && hs.gv_mean && hs.gv_var && hs.gv_switch) {
+                if ((rc = b->upload(hs.gv_mean, sizeof(double) * sd.vector_length, &dp)))
+                    return rc;
+                ds.gv_mean = (const double *)dp;
+                if ((rc = b->upload(hs.gv_var, sizeof(double) * sd.vector_length, &dp)))
+                    return rc;
+                ds.gv_var = (const double *)dp;
+                if ((rc = b->upload(hs.gv_switch, u.num_states, &dp)))
+                    return rc;
+                ds.gv_switch = (const uint8_t *)dp;
+            }
+            ds.gv_weight = hs.gv_weight;
+            ds.msd_threshold = hs.msd_threshold;
+        }
+    }
+    b->frame_off[n] = sumT;
+    b->sumT = sumT;
+    b->maxT = maxT;
+
+    UttDev *dutt;
+    if ((rc = b->dalloc(&dutt, n, false)))
+        return rc;
+    if (n)
+        hipMemcpy(dutt, hu.data(), sizeof(UttDev) * n, hipMemcpyHostToDevice);
+    // launch order: longest utterance first (LPT within the GPU)
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](uint32_t a, uint32_t c) { return b->T[a] > b->T[c]; });
+    uint32_t *dord;
+    if ((rc = b->dalloc(&dord, n, false)))
+        return rc;
+    if (n)
+        hipMemcpy(dord, order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice);
+    b->bd.B = B;
+    b->bd.utt = dutt;
+    b->bd.order = dord;
+    b->bd.maxT = maxT;
+
+    // ---- per-stream scratch + MLPG workspace ----
+    for (uint32_t si = 0; si < voice->nstream; si++) {
+        const jb_stream_desc &hs = voice->stream[si];
+        StreamDev &sd = b->sd[si];
+        memset(&sd, 0, sizeof sd);
+        sd.L = (int)hs.vector_length;
+        sd.W = (int)hs.num_windows;
+        sd.is_msd = (int)hs.is_msd;
+        sd.use_gv = (int)hs.use_gv;
+        int off = 0, maxw = 0;
+        for (int w = 0; w < sd.W; w++) {
+            sd.win_width[w] = (int)hs.win_width[w];
+            sd.win_off[w] = off;
+            for (int k = 0; k < sd.win_width[w]; k++)
+                sd.win_coef[off + k] = hs.win_coef[off + k];
+            off += sd.win_width[w];
+            maxw = std::max(maxw, sd.win_width[w]);
+        }
+        sd.BW = (maxw / 2) * 2 + 1; // Windows::max_width()*2+1 (window.rs:19-21, mlpg.rs:27)
+        const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L;
+        if ((rc = b->dalloc(&sd.fstate, nf, false)) || (rc = b->dalloc(&sd.voiced, nf, false)) ||
+            (rc = b->dalloc(&sd.fl, nf, false)) || (rc = b->dalloc(&sd.fr, nf, false)) ||
+            (rc = b->dalloc(&sd.vidx, nf, false)) || (rc = b->dalloc(&sd.vsw, nf, false)) ||
+            (rc = b->dalloc(&sd.Tv, n, true)) || (rc = b->dalloc(&sd.gvlen, n, true)))
+            return rc;
+        for (int j = 0; j < sd.BW; j++)
+            if ((rc = b->dalloc(&sd.A[j], nfl, false)) || (rc = b->dalloc(&sd.F[j], nfl, false)))
+                return rc;
+        if ((rc = b->dalloc(&sd.bvec, nfl, false)) || (rc = b->dalloc(&sd.g, nfl, false)) ||
+            (rc = b->dalloc(&sd.par, nfl, false)) || (rc = b->dalloc(&sd.out, nfl, false)))
+            return rc;
+    }
+
+    // ---- vocoder ----
+    VocDev &vd = b->vd;
+    memset(&vd, 0, sizeof vd);
+    vd.fs = (int)voice->sampling_frequency;
+    vd.fperiod = (int)voice->fperiod;
+    vd.nmcp = (int)voice->stream[0].vector_length;
+    vd.nlpf = (int)voice->stream[2].vector_length;
+    int bs = std::min(64, vd.fperiod);
+    while (vd.fperiod % bs)
+        bs--;
+    if (bs < vd.nlpf - 1) {
+        set_error("fperiod has no block divisor >= nlpf-1 (unsupported frame period)");
+        return JB_ERR_UNSUPPORTED;
+    }
+    vd.bs = bs;
+    vd.nblk = vd.fperiod / bs;
+    vd.alpha = voice->alpha;
+    vd.volume = voice->volume;
+    vd.mcp = b->sd[0].out;
+    vd.lf0 = b->sd[1].out;
+    vd.lpf = b->sd[2].out;
+    const size_t nf = (size_t)sumT;
+    b->total_samples = nf * (size_t)vd.fperiod;
+    if ((rc = b->dalloc(&vd.bcoef, nf * (size_t)vd.nmcp, false)) ||
+        (rc = b->dalloc(&vd.pitch, nf, false)) || (rc = b->dalloc(&vd.cur_start, nf, false)) ||
+        (rc = b->dalloc(&vd.pinc, nf, false)) || (rc = b->dalloc(&vd.counter_start, nf, false)) ||
+        (rc = b->dalloc(&vd.pmask, nf * (size_t)vd.nblk, false)) ||
+        (rc = b->dalloc(&vd.pcm, b->total_samples, false)))
+        return rc;
+    if (b->flags & JB_BATCH_KEEP_TRACKS)
+        if ((rc = b->dalloc(&vd.exc, b->total_samples, false)))
+            return rc;
+    vd.state_stride = vocoder_state_doubles(vd.nmcp);
+    if ((rc = b->dalloc(&vd.state, (size_t)vd.state_stride * n, true)))
+        return rc;
+    const double *np;
+    size_t nl;
+    if ((rc = noise_table(dev, (size_t)maxT * (size_t)vd.fperiod, &np, &nl)))
+        return rc;
+    vd.noise = np;
+    vd.noise_len = nl;
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess)
+        return hip_fail(e, "upload");
+    *out = b.release();
+    return JB_OK;
+}
+
+int Batch::enqueue_paramgen()
+{
+    hipError_t e;
+    for (uint32_t si = 0; si < voice.nstream; si++) {
+        if ((e = launch_prep(bd, sd[si], (int)si, stream)) != hipSuccess)
+            return hip_fail(e, "k_prep");
+        if ((e = launch_mlpg(bd, sd[si], (int)si, stream)) != hipSuccess)
+            return hip_fail(e, "k_mlpg");
+    }
+    if ((e = launch_prologue(bd, vd, stream)) != hipSuccess)
+        return hip_fail(e, "k_prologue");
+    if ((e = launch_pulse(bd, vd, stream)) != hipSuccess)
+        return hip_fail(e, "k_pulse");
+    return JB_OK;
+}
+
+int Batch::run(bool timed)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipSetDevice");
+    if (timed)
+        hipEventRecord(ev0, stream);
+    int rc = enqueue_paramgen();
+    if (rc)
+        return rc;
+    if (timed)
+        hipEventRecord(ev1, stream);
+    if ((e = launch_vocoder(bd, vd, 0, maxT, 0, stream)) != hipSuccess)
+        return hip_fail(e, "k_vocoder");
+    if (timed) {
+        hipEventRecord(ev2, stream);
+    }
+    return JB_OK;
+}
+
+int Batch::sync()
+{
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess)
+        return hip_fail(e, "stream sync");
+    return JB_OK;
+}
+
+int Batch::read(const void *dev, void *dst, size_t bytes)
+{
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess)
+        e = hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipMemcpy(D2H)");
+    return JB_OK;
+}
+
+} // namespace jb
+
+using jb::Batch;
+
+extern "C" {
+
+const char *jb_last_error(void) { return jb::g_err.c_str(); }
+
+const char *jb_version(void) { return "jbonsai_amd 0.1.0 (gfx950; reference jbonsai 0.4.2)"; }
+
+int jb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int jb_device_arch(int dev, char *buf, size_t cap)
+{
+    hipDeviceProp_t p;
+    hipError_t e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess)
+        return jb::hip_fail(e, "hipGetDeviceProperties");
+    snprintf(buf, cap, "%s", p.gcnArchName);
+    return JB_OK;
+}
+
+int jb_batch_create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
+                    const jb_batch_opts *opts, jb_batch **out)
+{
+    if (!out)
+        return JB_ERR_INVALID;
+    Batch *b = nullptr;
+    int rc = Batch::create(voice, utts, n_utts, opts, &b);
+    *out = (jb_batch *)b;
+    return rc;
+}
+
+int jb_batch_run(jb_batch *b) { return b ? ((Batch *)b)->run(false) : JB_ERR_INVALID; }
+int jb_batch_sync(jb_batch *b) { return b ? ((Batch *)b)->sync() : JB_ERR_INVALID; }
+
+int jb_batch_run_timed(jb_batch *hb, float *total_ms, float *vocoder_ms)
+{
+    if (!hb)
+        return JB_ERR_INVALID;
+    Batch *b = (Batch *)hb;
+    int rc = b->run(true);
+    if (rc)
+        return rc;
+    if ((rc = b->sync()))
+        return rc;
+    float t = 0, v = 0;
+    hipEventElapsedTime(&t, b->ev0, b->ev2);
+    hipEventElapsedTime(&v, b->ev1, b->ev2);
+    if (total_ms)
+        *total_ms = t;
+    if (vocoder_ms)
+        *vocoder_ms = v;
+    return JB_OK;
+}
+
+size_t jb_batch_size(const jb_batch *b) { return b ? (size_t)((const Batch *)b)->B : 0; }
+size_t jb_batch_num_frames(const jb_batch *hb, size_t i)
+{
+    const Batch *b = (const Batch *)hb;
+    return (b && i < (size_t)b->B) ? b->T[i] : 0;
+}
+size_t jb_batch_num_samples(const jb_batch *hb, size_t i)
+{
+    const Batch *b = (const Batch *)hb;
+    return (b && i < (size_t)b->B) ? (size_t)b->T[i] * b->voice.fperiod : 0;
+}
+size_t jb_batch_total_samples(const jb_batch *b) { return b ? ((const Batch *)b)->total_samples : 0; }
+size_t jb_batch_pcm_offset(const jb_batch *hb, size_t i)
+{
+    const Batch *b = (const Batch *)hb;
+    return (b && i <= (size_t)b->B) ? (size_t)b->frame_off[i] * b->voice.fperiod : 0;
+}
+void *jb_batch_device_pcm(jb_batch *hb, size_t *n)
+{
+    Batch *b = (Batch *)hb;
+    if (!b)
+        return nullptr;
+    if (n)
+        *n = b->total_samples;
+    return b->vd.pcm;
+}
+
+int jb_batch_read_pcm(jb_batch *hb, size_t i, double *dst, size_t cap)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || i >= (size_t)b->B)
+        return JB_ERR_INVALID;
+    size_t ns = (size_t)b->T[i] * b->voice.fperiod;
+    if (cap < ns) {
+        jb::set_error("pcm buffer too small");
+        return JB_ERR_BUFFER;
+    }
+    if (ns == 0)
+        return JB_OK;
+    if (!dst)
+        return JB_ERR_INVALID;
+    return b->read(b->vd.pcm + (size_t)b->frame_off[i] * b->voice.fperiod, dst, ns * sizeof(double));
+}
+
+int jb_batch_read_track(jb_batch *hb, size_t i, uint32_t si, double *dst, size_t cap)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || i >= (size_t)b->B || si >= b->voice.nstream)
+        return JB_ERR_INVALID;
+    size_t L = (size_t)b->sd[si].L, ne = (size_t)b->T[i] * L;
+    if (cap < ne)
+        return JB_ERR_BUFFER;
+    if (ne == 0)
+        return JB_OK;
+    return b->read(b->sd[si].out + (size_t)b->frame_off[i] * L, dst, ne * sizeof(double));
+}
+
+int jb_batch_read_excitation(jb_batch *hb, size_t i, double *dst, size_t cap)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || i >= (size_t)b->B)
+        return JB_ERR_INVALID;
+    if (!b->vd.exc) {
+        jb::set_error("excitation tap needs JB_BATCH_KEEP_TRACKS");
+        return JB_ERR_INVALID;
+    }
+    size_t ns = (size_t)b->T[i] * b->voice.fperiod;
+    if (cap < ns)
+        return JB_ERR_BUFFER;
+    if (ns == 0)
+        return JB_OK;
+    return b->read(b->vd.exc + (size_t)b->frame_off[i] * b->voice.fperiod, dst, ns * sizeof(double));
+}
+
+void jb_batch_free(jb_batch *b) { delete (Batch *)b; }
+
+int jb_paramgen_vocode_batch(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,
+                             const jb_batch_opts *opts, double *const *pcm, size_t *n_samples)
+{
+    jb_batch *hb = nullptr;
+    int rc = jb_batch_create(voice, utts, n, opts, &hb);
+    if (rc)
+        return rc;
+    std::unique_ptr<Batch> guard((Batch *)hb);
+    if (n_samples)
+        for (size_t i = 0; i < n; i++)
+            n_samples[i] = jb_batch_num_samples(hb, i);
+    if (!pcm)
+        return JB_OK;
+    if ((rc = guard->run(false)) || (rc = guard->sync()))
+        return rc;
+    for (size_t i = 0; i < n; i++) {
+        size_t ns = jb_batch_num_samples(hb, i);
+        if (ns && (rc = jb_batch_read_pcm(hb, i, pcm[i], ns)))
+            return rc;
+    }
+    return JB_OK;
+}
+
+} // extern "C"

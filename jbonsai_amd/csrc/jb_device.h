@@ -1,0 +1,104 @@
+// jb_device.h -- device-side data model and kernel launchers (internal).
+//
+// HBM layout of one batch (B utterances, independent):
+//   * per-utterance descriptor table  UttDev[B]  (pointers into de-duplicated
+//     state arrays; utterances that alias the same host arrays share one copy)
+//   * frame-indexed arrays are concatenated over utterances, utterance b owning
+//     frames [frame_off[b], frame_off[b]+T_b); frame-major, vector dim fastest,
+//     so that "lane = vector dim" (MLPG) and "lane = sample" (PCM) accesses are
+//     coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jb {
+
+constexpr int kMaxStream = 3;
+constexpr int kMaxWin = 8;
+constexpr int kMaxCoef = 32;
+constexpr int kPade = 5;          // MelLogSpectrumApproximation<6>: 5 stages (src/vocoder/mlsa.rs:31)
+constexpr int kGroups = 12;       // lane groups per Pade stage: 5*12 = 60 lanes of a wave64
+constexpr int kMaxTPL = 5;        // taps per lane => nmcp-1 <= 60
+constexpr double kNoData = -1e10; // src/constants.rs:13
+
+struct StreamStatesDev {
+    const double *mean;   // [S][W*L]
+    const double *var;    // [S][W*L]
+    const double *msd;    // [S] or nullptr
+    const double *gv_mean;// [L] or nullptr
+    const double *gv_var; // [L]
+    const uint8_t *gv_switch; // [S]
+    double gv_weight;
+    double msd_threshold;
+};
+
+struct UttDev {
+    uint32_t S;
+    uint32_t T;
+    uint64_t frame_off;       // first frame in concatenated frame arrays
+    uint64_t state_off;       // first state in concatenated state scratch
+    const uint32_t *dur;      // [S]
+    StreamStatesDev st[kMaxStream];
+};
+
+struct StreamDev {
+    int L, W, is_msd, use_gv;
+    int BW;                   // band width = 2*max_width+1 (src/mlpg_adjust/mlpg.rs:27)
+    int win_width[kMaxWin];
+    int win_off[kMaxWin];
+    double win_coef[kMaxCoef];
+    // ---- per-frame scratch written by k_prep (concatenated frames) ----
+    uint32_t *fstate;   // [sumT] state index of frame
+    uint8_t *voiced;    // [sumT]
+    uint8_t *fl, *fr;   // [sumT] boundary distances clipped to 255 (mask.rs:51-82)
+    uint32_t *vidx;     // [sumT] compacted index -> frame (voiced frames only)
+    uint8_t *vsw;       // [sumT] gv switch per compacted frame
+    uint32_t *Tv;       // [B] number of voiced frames
+    uint32_t *gvlen;    // [B] number of switched-on voiced frames
+    // ---- MLPG workspace, each [sumT][L] ----
+    double *A[5];       // un-factored W'U^-1W band (needed again by GV)
+    double *bvec;       // W'U^-1 mu
+    double *F[5];       // LDL^T factors
+    double *g;          // forward-substitution result / GV gradient
+    double *par;        // compacted solution
+    double *out;        // [sumT][L] scattered parameter track (NODATA in unvoiced frames)
+};
+
+struct VocDev {
+    int fs, fperiod, nmcp, nlpf, bs, nblk; // bs = samples per block (divides fperiod, <=64)
+    double alpha, volume;
+    const double *mcp;    // [sumT][nmcp] (MLPG out of stream 0)
+    const double *lf0;    // [sumT]
+    const double *lpf;    // [sumT][nlpf]
+    double *bcoef;        // [sumT][nmcp]  mc2b(mcp)  (src/vocoder/cepstrum.rs:139-149)
+    double *pitch;        // [sumT]  period in samples, 0 = unvoiced
+    double *cur_start;    // [sumT]  pitch_of_curr_point at frame start
+    double *pinc;         // [sumT]  pitch_inc_per_point
+    double *counter_start;// [sumT]  pitch_counter at frame start
+    unsigned long long *pmask; // [sumT][nblk] pulse bit per sample of each block
+    const double *noise;  // [noise_len] shared Gaussian stream
+    uint64_t noise_len;
+    double *pcm;          // [sumT*fperiod]
+    double *exc;          // optional [sumT*fperiod] excitation before gain, or nullptr
+    double *state;        // optional per-utterance filter state (streaming), or nullptr
+    int state_stride;     // doubles per utterance
+};
+
+struct BatchDev {
+    int B;
+    const UttDev *utt;        // device
+    const uint32_t *order;    // [B] launch order (longest first)
+    uint32_t maxT;
+};
+
+// launchers (all asynchronous on `stream`)
+hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
+hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
+hipError_t launch_prologue(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+// frames [t0, t1) of every utterance (t1 clipped to T_b); resume!=0 => load/save vd.state
+hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, uint32_t t0, uint32_t t1, int resume,
+                          hipStream_t stream);
+int vocoder_state_doubles(int nmcp);
+
+} // namespace jb

@@ -1,0 +1,484 @@
+// jb_vocoder.hip -- mixed excitation + MLSA cascade kernels for gfx950 (CDNA4).
+//
+// Restates /root/reference/src/vocoder (Stage::Zero) and src/speech.rs:
+//   k_prologue  V2  pitch from lf0, mc2b            (vocoder/mod.rs:73-77, cepstrum.rs:139-149)
+//   k_pulse     V3  pulse scheduler, per voiced run (excitation.rs:25-33,73-81,102-104)
+//   k_vocoder   V3 (ring buffer as a 31-tap feed-forward FIR), V5 gain,
+//               V6 df1, V7 df2/fir, V8 coefficient interpolation, V9 frame loop.
+//
+// k_vocoder design (one wave64 per utterance, the recursion is time-serial):
+//   * the 5 Pade stages x (nmcp-1) all-pass taps of df2 live in registers,
+//     lane = 12*stage + group, TPL consecutive taps per lane (60 lanes busy);
+//   * the tap recursion rem' = d - a*rem has a constant ratio, so a lane's TPL
+//     taps collapse to (loc, kappa=(-a)^TPL) and the carry across the 12 lanes of a
+//     stage is a segmented weighted Kogge-Stone scan done with DPP row_shr 1/2/4/8
+//     plus one row_bcast:15 step (a 12-lane segment straddles at most one 16-lane
+//     DPP row boundary); per-lane coefficient registers encode segment ends;
+//   * the dot product with c[2..] is the same scan with weights 1;
+//   * a stage's output reaches the next stage's head lane with one wave_shr:1;
+//   * the Pade combine broadcasts the five stage sums with v_readlane;
+//   * excitation for a block of `bs` samples is computed lane-parallel
+//     (lane = sample) into a VGPR and fed to the serial loop with v_readlane;
+//     PCM is collected lane = sample and stored coalesced, bs*8 bytes per store.
+// All arithmetic is f64; fused multiply-adds are written explicitly (the TU is
+// compiled with -ffp-contract=off), sums are re-associated w.r.t. the reference
+// (tolerance: see DESIGN.md; measured ~1e-13 relative).
+#include "jb_device.h"
+
+namespace jb {
+
+// --------------------------------------------------------------------------
+// V2: thread per frame.
+__global__ void k_prologue(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.y;
+    const UttDev u = bd.utt[b];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= u.T)
+        return;
+    const uint64_t f = u.frame_off + t;
+    const double MAX_LF0 = 9.903487552536127, MIN_LF0 = 2.995732273553991; // constants.rs:4-6
+    const double l = vd.lf0[f];
+    double p;
+    if (l == kNoData) {
+        p = 0.0;
+    } else {
+        double cl = l < MIN_LF0 ? MIN_LF0 : (l > MAX_LF0 ? MAX_LF0 : l);
+        p = (double)vd.fs / exp(cl);
+    }
+    vd.pitch[f] = p;
+    const int n = vd.nmcp;
+    const double *mc = vd.mcp + f * (uint64_t)n;
+    double *bc = vd.bcoef + f * (uint64_t)n;
+    if (vd.alpha != 0.0) {
+        double prev = mc[n - 1];
+        bc[n - 1] = prev;
+        for (int i = n - 2; i >= 0; i--) {
+            prev = mc[i] - vd.alpha * prev;
+            bc[i] = prev;
+        }
+    } else {
+        for (int i = 0; i < n; i++)
+            bc[i] = mc[i];
+    }
+}
+
+// --------------------------------------------------------------------------
+// V3 pulse scheduler.  Thread per frame; only the first frame of a voiced run
+// walks its run (the counter is the only state carried across frames: at every
+// frame start pitch_of_curr_point is reset to the previous frame's pitch by
+// Excitation::end, excitation.rs:102-104).
+__global__ void k_pulse(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.y;
+    const UttDev u = bd.utt[b];
+    const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t0 >= u.T)
+        return;
+    const uint64_t base = u.frame_off;
+    const double p0 = vd.pitch[base + t0];
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+    if (p0 == 0.0) {
+        vd.cur_start[base + t0] = 0.0;
+        vd.pinc[base + t0] = 0.0;
+        vd.counter_start[base + t0] = 0.0;
+        for (int q = 0; q < nblk; q++)
+            vd.pmask[(base + t0) * nblk + q] = 0ull;
+        return;
+    }
+    if (t0 > 0 && vd.pitch[base + t0 - 1] != 0.0)
+        return; // not a run start
+    double prevp = 0.0, counter = 0.0;
+    for (uint32_t t = t0; t < u.T; t++) {
+        const double p = vd.pitch[base + t];
+        if (p == 0.0)
+            break;
+        double cur, inc;
+        // Excitation::start (excitation.rs:25-33)
+        if (prevp != 0.0) {
+            cur = prevp;
+            inc = (p - prevp) / (double)fp;
+        } else {
+            inc = 0.0;
+            cur = p;
+            counter = p;
+        }
+        vd.cur_start[base + t] = cur;
+        vd.pinc[base + t] = inc;
+        vd.counter_start[base + t] = counter;
+        int i = 0;
+        for (int q = 0; q < nblk; q++) {
+            unsigned long long mask = 0ull;
+            for (int j = 0; j < bs; j++, i++) {
+                // voiced branch of Excitation::get (excitation.rs:73-81)
+                counter += 1.0;
+                if (counter >= cur) {
+                    counter -= cur;
+                    mask |= 1ull << j;
+                }
+                cur += inc;
+            }
+            vd.pmask[(base + t) * nblk + q] = mask;
+        }
+        prevp = p; // Excitation::end
+    }
+}
+
+// --------------------------------------------------------------------------
+// DPP helpers (f64 moves as two 32-bit DPP movs; invalid source lanes read 0).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
+              DPP_ROW_SHR8 = 0x118, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142;
+
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+struct ScanCoef {
+    double c1, c2, c4, c8, cb;
+};
+
+// segmented weighted inclusive scan over the 12-lane stage segments
+__device__ __forceinline__ double seg_scan(double v, const ScanCoef &k)
+{
+    v = fma(k.c1, dpp_f64<DPP_ROW_SHR1>(v), v);
+    v = fma(k.c2, dpp_f64<DPP_ROW_SHR2>(v), v);
+    v = fma(k.c4, dpp_f64<DPP_ROW_SHR4>(v), v);
+    v = fma(k.c8, dpp_f64<DPP_ROW_SHR8>(v), v);
+    v = fma(k.cb, dpp_f64<DPP_ROW_BCAST15>(v), v);
+    return v;
+}
+
+__device__ __forceinline__ double ipow(double x, int n)
+{
+    double r = 1.0;
+    for (int i = 0; i < n; i++)
+        r *= x;
+    return r;
+}
+
+// PPADE (src/vocoder/mlsa.rs:31)
+__device__ __constant__ double kPPade[6] = {1.00000000000, 0.49993910000, 0.11070980000,
+                                            0.01369984000, 0.00095648530, 0.00003041721};
+
+constexpr int kEStride = 64; // LDS slots per block of excitation source samples
+
+// state layout (doubles): d[TPL][64] | ulane[64] | e11[6] | e12[6] | Eprev[64]
+__host__ __device__ inline int voc_state_doubles(int tpl) { return 64 * tpl + 64 + 6 + 6 + 64; }
+
+template <int TPL>
+__global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t t_begin,
+                                                uint32_t t_end, int resume)
+{
+    const int b = bd.order[blockIdx.x];
+    const UttDev u = bd.utt[b];
+    const uint32_t T = u.T;
+    if (t_end > T)
+        t_end = T;
+    if (t_begin >= t_end)
+        return;
+    const int lane = threadIdx.x;
+    const uint64_t base = u.frame_off;
+    const int nmcp = vd.nmcp, nlpf = vd.nlpf, fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+    const int M = nmcp - 1; // live taps 1..M
+    const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
+
+    // ---- lane roles ----
+    const int s = lane / kGroups, g = lane % kGroups;
+    const bool active = lane < kPade * kGroups;
+    const bool head = active && g == 0;
+    const double kappa = ipow(-a, TPL);
+    ScanCoef kc, ks; // weighted (carry) and unit (sum) coefficients
+    {
+        const int r16 = lane & 15;
+        auto ok = [&](int sh) { return active && g >= sh && r16 >= sh; };
+        kc.c1 = ok(1) ? ipow(kappa, 1) : 0.0;
+        kc.c2 = ok(2) ? ipow(kappa, 2) : 0.0;
+        kc.c4 = ok(4) ? ipow(kappa, 4) : 0.0;
+        kc.c8 = ok(8) ? ipow(kappa, 8) : 0.0;
+        const int rowstart = lane & ~15, segstart = s * kGroups;
+        const bool straddle = active && rowstart > 0 && segstart < rowstart;
+        kc.cb = straddle ? ipow(kappa, lane - rowstart + 1) : 0.0;
+        ks.c1 = kc.c1 != 0.0 ? 1.0 : 0.0;
+        ks.c2 = kc.c2 != 0.0 ? 1.0 : 0.0;
+        ks.c4 = kc.c4 != 0.0 ? 1.0 : 0.0;
+        ks.c8 = kc.c8 != 0.0 ? 1.0 : 0.0;
+        ks.cb = straddle ? 1.0 : 0.0;
+    }
+    const double nh = (active && !head) ? 1.0 : 0.0;           // takes carry from lane-1
+    const double hmask = (head && s > 0) ? 1.0 : 0.0;          // stage input from previous stage
+    const double l0mask = (lane == 0) ? 1.0 : 0.0;             // stage-1 input = d22[0]
+    const double Pl = active ? kPPade[s + 1] : 0.0;
+    // tap indices of this lane: j = g*TPL + k + 1
+    int tapj[TPL];
+    bool dotv[TPL]; // participates in the c[2..] dot product
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+        tapj[k] = g * TPL + k + 1;
+        dotv[k] = active && tapj[k] >= 2 && tapj[k] <= M;
+    }
+
+    // ---- LDS: excitation source ring + LPF taps of current / previous frame ----
+    __shared__ double E[2 * kEStride];
+    __shared__ double taps[2][64];
+
+    // ---- state ----
+    double d[TPL], cd[TPL], cdinc[TPL], ctgt[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; k++)
+        d[k] = 0.0;
+    double ulane = 0.0;
+    double e11[6], e12[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+        e11[i] = e12[i] = 0.0;
+    E[lane] = 0.0;
+    E[kEStride + lane] = 0.0;
+    taps[0][lane] = 0.0;
+    taps[1][lane] = 0.0;
+    if (resume && vd.state && t_begin > 0) {
+        const double *sp = vd.state + (uint64_t)b * (uint64_t)vd.state_stride;
+#pragma unroll
+        for (int k = 0; k < TPL; k++)
+            d[k] = sp[64 * k + lane];
+        ulane = sp[64 * TPL + lane];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            e11[i] = sp[64 * TPL + 64 + i];
+            e12[i] = sp[64 * TPL + 70 + i];
+        }
+        E[lane] = sp[64 * TPL + 76 + lane];
+    }
+    __syncthreads();
+
+    const int anti = (nlpf - 1) / 2;
+
+    for (uint32_t t = t_begin; t < t_end; t++) {
+        const uint64_t f = base + t;
+        // ---- frame setup (vocoder/mod.rs:116-125) ----
+        // c at frame start = previous frame's cc exactly (mod.rs:140); first frame: c = cc.
+        const double *bcur = vd.bcoef + f * (uint64_t)nmcp;
+        const double *bprev = (t > 0) ? bcur - nmcp : bcur;
+#pragma unroll
+        for (int k = 0; k < TPL; k++) {
+            double c0v = dotv[k] ? bprev[tapj[k]] : 0.0;
+            double c1v = dotv[k] ? bcur[tapj[k]] : 0.0;
+            cd[k] = c0v;
+            ctgt[k] = c1v;
+            cdinc[k] = (c1v - c0v) / (double)fp;
+        }
+        double c1 = bprev[1];
+        const double c1inc = (bcur[1] - c1) / (double)fp;
+        const double c0 = bprev[0];
+        const double c0inc = (bcur[0] - c0) / (double)fp;
+        const double pcur = vd.pitch[f];
+        const bool voiced = pcur != 0.0;
+        const bool pvoiced = (t > 0) && vd.pitch[f - 1] != 0.0;
+        const double cur0 = vd.cur_start[f], pinc = vd.pinc[f];
+        // LPF taps of this frame into taps[t&1]; previous frame's stay in taps[(t-1)&1]
+        if (lane < nlpf)
+            taps[t & 1][lane] = vd.lpf[f * (uint64_t)nlpf + lane];
+        if (t == t_begin && t > 0 && lane < nlpf)
+            taps[(t - 1) & 1][lane] = vd.lpf[(f - 1) * (uint64_t)nlpf + lane];
+        __syncthreads();
+
+        for (int q = 0; q < nblk; q++) {
+            const int i0 = q * bs; // first sample of block within frame
+            const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)i0; // within utterance
+            // =========== Phase A: excitation for bs samples, lane = sample ===========
+            double xin = 0.0;
+            {
+                const bool lv = lane < bs;
+                const uint64_t n = n0 + (uint64_t)lane;
+                double nz = 0.0, nz15 = 0.0;
+                if (lv) {
+                    nz = vd.noise[n];
+                    if (n >= (uint64_t)anti)
+                        nz15 = vd.noise[n - (uint64_t)anti];
+                }
+                double e = 0.0;
+                if (lv && voiced) {
+                    const unsigned long long pm = vd.pmask[f * (uint64_t)nblk + q];
+                    double pulse = 0.0;
+                    if ((pm >> lane) & 1ull)
+                        pulse = sqrt(fma((double)(i0 + lane), pinc, cur0));
+                    e = pulse - nz;
+                }
+                E[kEStride + lane] = e;
+                __syncthreads();
+                double x = nz15;
+                // previous block: same frame (q>0) or previous frame (q==0)
+                const bool prevv = (q > 0) ? voiced : pvoiced;
+                if (voiced || prevv) {
+                    const double *tc = taps[t & 1];
+                    const double *tp = (q > 0) ? tc : taps[(t - 1) & 1];
+                    for (int k = 0; k < nlpf; k++) {
+                        const int idx = lane - k;
+                        const double src = idx >= 0 ? E[kEStride + idx] : E[bs + idx];
+                        const double tap = idx >= 0 ? tc[k] : tp[k];
+                        x = fma(src, tap, x);
+                    }
+                }
+                if (vd.exc && lv)
+                    vd.exc[base * (uint64_t)fp + n] = x;
+                // V5 gain with the interpolated c[0] of this sample (mod.rs:129-131)
+                if (x != 0.0)
+                    x *= exp(fma((double)(i0 + lane), c0inc, c0));
+                xin = lv ? x : 0.0;
+                __syncthreads();
+                // roll the source ring: this block becomes "previous"
+                E[lane] = E[kEStride + lane];
+                __syncthreads();
+            }
+            // =========== Phase B: bs serial filter steps ===========
+            double ob = 0.0;
+            for (int i = 0; i < bs; i++) {
+                double x = readlane_f64(xin, i);
+                // ---- V6 df1 (mlsa.rs:54-66), uniform across lanes ----
+                {
+                    double out = 0.0;
+#pragma unroll
+                    for (int ii = 5; ii >= 1; ii--) {
+                        e11[ii] = fma(iaa, e12[ii - 1], a * e11[ii]);
+                        e12[ii] = e11[ii] * c1;
+                        const double v = e12[ii] * kPPade[ii];
+                        x += (ii & 1) ? v : -v;
+                        out += v;
+                    }
+                    e12[0] = x;
+                    x += out;
+                }
+                // ---- V7 df2: five fir() calls at once ----
+                // carry-free aggregate of this lane's taps
+                double loc = d[0];
+#pragma unroll
+                for (int k = 1; k < TPL; k++)
+                    loc = fma(-a, loc, d[k]);
+                double I = fma(kappa, ulane, loc); // ulane != 0 only on head lanes
+                I = seg_scan(I, kc);
+                double r = fma(nh, dpp_f64<DPP_WAVE_SHR1>(I), ulane); // rem entering tap 0 of lane
+#pragma unroll
+                for (int k = 0; k < TPL; k++) {
+                    const double dn = fma(iaa, r, a * d[k]);
+                    r = fma(-a, r, d[k]);
+                    d[k] = dn;
+                }
+                double yl = cd[0] * d[0];
+#pragma unroll
+                for (int k = 1; k < TPL; k++)
+                    yl = fma(cd[k], d[k], yl);
+                const double Y = seg_scan(yl, ks); // stage sums at lanes 12*s+11
+                const double Yp = Y * Pl;
+                const double v1 = readlane_f64(Yp, 11), v2 = readlane_f64(Yp, 23),
+                             v3 = readlane_f64(Yp, 35), v4 = readlane_f64(Yp, 47),
+                             v5 = readlane_f64(Yp, 59);
+                // Pade combine in the reference's order (mlsa.rs:71-78)
+                x += v5;
+                x -= v4;
+                x += v3;
+                x -= v2;
+                x += v1;
+                double out = v5;
+                out += v4;
+                out += v3;
+                out += v2;
+                out += v1;
+                // d22[0] = x feeds stage 1; d22[i] = y_i feeds stage i+1 (next sample)
+                ulane = fma(hmask, dpp_f64<DPP_WAVE_SHR1>(Y), l0mask * x);
+                x += out;
+                // ---- V8 ----
+#pragma unroll
+                for (int k = 0; k < TPL; k++)
+                    cd[k] += cdinc[k];
+                c1 += c1inc;
+                ob = (lane == i) ? x * vol : ob;
+            }
+            if (lane < bs)
+                vd.pcm[base * (uint64_t)fp + n0 + (uint64_t)lane] = ob;
+        }
+        (void)ctgt;
+    }
+
+    if (resume && vd.state) {
+        double *sp = vd.state + (uint64_t)b * (uint64_t)vd.state_stride;
+#pragma unroll
+        for (int k = 0; k < TPL; k++)
+            sp[64 * k + lane] = d[k];
+        sp[64 * TPL + lane] = ulane;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                sp[64 * TPL + 64 + i] = e11[i];
+                sp[64 * TPL + 70 + i] = e12[i];
+            }
+        }
+        sp[64 * TPL + 76 + lane] = E[lane];
+    }
+}
+
+static int tpl_for(int nmcp)
+{
+    int M = nmcp - 1;
+    int tpl = (M + kGroups - 1) / kGroups;
+    return tpl < 1 ? 1 : tpl;
+}
+
+int vocoder_state_doubles(int nmcp) { return voc_state_doubles(tpl_for(nmcp)); }
+
+hipError_t launch_prologue(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
+{
+    if (bd.B == 0 || bd.maxT == 0)
+        return hipSuccess;
+    dim3 grid((bd.maxT + 255) / 256, bd.B), block(256);
+    hipLaunchKernelGGL(k_prologue, grid, block, 0, stream, bd, vd);
+    return hipGetLastError();
+}
+
+hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
+{
+    if (bd.B == 0 || bd.maxT == 0)
+        return hipSuccess;
+    dim3 grid((bd.maxT + 63) / 64, bd.B), block(64);
+    hipLaunchKernelGGL(k_pulse, grid, block, 0, stream, bd, vd);
+    return hipGetLastError();
+}
+
+hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, uint32_t t0, uint32_t t1, int resume,
+                          hipStream_t stream)
+{
+    if (bd.B == 0 || bd.maxT == 0)
+        return hipSuccess;
+    dim3 grid(bd.B), block(64);
+    switch (tpl_for(vd.nmcp)) {
+    case 1:
+        hipLaunchKernelGGL(k_vocoder<1>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        break;
+    case 2:
+        hipLaunchKernelGGL(k_vocoder<2>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        break;
+    case 3:
+        hipLaunchKernelGGL(k_vocoder<3>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        break;
+    case 4:
+        hipLaunchKernelGGL(k_vocoder<4>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        break;
+    case 5:
+        hipLaunchKernelGGL(k_vocoder<5>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+} // namespace jb

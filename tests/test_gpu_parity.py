@@ -1,0 +1,86 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU
+oracle on the same inputs.  Tolerances (f64 device path, sums re-associated):
+  * MLPG+GV tracks: bit-exact expected (same order, no FMA); gate rel 1e-12
+  * excitation: abs 1e-9 on O(1..30) values; pulse positions exactly equal
+  * PCM: relative RMS <= 1e-9 (north_star allows 1e-4), length exact
+"""
+import numpy as np
+import pytest
+
+import jbonsai_amd as J
+from oracle import oracle as O
+from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
+from tests.helpers import oracle_run, oracle_states, rel_rms, to_utt, voice_info
+
+pytestmark = pytest.mark.gpu
+
+PCM_TOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def have_gpu():
+    n = J.lib().jb_device_count()
+    assert n > 0, "no HIP device: the product has no CPU path"
+    return n
+
+
+def test_bonsai_tracks_excitation_pcm(oracle_voice, have_gpu):
+    v = oracle_voice
+    dur, sts = oracle_states(v, SAMPLE_SENTENCE_1)
+    tracks, (pcm, exc, pulse) = oracle_run(v, dur, sts, dumps=True)
+    with J.Batch(voice_info(v), [to_utt(dur, sts)], keep_tracks=True) as b:
+        b.run()
+        b.sync()
+        assert b.num_samples(0) == 66480
+        for si in range(3):
+            got = b.track(0, si)
+            assert got.shape == tracks[si].shape
+            nod = tracks[si] == O.NODATA
+            assert np.array_equal(got == O.NODATA, nod)
+            np.testing.assert_allclose(got, tracks[si], rtol=1e-12, atol=0)
+        gexc = b.excitation(0)
+        np.testing.assert_allclose(gexc, exc, rtol=0, atol=1e-9)
+        got = b.pcm(0)
+    assert rel_rms(got, pcm) <= PCM_TOL
+    # the reference's own goldens (src/lib.rs:44-46), through the GPU
+    assert abs(got[2000] - 19.35141137623778) < 1e-6
+    assert abs(got[30000] - -980.6757547598129) < 1e-6
+
+
+def test_is_this_bonsai_and_speed(oracle_voice, have_gpu):
+    v = oracle_voice
+    utts, refs = [], []
+    for speed in (1.0, 1.4):
+        dur, sts = oracle_states(v, SAMPLE_SENTENCE_2, speed=speed)
+        utts.append(to_utt(dur, sts))
+        refs.append(oracle_run(v, dur, sts)[1])
+    got = J.paramgen_vocode_batch(voice_info(v), utts)
+    assert [len(g) for g in got] == [100800, 72000]
+    for g, r in zip(got, refs):
+        assert rel_rms(g, r) <= PCM_TOL
+    assert abs(got[0][70000] - -1898.2890228814217) < 1e-6
+    assert abs(got[1][71199] - 7.840225089163972) < 1e-6
+
+
+def test_batch_mixed_and_empty(oracle_voice, have_gpu):
+    """Ragged batch: empty utterance, two different sentences, duplicates."""
+    v = oracle_voice
+    d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
+    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+    empty = to_utt(np.zeros(0, np.uint32), [type(s)(s.L, s.W, s.is_msd, s.use_gv, s.win_width, s.win_coef,
+                                                      np.zeros((0, s.W * s.L)), np.zeros((0, s.W * s.L)),
+                                                      np.zeros(0)) for s in s1])
+    u1, u2 = to_utt(d1, s1), to_utt(d2, s2)
+    got = J.paramgen_vocode_batch(voice_info(v), [u1, empty, u2, u1, u2])
+    r1, r2 = oracle_run(v, d1, s1)[1], oracle_run(v, d2, s2)[1]
+    assert len(got[1]) == 0
+    assert rel_rms(got[0], r1) <= PCM_TOL and rel_rms(got[2], r2) <= PCM_TOL
+    assert np.array_equal(got[0], got[3]) and np.array_equal(got[2], got[4])
+
+
+def test_volume_and_gv_weight(oracle_voice, have_gpu):
+    v = oracle_voice
+    dur, sts = oracle_states(v, SAMPLE_SENTENCE_1, gv_weight=(0.7, 1.3, 1.0), msd_threshold=(0.5, 0.3, 0.5))
+    ref = oracle_run(v, dur, sts, volume=0.5)[1]
+    got = J.paramgen_vocode_batch(voice_info(v, volume=0.5), [to_utt(dur, sts)])[0]
+    assert len(got) == len(ref) and rel_rms(got, ref) <= PCM_TOL
