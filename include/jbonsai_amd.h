@@ -198,6 +198,18 @@ const jb_state_utt *jb_states_utt(const jb_states *s);
 const jb_voice_desc *jb_engine_voice_desc(const jb_engine *e);
 void jb_states_free(jb_states *s);
 
+/* Model introspection (pub fields of Voice/Model, src/model/voice/model.rs:12-82).
+ * kind: 0 duration model, 1+s stream model s, 4+s GV model of stream s. */
+int jb_engine_model_shape(const jb_engine *e, size_t voice, int kind, size_t *ntree,
+                          size_t *pdf_len);
+/* pdf table of one tree: *table -> npdf*pdf_len f32 (means, variances, [msd]); engine-owned. */
+int jb_engine_pdf_table(const jb_engine *e, size_t voice, int kind, size_t tree,
+                        const float **table, size_t *npdf);
+/* Model::get_index (src/model/voice/model.rs:51-68): tree_state = matched tree's state
+ * (or -1 when none has that state index), pdf_index 1-based. */
+int jb_engine_tree_index(const jb_engine *e, size_t voice, int kind, int state_index,
+                         const char *label, int *tree_state, int *pdf_index);
+
 /* Engine::generator (src/engine.rs:301) + SpeechGenerator (src/speech.rs:25-96). */
 int jb_generator_new(const jb_engine *e, const char *const *label_lines, size_t n_lines,
                      jb_generator **out);

@@ -7,5 +7,7 @@ thin host-side mirror of the reference's API used by tests and the benchmark.
 from ._ffi import JbError, LIB_PATH, NODATA, build, lib  # noqa: F401
 from .batch import Batch, StreamInfo, StreamStates, Utterance, VoiceInfo, paramgen_vocode_batch  # noqa: F401
 
-__all__ = ["JbError", "LIB_PATH", "NODATA", "build", "lib", "Batch", "StreamInfo", "StreamStates",
+from .engine import Engine, SpeechGenerator  # noqa: F401,E402
+
+__all__ = ["Engine", "SpeechGenerator", "JbError", "LIB_PATH", "NODATA", "build", "lib", "Batch", "StreamInfo", "StreamStates",
            "Utterance", "VoiceInfo", "paramgen_vocode_batch"]

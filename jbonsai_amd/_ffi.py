@@ -96,6 +96,7 @@ SYMBOLS = [
     "jb_engine_set_additional_half_tone", "jb_engine_get_additional_half_tone",
     "jb_engine_num_voices", "jb_engine_num_streams", "jb_engine_num_states",
     "jb_engine_set_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_synthesize_batch",
+    "jb_engine_model_shape", "jb_engine_pdf_table", "jb_engine_tree_index",
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
     "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",
     "jb_generator_total_frames", "jb_generator_step", "jb_generator_free",

@@ -1,0 +1,769 @@
+// jb_engine.cpp -- engine-level C ABI (include/jbonsai_amd.h, part 2).
+//
+// Host front half (cold, per utterance O(labels)): label lines -> per-state pdfs
+// (decision-tree search, multi-voice blend) -> state durations.  Mirrors
+//   Engine / Condition            src/engine.rs:31-366
+//   Labels::load_from_strings     src/label.rs:35-113
+//   Models::{duration,stream,gv}  src/model/mod.rs:80-156
+//   VoiceSet::{new,weighted}      src/model/voice_set.rs:22-95
+//   DurationEstimator             src/duration.rs:20-131
+//   InterporationWeight           src/model/interporation_weight.rs:48-160
+// Everything from the state level down (MLPG, GV, excitation, MLSA) is handed to
+// the HIP batch (jb_batch.cpp); nothing here synthesises audio.
+#include "jb_host.h"
+#include "jb_voice.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace jb {
+
+constexpr double kDB = 0.11512925464970228;        // ln(10)/20, src/constants.rs:11
+constexpr double kHalfTone = 0.05776226504666211;  // ln(2)/12,  src/constants.rs:9
+constexpr double kMaxLf0 = 9.903487552536127, kMinLf0 = 2.995732273553991;
+
+struct Condition {
+    size_t sampling_frequency = 0, fperiod = 0;
+    double volume = 1.0;
+    std::vector<double> msd_threshold, gv_weight;
+    bool phoneme_alignment = false;
+    double speed = 1.0;
+    size_t stage = 0;
+    bool use_log_gain = false;
+    double alpha = 0.0, beta = 0.0, additional_half_tone = 0.0;
+    // InterporationWeight
+    std::vector<double> w_duration;
+    std::vector<std::vector<double>> w_param, w_gv;
+};
+
+struct Engine {
+    std::vector<std::shared_ptr<Voice>> voices;
+    Condition cond;
+    // cached static description for the state-level ABI
+    jb_voice_desc desc{};
+    std::vector<double> win_coef[kMaxStream];
+    void refresh_desc();
+};
+
+void Engine::refresh_desc()
+{
+    const Voice &v = *voices[0];
+    memset(&desc, 0, sizeof desc);
+    desc.sampling_frequency = (uint32_t)cond.sampling_frequency;
+    desc.fperiod = (uint32_t)cond.fperiod;
+    desc.nstream = (uint32_t)v.meta.num_streams;
+    desc.stage = (uint32_t)cond.stage;
+    desc.use_log_gain = cond.use_log_gain;
+    desc.alpha = cond.alpha;
+    desc.beta = cond.beta;
+    desc.volume = cond.volume;
+    for (size_t i = 0; i < v.streams.size() && i < (size_t)kMaxStream; i++) {
+        const StreamModel &s = v.streams[i];
+        jb_stream_desc &d = desc.stream[i];
+        d.vector_length = (uint32_t)s.vector_length;
+        d.num_windows = (uint32_t)s.num_windows;
+        d.is_msd = s.is_msd;
+        d.use_gv = s.use_gv;
+        win_coef[i].clear();
+        for (size_t w = 0; w < s.windows.size() && w < JB_MAX_WINDOW; w++) {
+            d.win_width[w] = (uint32_t)s.windows[w].size();
+            win_coef[i].insert(win_coef[i].end(), s.windows[w].begin(), s.windows[w].end());
+        }
+        d.win_coef = win_coef[i].data();
+    }
+}
+
+// Condition::load_model (src/engine.rs:84-125)
+static int load_condition(Engine &e)
+{
+    const Voice &v = *e.voices[0];
+    Condition &c = e.cond;
+    const size_t ns = (size_t)v.meta.num_streams, nv = e.voices.size();
+    c.sampling_frequency = (size_t)v.meta.sampling_frequency;
+    c.fperiod = (size_t)v.meta.frame_period;
+    c.msd_threshold.assign(ns, 0.5);
+    c.gv_weight.assign(ns, 1.0);
+    for (const std::string &opt : v.streams[0].options) { // options of stream 0 only
+        size_t eq = opt.find('=');
+        if (eq == std::string::npos)
+            continue; // "Skipped unrecognized option"
+        std::string key = opt.substr(0, eq), val = opt.substr(eq + 1);
+        char *end = nullptr;
+        if (key == "GAMMA") {
+            unsigned long g = strtoul(val.c_str(), &end, 10);
+            if (val.empty() || *end) {
+                set_error("Failed to parse option GAMMA");
+                return JB_ERR_PARSE_OPTION;
+            }
+            c.stage = g;
+        } else if (key == "LN_GAIN") {
+            if (val == "1")
+                c.use_log_gain = true;
+            else if (val == "0")
+                c.use_log_gain = false;
+            else {
+                set_error("Failed to parse option LN_GAIN");
+                return JB_ERR_PARSE_OPTION;
+            }
+        } else if (key == "ALPHA") {
+            double a = strtod(val.c_str(), &end);
+            if (val.empty() || *end) {
+                set_error("Failed to parse option ALPHA");
+                return JB_ERR_PARSE_OPTION;
+            }
+            c.alpha = a;
+        }
+    }
+    // InterporationWeight::new(nvoices, nstream): equal weights
+    c.w_duration.assign(nv, 1.0 / (double)nv);
+    c.w_param.assign(ns, c.w_duration);
+    c.w_gv.assign(ns, c.w_duration);
+    return JB_OK;
+}
+
+// VoiceSet::new metadata checks (src/model/voice_set.rs:22-42)
+static int check_voiceset(const std::vector<std::shared_ptr<Voice>> &vs)
+{
+    if (vs.empty()) {
+        set_error("No HTS voice was given.");
+        return JB_ERR_MODEL;
+    }
+    const Voice &f = *vs[0];
+    for (size_t i = 1; i < vs.size(); i++) {
+        const Voice &v = *vs[i];
+        bool ok = v.meta == f.meta && v.streams.size() == f.streams.size();
+        for (size_t s = 0; ok && s < f.streams.size(); s++) {
+            const StreamModel &a = v.streams[s], &b = f.streams[s];
+            ok = a.vector_length == b.vector_length && a.num_windows == b.num_windows &&
+                 a.is_msd == b.is_msd && a.use_gv == b.use_gv && a.options == b.options;
+        }
+        if (!ok) {
+            set_error("The global metadata does not match.");
+            return JB_ERR_MODEL;
+        }
+    }
+    return JB_OK;
+}
+
+// ---- labels ----------------------------------------------------------------
+struct ParsedLabels {
+    std::vector<std::string> labels;
+    std::vector<std::pair<double, double>> times;
+};
+
+// minimal shape check standing in for jlabel's grammar (src/label.rs:65,72)
+static bool label_shape_ok(const std::string &l)
+{
+    return glob_match("*^*-*+*=*/A:*/B:*/C:*/D:*/E:*/F:*/G:*/H:*/I:*/J:*/K:*", l);
+}
+
+static int parse_labels(const Condition &c, const char *const *lines, size_t n, ParsedLabels &out)
+{
+    const double rate = (double)c.sampling_frequency / ((double)c.fperiod * 1e+7);
+    for (size_t i = 0; i < n; i++) {
+        if (!lines[i]) {
+            set_error("null label line");
+            return JB_ERR_LABEL;
+        }
+        std::string line(lines[i]);
+        size_t s1 = line.find(' ');
+        if (s1 != std::string::npos) {
+            size_t s2 = line.find(' ', s1 + 1);
+            if (s2 == std::string::npos) {
+                set_error("Expected a fullcontext-label in " + line);
+                return JB_ERR_LABEL;
+            }
+            char *e1 = nullptr, *e2 = nullptr;
+            std::string a = line.substr(0, s1), b = line.substr(s1 + 1, s2 - s1 - 1);
+            double st = strtod(a.c_str(), &e1), en = strtod(b.c_str(), &e2);
+            if (a.empty() || b.empty() || *e1 || *e2) {
+                set_error("Failed to parse as floating-point number");
+                return JB_ERR_LABEL;
+            }
+            out.times.emplace_back(st * rate, en * rate);
+            out.labels.push_back(line.substr(s2 + 1));
+        } else if (line.empty()) {
+            continue;
+        } else {
+            out.times.emplace_back(-1.0, -1.0);
+            out.labels.push_back(line);
+        }
+        if (!label_shape_ok(out.labels.back())) {
+            set_error("jlabel failed to parse fullcontext-label: " + out.labels.back());
+            return JB_ERR_LABEL;
+        }
+    }
+    // Labels::new (src/label.rs:83-113)
+    auto &t = out.times;
+    for (size_t i = 0; i < t.size(); i++) {
+        if (i + 1 < t.size()) {
+            if (t[i].second < 0.0 && t[i + 1].first >= 0.0)
+                t[i].second = t[i + 1].first;
+            else if (t[i].second >= 0.0 && t[i + 1].first < 0.0)
+                t[i + 1].first = t[i].second;
+        }
+        if (t[i].first < 0.0)
+            t[i].first = -1.0;
+        if (t[i].second < 0.0)
+            t[i].second = -1.0;
+    }
+    return JB_OK;
+}
+
+// ---- durations (src/duration.rs) -------------------------------------------
+struct MV {
+    double mean, vari;
+};
+
+static void estimate_duration(const MV *p, size_t n, double rho, uint32_t *d)
+{
+    for (size_t i = 0; i < n; i++) {
+        double r = std::round(p[i].mean + rho * p[i].vari); // f64::round: half away from zero
+        d[i] = (uint32_t)(r > 1.0 ? r : 1.0);
+    }
+}
+
+static void estimate_with_frame_length(const MV *p, size_t n, double frame_length, uint32_t *d)
+{
+    double tl = std::round(frame_length);
+    const size_t target = (size_t)(tl > 1.0 ? tl : 1.0);
+    if (target <= n) {
+        std::fill(d, d + n, 1u);
+        return;
+    }
+    double mean = 0.0, vari = 0.0;
+    for (size_t i = 0; i < n; i++) {
+        mean = mean + p[i].mean;
+        vari = vari + p[i].vari;
+    }
+    const double rho = ((double)target - mean) / vari;
+    estimate_duration(p, n, rho, d);
+    if (n == 0)
+        return;
+    size_t sum = 0;
+    for (size_t i = 0; i < n; i++)
+        sum += d[i];
+    auto cost = [&](double dd, const MV &q) { return std::fabs(rho - (dd - q.mean) / q.vari); };
+    while (sum != target) {
+        const bool grow = target > sum;
+        size_t best = n;
+        double bc = 0.0;
+        for (size_t i = 0; i < n; i++) {
+            if (!grow && d[i] <= 1)
+                continue;
+            double c = cost((double)d[i] + (grow ? 1.0 : -1.0), p[i]);
+            if (best == n || c < bc) { // first minimum wins (Iterator::min_by)
+                best = i;
+                bc = c;
+            }
+        }
+        if (best == n)
+            break;
+        if (grow) {
+            d[best]++;
+            sum++;
+        } else {
+            d[best]--;
+            sum--;
+        }
+    }
+}
+
+// ---- state construction ------------------------------------------------------
+struct States {
+    jb_state_utt utt{};
+    std::vector<uint32_t> dur;
+    std::vector<double> mean[kMaxStream], var[kMaxStream], msd[kMaxStream], gvm[kMaxStream],
+        gvv[kMaxStream];
+    std::vector<uint8_t> gsw[kMaxStream];
+};
+
+// VoiceSet::weighted (voice_set.rs:80-95): first*w0, then += w_i * param_i, in order.
+template <class F>
+static void blend(const Engine &e, const std::vector<double> &w, size_t len, double *out, F get)
+{
+    const float *p0 = get(*e.voices[0]);
+    for (size_t k = 0; k < len; k++)
+        out[k] = (double)p0[k] * w[0];
+    for (size_t v = 1; v < e.voices.size(); v++) {
+        const float *p = get(*e.voices[v]);
+        for (size_t k = 0; k < len; k++)
+            out[k] += w[v] * (double)p[k];
+    }
+}
+
+static int build_states(const Engine &e, const char *const *lines, size_t n, States &st)
+{
+    const Condition &c = e.cond;
+    const Voice &v0 = *e.voices[0];
+    ParsedLabels pl;
+    int rc = parse_labels(c, lines, n, pl);
+    if (rc)
+        return rc;
+    const size_t nl = pl.labels.size(), ns = (size_t)v0.meta.num_states, S = nl * ns;
+    st.dur.assign(S, 0);
+    try {
+        // Models::duration (model/mod.rs:80-92)
+        std::vector<MV> dp(S);
+        std::vector<double> tmp(2 * ns);
+        for (size_t i = 0; i < nl; i++) {
+            blend(e, c.w_duration, 2 * ns, tmp.data(),
+                  [&](const Voice &v) { return v.duration.get_parameter(2, pl.labels[i]); });
+            for (size_t s = 0; s < ns; s++)
+                dp[i * ns + s] = {tmp[s], tmp[s + ns]};
+        }
+        if (S) {
+            if (c.phoneme_alignment) {
+                // create_with_alignment (duration.rs:41-65)
+                size_t frame_count = 0, next_state = 0, state = 0, nd = 0;
+                for (size_t i = 0; i < nl; i++) {
+                    double end_frame = pl.times[i].second;
+                    if (end_frame >= 0.0) {
+                        size_t cnt = state + ns - next_state;
+                        estimate_with_frame_length(dp.data() + next_state, cnt,
+                                                   end_frame - (double)frame_count, st.dur.data() + nd);
+                        for (size_t k = 0; k < cnt; k++)
+                            frame_count += st.dur[nd + k];
+                        nd += cnt;
+                        next_state = state + ns;
+                    }
+                    state += ns;
+                }
+                // states after the last aligned label get no duration in the reference
+            } else {
+                // create (duration.rs:28-38)
+                estimate_duration(dp.data(), S, 0.0, st.dur.data());
+                if (c.speed != 1.0) {
+                    size_t length = 0;
+                    for (uint32_t d : st.dur)
+                        length += d;
+                    estimate_with_frame_length(dp.data(), S, (double)length / c.speed, st.dur.data());
+                }
+            }
+        }
+        st.utt.num_states = (uint32_t)S;
+        st.utt.durations = st.dur.data();
+        // Models::stream / gv (model/mod.rs:98-146)
+        for (size_t si = 0; si < v0.streams.size() && si < (size_t)kMaxStream; si++) {
+            const StreamModel &sm = v0.streams[si];
+            const size_t WL = (size_t)sm.vector_length * (size_t)sm.num_windows;
+            const size_t plen = 2 * WL + (sm.is_msd ? 1 : 0);
+            st.mean[si].assign(S * WL, 0.0);
+            st.var[si].assign(S * WL, 0.0);
+            st.msd[si].assign(S, DBL_MAX);
+            std::vector<double> buf(plen);
+            for (size_t i = 0; i < nl; i++)
+                for (size_t s = 0; s < ns; s++) {
+                    blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
+                        return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i]);
+                    });
+                    const size_t row = i * ns + s;
+                    std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
+                    std::copy(buf.begin() + WL, buf.begin() + 2 * WL, st.var[si].begin() + row * WL);
+                    if (sm.is_msd)
+                        st.msd[si][row] = buf[2 * WL];
+                }
+            jb_stream_states &o = st.utt.stream[si];
+            o.mean = st.mean[si].data();
+            o.var = st.var[si].data();
+            o.msd = sm.is_msd ? st.msd[si].data() : nullptr;
+            o.gv_weight = c.gv_weight[si];
+            o.msd_threshold = c.msd_threshold[si];
+            if (sm.use_gv && nl > 0) {
+                const size_t L = (size_t)sm.vector_length;
+                std::vector<double> g(2 * L);
+                blend(e, c.w_gv[si], 2 * L, g.data(), [&](const Voice &v) {
+                    return v.streams[si].gv->get_parameter(2, pl.labels[0]); // first label only
+                });
+                st.gvm[si].assign(g.begin(), g.begin() + L);
+                st.gvv[si].assign(g.begin() + L, g.end());
+                st.gsw[si].assign(S, 0);
+                for (size_t i = 0; i < nl; i++) {
+                    uint8_t sw = !v0.gv_off.test(pl.labels[i]);
+                    for (size_t s = 0; s < ns; s++)
+                        st.gsw[si][i * ns + s] = sw;
+                }
+                o.gv_mean = st.gvm[si].data();
+                o.gv_var = st.gvv[si].data();
+                o.gv_switch = st.gsw[si].data();
+            }
+        }
+        // apply_additional_half_tone (stream_parameter.rs:29-37, engine.rs:342-345)
+        if (c.additional_half_tone != 0.0 && v0.streams.size() > 1) {
+            const size_t WL = (size_t)v0.streams[1].vector_length * (size_t)v0.streams[1].num_windows;
+            for (size_t s = 0; s < S; s++) {
+                double x = st.mean[1][s * WL] + c.additional_half_tone * kHalfTone;
+                st.mean[1][s * WL] = std::min(std::max(x, kMinLf0), kMaxLf0);
+            }
+        }
+    } catch (const ModelError &ex) {
+        set_error(std::string("Model error: ") + ex.what());
+        return JB_ERR_MODEL;
+    }
+    return JB_OK;
+}
+
+struct Generator {
+    std::unique_ptr<Batch> batch;
+    size_t fperiod = 0, next = 0, total = 0;
+};
+
+} // namespace jb
+
+using namespace jb;
+
+#define ENG(e) ((jb::Engine *)(e))
+#define CENG(e) ((const jb::Engine *)(e))
+
+extern "C" {
+
+static int finish_load(std::unique_ptr<jb::Engine> &e, jb_engine **out)
+{
+    int rc = check_voiceset(e->voices);
+    if (rc)
+        return rc;
+    if ((rc = load_condition(*e)))
+        return rc;
+    e->refresh_desc();
+    *out = (jb_engine *)e.release();
+    return JB_OK;
+}
+
+int jb_engine_load(const char *const *paths, size_t n, jb_engine **out)
+{
+    if (!out || (n && !paths))
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    std::unique_ptr<jb::Engine> e(new jb::Engine());
+    try {
+        for (size_t i = 0; i < n; i++)
+            e->voices.push_back(load_htsvoice(paths[i]));
+    } catch (const std::exception &ex) {
+        set_error(std::string("Model error: ") + ex.what());
+        return JB_ERR_MODEL;
+    }
+    return finish_load(e, out);
+}
+
+int jb_engine_load_from_bytes(const uint8_t *const *bufs, const size_t *lens, size_t n, jb_engine **out)
+{
+    if (!out || (n && (!bufs || !lens)))
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    std::unique_ptr<jb::Engine> e(new jb::Engine());
+    try {
+        for (size_t i = 0; i < n; i++)
+            e->voices.push_back(parse_htsvoice(bufs[i], lens[i]));
+    } catch (const std::exception &ex) {
+        set_error(std::string("Model error: ") + ex.what());
+        return JB_ERR_MODEL;
+    }
+    return finish_load(e, out);
+}
+
+void jb_engine_free(jb_engine *e) { delete ENG(e); }
+
+// ---- Condition (src/engine.rs:127-243) ----
+int jb_engine_set_sampling_frequency(jb_engine *e, size_t v)
+{
+    ENG(e)->cond.sampling_frequency = std::max<size_t>(v, 1);
+    ENG(e)->refresh_desc();
+    return JB_OK;
+}
+size_t jb_engine_get_sampling_frequency(const jb_engine *e) { return CENG(e)->cond.sampling_frequency; }
+int jb_engine_set_fperiod(jb_engine *e, size_t v)
+{
+    ENG(e)->cond.fperiod = std::max<size_t>(v, 1);
+    ENG(e)->refresh_desc();
+    return JB_OK;
+}
+size_t jb_engine_get_fperiod(const jb_engine *e) { return CENG(e)->cond.fperiod; }
+int jb_engine_set_volume(jb_engine *e, double db)
+{
+    ENG(e)->cond.volume = std::exp(db * kDB);
+    ENG(e)->refresh_desc();
+    return JB_OK;
+}
+double jb_engine_get_volume(const jb_engine *e) { return std::log(CENG(e)->cond.volume) / kDB; }
+int jb_engine_set_msd_threshold(jb_engine *e, size_t s, double v)
+{
+    if (s >= ENG(e)->cond.msd_threshold.size())
+        return JB_ERR_INVALID;
+    ENG(e)->cond.msd_threshold[s] = std::min(std::max(v, 0.0), 1.0);
+    return JB_OK;
+}
+double jb_engine_get_msd_threshold(const jb_engine *e, size_t s)
+{
+    return s < CENG(e)->cond.msd_threshold.size() ? CENG(e)->cond.msd_threshold[s] : NAN;
+}
+int jb_engine_set_gv_weight(jb_engine *e, size_t s, double v)
+{
+    if (s >= ENG(e)->cond.gv_weight.size())
+        return JB_ERR_INVALID;
+    ENG(e)->cond.gv_weight[s] = std::max(v, 0.0);
+    return JB_OK;
+}
+double jb_engine_get_gv_weight(const jb_engine *e, size_t s)
+{
+    return s < CENG(e)->cond.gv_weight.size() ? CENG(e)->cond.gv_weight[s] : NAN;
+}
+int jb_engine_set_phoneme_alignment_flag(jb_engine *e, int f)
+{
+    ENG(e)->cond.phoneme_alignment = f != 0;
+    return JB_OK;
+}
+int jb_engine_get_phoneme_alignment_flag(const jb_engine *e) { return CENG(e)->cond.phoneme_alignment; }
+int jb_engine_set_speed(jb_engine *e, double v)
+{
+    ENG(e)->cond.speed = std::max(v, 1.0E-06);
+    return JB_OK;
+}
+double jb_engine_get_speed(const jb_engine *e) { return CENG(e)->cond.speed; }
+int jb_engine_set_alpha(jb_engine *e, double v)
+{
+    ENG(e)->cond.alpha = std::min(std::max(v, 0.0), 1.0);
+    ENG(e)->refresh_desc();
+    return JB_OK;
+}
+double jb_engine_get_alpha(const jb_engine *e) { return CENG(e)->cond.alpha; }
+int jb_engine_set_beta(jb_engine *e, double v)
+{
+    ENG(e)->cond.beta = std::min(std::max(v, 0.0), 1.0);
+    ENG(e)->refresh_desc();
+    return JB_OK;
+}
+double jb_engine_get_beta(const jb_engine *e) { return CENG(e)->cond.beta; }
+int jb_engine_set_additional_half_tone(jb_engine *e, double v)
+{
+    ENG(e)->cond.additional_half_tone = v;
+    return JB_OK;
+}
+double jb_engine_get_additional_half_tone(const jb_engine *e) { return CENG(e)->cond.additional_half_tone; }
+size_t jb_engine_num_voices(const jb_engine *e) { return CENG(e)->voices.size(); }
+size_t jb_engine_num_streams(const jb_engine *e) { return (size_t)CENG(e)->voices[0]->meta.num_streams; }
+size_t jb_engine_num_states(const jb_engine *e) { return (size_t)CENG(e)->voices[0]->meta.num_states; }
+
+int jb_engine_set_interpolation_weight(jb_engine *e, int which, size_t stream, const double *w, size_t n)
+{
+    Condition &c = ENG(e)->cond;
+    if (!w)
+        return JB_ERR_INVALID;
+    // Weights::new: sum must equal 1.0 within f64::EPSILON (approx default)
+    double sum = 0.0;
+    for (size_t i = 0; i < n; i++)
+        sum += w[i];
+    if (std::fabs(sum - 1.0) > DBL_EPSILON) {
+        set_error("Weights do not sum to 1.0");
+        return JB_ERR_WEIGHT;
+    }
+    if (n != ENG(e)->voices.size()) {
+        set_error("Weights length is invalid; expected " + std::to_string(ENG(e)->voices.size()) +
+                  ", got " + std::to_string(n));
+        return JB_ERR_WEIGHT;
+    }
+    std::vector<double> v(w, w + n);
+    if (which == 0) {
+        c.w_duration = v;
+    } else if (which == 1 || which == 2) {
+        auto &tab = which == 1 ? c.w_param : c.w_gv;
+        if (stream >= tab.size())
+            return JB_ERR_INVALID; // reference: index panic
+        tab[stream] = v;
+    } else {
+        return JB_ERR_INVALID;
+    }
+    return JB_OK;
+}
+
+// ---- model introspection ----
+static const jb::Model *model_of(const jb::Engine *e, size_t voice, int kind)
+{
+    if (voice >= e->voices.size())
+        return nullptr;
+    const Voice &v = *e->voices[voice];
+    if (kind == 0)
+        return &v.duration;
+    if (kind >= 1 && kind <= 3 && (size_t)(kind - 1) < v.streams.size())
+        return &v.streams[(size_t)(kind - 1)].stream;
+    if (kind >= 4 && kind <= 6 && (size_t)(kind - 4) < v.streams.size() &&
+        v.streams[(size_t)(kind - 4)].gv)
+        return &*v.streams[(size_t)(kind - 4)].gv;
+    return nullptr;
+}
+
+int jb_engine_model_shape(const jb_engine *e, size_t voice, int kind, size_t *ntree, size_t *pdf_len)
+{
+    const jb::Model *m = model_of(CENG(e), voice, kind);
+    if (!m)
+        return JB_ERR_INVALID;
+    if (ntree)
+        *ntree = m->trees.size();
+    if (pdf_len)
+        *pdf_len = (size_t)m->pdf_len;
+    return JB_OK;
+}
+
+int jb_engine_pdf_table(const jb_engine *e, size_t voice, int kind, size_t tree, const float **table,
+                        size_t *npdf)
+{
+    const jb::Model *m = model_of(CENG(e), voice, kind);
+    if (!m || tree >= m->trees.size() || !table)
+        return JB_ERR_INVALID;
+    *table = m->pdf[tree].data();
+    if (npdf)
+        *npdf = (size_t)m->npdf[tree];
+    return JB_OK;
+}
+
+int jb_engine_tree_index(const jb_engine *e, size_t voice, int kind, int state_index, const char *label,
+                         int *tree_state, int *pdf_index)
+{
+    const jb::Model *m = model_of(CENG(e), voice, kind);
+    if (!m || !label)
+        return JB_ERR_INVALID;
+    int tp, pi;
+    m->get_index(state_index, label, tp, pi);
+    if (tree_state)
+        *tree_state = tp < 0 ? -1 : m->trees[(size_t)tp].state;
+    if (pdf_index)
+        *pdf_index = pi;
+    return JB_OK;
+}
+
+// ---- states ----
+int jb_engine_states(const jb_engine *e, const char *const *lines, size_t n, jb_states **out)
+{
+    if (!e || !out || (n && !lines))
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    std::unique_ptr<jb::States> st(new jb::States());
+    int rc = build_states(*CENG(e), lines, n, *st);
+    if (rc)
+        return rc;
+    *out = (jb_states *)st.release();
+    return JB_OK;
+}
+const jb_state_utt *jb_states_utt(const jb_states *s) { return s ? &((const jb::States *)s)->utt : nullptr; }
+const jb_voice_desc *jb_engine_voice_desc(const jb_engine *e) { return e ? &CENG(e)->desc : nullptr; }
+void jb_states_free(jb_states *s) { delete (jb::States *)s; }
+
+// ---- synthesize ----
+void jb_pcm_free(double *p) { free(p); }
+
+int jb_synthesize_batch(const jb_engine *e, const char *const *lines, const size_t *line_off,
+                        size_t n_utts, int32_t device, double **pcm, size_t *n_samples)
+{
+    if (!e || !pcm || !n_samples || (n_utts && !line_off))
+        return JB_ERR_INVALID;
+    for (size_t u = 0; u < n_utts; u++) {
+        pcm[u] = nullptr;
+        n_samples[u] = 0;
+    }
+    std::vector<std::unique_ptr<jb::States>> sts(n_utts);
+    std::vector<jb_state_utt> utts(n_utts);
+    for (size_t u = 0; u < n_utts; u++) {
+        sts[u].reset(new jb::States());
+        int rc = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u]);
+        if (rc)
+            return rc;
+        utts[u] = sts[u]->utt;
+    }
+    jb_batch_opts opts{};
+    opts.device = device;
+    jb::Batch *b = nullptr;
+    int rc = jb::Batch::create(&CENG(e)->desc, utts.data(), n_utts, &opts, &b);
+    if (rc)
+        return rc;
+    std::unique_ptr<jb::Batch> guard(b);
+    if ((rc = b->run(false)) || (rc = b->sync()))
+        return rc;
+    for (size_t u = 0; u < n_utts; u++) {
+        size_t ns = (size_t)b->T[u] * b->voice.fperiod;
+        n_samples[u] = ns;
+        if (!ns)
+            continue;
+        pcm[u] = (double *)malloc(ns * sizeof(double));
+        if (!pcm[u])
+            return JB_ERR_INVALID;
+        if ((rc = b->read(b->vd.pcm + (size_t)b->frame_off[u] * b->voice.fperiod, pcm[u],
+                          ns * sizeof(double))))
+            return rc;
+    }
+    return JB_OK;
+}
+
+int jb_synthesize(const jb_engine *e, const char *const *lines, size_t n, double **pcm, size_t *n_samples)
+{
+    if (!pcm || !n_samples)
+        return JB_ERR_INVALID;
+    size_t off[2] = {0, n};
+    return jb_synthesize_batch(e, lines, off, 1, -1, pcm, n_samples);
+}
+
+// ---- generator (src/speech.rs) ----
+int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_generator **out)
+{
+    if (!e || !out)
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    jb::States st;
+    int rc = build_states(*CENG(e), lines, n, st);
+    if (rc)
+        return rc;
+    std::unique_ptr<jb::Generator> g(new jb::Generator());
+    jb_batch_opts opts{};
+    opts.device = -1;
+    jb::Batch *b = nullptr;
+    if ((rc = jb::Batch::create(&CENG(e)->desc, &st.utt, 1, &opts, &b)))
+        return rc;
+    g->batch.reset(b);
+    g->fperiod = b->voice.fperiod;
+    g->total = b->T[0];
+    // Engine::generator runs all three MLPGs before returning (src/engine.rs:333-357)
+    if (hipSetDevice(b->device) != hipSuccess)
+        return JB_ERR_DEVICE;
+    if ((rc = b->enqueue_paramgen()) || (rc = b->sync()))
+        return rc;
+    *out = (jb_generator *)g.release();
+    return JB_OK;
+}
+
+size_t jb_generator_fperiod(const jb_generator *g) { return g ? ((const jb::Generator *)g)->fperiod : 0; }
+size_t jb_generator_synthesized_frames(const jb_generator *g)
+{
+    return g ? ((const jb::Generator *)g)->next : 0;
+}
+size_t jb_generator_total_frames(const jb_generator *g) { return g ? ((const jb::Generator *)g)->total : 0; }
+
+long jb_generator_step(jb_generator *hg, double *buf, size_t buf_len)
+{
+    jb::Generator *g = (jb::Generator *)hg;
+    if (!g)
+        return JB_ERR_INVALID;
+    if (g->total <= g->next)
+        return 0;
+    if (buf_len < g->fperiod || !buf) {
+        set_error("The length of speech buffer must be larger than fperiod.");
+        return JB_ERR_BUFFER;
+    }
+    jb::Batch *b = g->batch.get();
+    if (hipSetDevice(b->device) != hipSuccess)
+        return JB_ERR_DEVICE;
+    hipError_t he = launch_vocoder(b->bd, b->vd, (uint32_t)g->next, (uint32_t)g->next + 1, 1, b->stream);
+    if (he != hipSuccess)
+        return hip_fail(he, "k_vocoder");
+    int rc = b->sync();
+    if (rc)
+        return rc;
+    if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, buf, g->fperiod * sizeof(double))))
+        return rc;
+    g->next++;
+    return (long)g->fperiod;
+}
+
+void jb_generator_free(jb_generator *g) { delete (jb::Generator *)g; }
+
+} // extern "C"
