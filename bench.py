@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- 48 kHz PCM samples/s of the parameter-generation + MLSA-vocoder hot
+path on MI355X (BASELINE.json metric), one process per GPU.
+
+A "step" = one pass of the whole hot path (MLPG+GV x3 -> frame prologue -> pulse
+schedule -> excitation + MLSA cascade) over one batch of synthetic utterances
+whose state-level inputs are already resident in HBM.  N=1 workload = BASELINE
+config 2: batch of 256 copies of the ~128 s utterance (T = 25,546 frames,
+6,131,040 samples each) built from real nitech pdfs (jbonsai_amd/synth.py).
+N>1: every rank runs the same per-GPU workload (weak scaling, no data-path
+collective: utterances are independent); RCCL is used only for the barrier and
+the max-over-ranks of the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+B_ALG = 8.67          # algorithmic bytes per output sample, f64 PCM
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+VOICE = ROOT / "tests" / "golden" / "voice" / "nitech_jp_atr503_m001.htsvoice"
+
+
+def cpu_baseline(utt, vi, n_utts_per_thread=2):
+    """The oracle (C restatement of jbonsai's CPU path, kind="port") on the host cores
+    of this box, on a bounded sample of the same workload."""
+    import numpy as np
+    from oracle import oracle as O
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("JB_CPU_THREADS", "16"))))  # one GPU's CPU share
+    sts = []
+    for i, s in enumerate(utt.streams):
+        si = vi.streams[i]
+        msd = s.msd if s.msd is not None else np.full(len(utt.durations), 1.7976931348623157e308)
+        sts.append(O.StreamStates(si.vector_length, len(si.windows), si.is_msd, si.use_gv,
+                                  [len(w) for w in si.windows], [c for w in si.windows for c in w],
+                                  s.mean, s.var, msd, s.gv_mean, s.gv_var, s.gv_switch))
+    O.lib()
+    nsamp = int(utt.durations.sum()) * vi.fperiod
+
+    def work():
+        for _ in range(n_utts_per_thread):
+            tr = [O.mlpg(s, utt.durations) for s in sts]
+            O.vocoder(vi.sampling_frequency, vi.fperiod, vi.alpha, 1.0, tr[1][:, 0], tr[0], tr[2])
+
+    th = [threading.Thread(target=work) for _ in range(cores)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = nsamp * n_utts_per_thread * cores
+    return {
+        "value": total / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+        "sample": f"{n_utts_per_thread * cores} utterances of {nsamp} samples (same synthetic "
+                  f"utterance as the GPU batch), one per thread x {n_utts_per_thread}, "
+                  f"{dt:.2f} s wall; C restatement of jbonsai's CPU path (oracle/), gcc -O2",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=0, help="frames per utterance (0 = 25,546 = ~128 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # first: so that this process uses ONE HIP runtime (same SONAME as ours)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+
+    import jbonsai_amd as J
+    from jbonsai_amd import synth
+
+    eng = J.Engine.load([VOICE])
+    tab = synth.VoiceTables(eng)
+    vi = eng.voice_info()
+    frames = args.frames or synth.T_128S
+    # every utterance of the batch is the same sequence (BASELINE config 2: "256 copies"),
+    # uploaded once and aliased; outputs / workspace / filter state are per utterance
+    utt = synth.synth_utterance(tab, frames, 0)
+    batch = J.Batch(vi, [utt] * args.batch, device=local_rank)
+    samples_per_step = batch.total_samples
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        batch.run()
+        batch.sync()
+    barrier()
+    t0 = time.perf_counter()
+    voc_ms = []
+    for _ in range(args.steps):
+        # run_timed = run + sync with HIP events on the batch's own stream
+        tot, voc = batch.run_timed()
+        voc_ms.append(voc)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total = samples_per_step * world * args.steps
+        value = total / dt
+        voc_avg_ms = sum(voc_ms) / len(voc_ms)
+        achieved = B_ALG * samples_per_step / (voc_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = ROOT / "profiles" / "traffic.json"
+        if tf.exists():
+            try:
+                tj = json.loads(tf.read_text())
+                if tj.get("batch") == args.batch and tj.get("frames") == frames:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "48 kHz PCM samples/sec (whole node), batched utterances",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"batch={args.batch}/GPU copies of a {frames}-frame "
+                            f"({frames * vi.fperiod / vi.sampling_frequency:.1f} s) synthetic state-level "
+                            "utterance from real nitech pdfs (BASELINE config 2), nitech voice",
+                "batch_per_gpu": args.batch, "frames_per_utterance": frames,
+                "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
+            },
+            "realtime_factor": value / vi.sampling_frequency,
+            "roofline": {
+                "bound": "hbm", "kernel": "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel_ms": voc_avg_ms, "alg_bytes_per_sample": B_ALG,
+                "note": "recursive IIR: serial-chain / VALU-issue bound, not HBM bound (DESIGN.md)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(utt, vi)
+        print(json.dumps(out), flush=True)
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

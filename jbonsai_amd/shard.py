@@ -1,0 +1,35 @@
+"""Multi-GPU sharding of a batch of independent utterances.
+
+Utterances share only read-only tables, so the path shards with no data-path
+collective: static LPT (longest-processing-time-first) partition by frame count so
+that the sum of frames per GPU is balanced; one process per GPU."""
+from __future__ import annotations
+
+import heapq
+from typing import List, Sequence
+
+
+def lpt_partition(lengths: Sequence[int], n_parts: int) -> List[List[int]]:
+    """Indices of `lengths` assigned to each of n_parts bins, longest first onto the
+    currently lightest bin.  Deterministic; every index appears exactly once."""
+    if n_parts <= 0:
+        raise ValueError("n_parts must be positive")
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    heap = [(0, p) for p in range(n_parts)]
+    heapq.heapify(heap)
+    parts: List[List[int]] = [[] for _ in range(n_parts)]
+    for i in order:
+        load, p = heapq.heappop(heap)
+        parts[p].append(i)
+        heapq.heappush(heap, (load + int(lengths[i]), p))
+    return parts
+
+
+def shard_for_rank(lengths: Sequence[int], rank: int, world: int) -> List[int]:
+    return lpt_partition(lengths, world)[rank]
+
+
+def imbalance(lengths: Sequence[int], parts: List[List[int]]) -> float:
+    loads = [sum(int(lengths[i]) for i in p) for p in parts]
+    mean = sum(loads) / max(1, len(loads))
+    return (max(loads) / mean) if mean > 0 else 1.0
