@@ -99,7 +99,8 @@ typedef struct jb_batch_opts {
     uint32_t reserved[6];
 } jb_batch_opts;
 
-#define JB_BATCH_KEEP_TRACKS 1u /* keep MLPG parameter tracks readable (tests) */
+#define JB_BATCH_KEEP_TRACKS 1u  /* keep MLPG parameter tracks readable (tests) */
+#define JB_BATCH_GENERIC_MLPG 2u /* un-fused, reference-shaped MLPG kernels (A/B parity tests) */
 
 typedef struct jb_batch jb_batch;
 

@@ -22,6 +22,7 @@ ERRORS = {
     -5: "JB_ERR_LABEL", -6: "JB_ERR_PARSE_OPTION", -7: "JB_ERR_WEIGHT", -8: "JB_ERR_BUFFER",
 }
 BATCH_KEEP_TRACKS = 1
+BATCH_GENERIC_MLPG = 2
 
 
 class JbError(RuntimeError):

@@ -96,7 +96,7 @@ class Batch:
     """A batch of utterances resident in HBM (jb_batch_*)."""
 
     def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
-                 keep_tracks: bool = False):
+                 keep_tracks: bool = False, generic_mlpg: bool = False):
         L = F.lib()
         self._L = L
         self.voice = voice
@@ -106,7 +106,8 @@ class Batch:
         for i, u in enumerate(self._utts):
             arr[i] = u.c_struct()
         opts = F.BatchOpts()
-        opts.device, opts.flags = device, (F.BATCH_KEEP_TRACKS if keep_tracks else 0)
+        opts.device = device
+        opts.flags = (F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
         h = C.c_void_p()
         F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
         self._h = h

@@ -280,7 +280,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->frame_off.resize(n + 1);
     std::vector<UttDev> hu(n);
     uint64_t sumT = 0, sumS = 0;
-    uint32_t maxT = 0;
+    uint32_t maxT = 0, maxS = 0;
     for (size_t i = 0; i < n; i++) {
         const jb_state_utt &u = utts[i];
         if (u.num_states && !u.durations)
@@ -301,6 +301,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         sumT += T;
         sumS += u.num_states;
         maxT = std::max(maxT, (uint32_t)T);
+        maxS = std::max(maxS, u.num_states);
         const void *dp;
         if ((rc = b->upload(u.durations, sizeof(uint32_t) * u.num_states, &dp)))
             return rc;
@@ -363,6 +364,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->bd.utt = dutt;
     b->bd.order = dord;
     b->bd.maxT = maxT;
+    b->bd.maxS = maxS;
 
     // ---- per-stream scratch + MLPG workspace ----
     for (uint32_t si = 0; si < voice->nstream; si++) {
@@ -383,17 +385,27 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
             maxw = std::max(maxw, sd.win_width[w]);
         }
         sd.BW = (maxw / 2) * 2 + 1; // Windows::max_width()*2+1 (window.rs:19-21, mlpg.rs:27)
-        const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L;
+        sd.generic_solver = (b->flags & JB_BATCH_GENERIC_MLPG) ? 1 : 0;
+        const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L, nst = (size_t)sumS;
+        if ((rc = b->dalloc(&sd.s_start, nst, false)) || (rc = b->dalloc(&sd.s_vpre, nst, false)) ||
+            (rc = b->dalloc(&sd.s_rstart, nst, false)) || (rc = b->dalloc(&sd.s_rend, nst, false)) ||
+            (rc = b->dalloc(&sd.s_voiced, nst, false)))
+            return rc;
         if ((rc = b->dalloc(&sd.fstate, nf, false)) || (rc = b->dalloc(&sd.voiced, nf, false)) ||
             (rc = b->dalloc(&sd.fl, nf, false)) || (rc = b->dalloc(&sd.fr, nf, false)) ||
             (rc = b->dalloc(&sd.vidx, nf, false)) || (rc = b->dalloc(&sd.vsw, nf, false)) ||
             (rc = b->dalloc(&sd.Tv, n, true)) || (rc = b->dalloc(&sd.gvlen, n, true)))
             return rc;
-        for (int j = 0; j < sd.BW; j++)
-            if ((rc = b->dalloc(&sd.A[j], nfl, false)) || (rc = b->dalloc(&sd.F[j], nfl, false)))
+        const bool is_static = sd.BW == 1 && sd.W == 1 && !sd.use_gv && !sd.generic_solver;
+        if (!is_static) {
+            for (int j = 0; j < sd.BW; j++)
+                if ((rc = b->dalloc(&sd.A[j], nfl, false)) || (rc = b->dalloc(&sd.F[j], nfl, false)))
+                    return rc;
+            if ((rc = b->dalloc(&sd.bvec, nfl, false)) || (rc = b->dalloc(&sd.g, nfl, false)) ||
+                (rc = b->dalloc(&sd.par, nfl, false)))
                 return rc;
-        if ((rc = b->dalloc(&sd.bvec, nfl, false)) || (rc = b->dalloc(&sd.g, nfl, false)) ||
-            (rc = b->dalloc(&sd.par, nfl, false)) || (rc = b->dalloc(&sd.out, nfl, false)))
+        }
+        if ((rc = b->dalloc(&sd.out, nfl, false)))
             return rc;
     }
 

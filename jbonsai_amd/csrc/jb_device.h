@@ -47,7 +47,14 @@ struct StreamDev {
     int win_width[kMaxWin];
     int win_off[kMaxWin];
     double win_coef[kMaxCoef];
-    // ---- per-frame scratch written by k_prep (concatenated frames) ----
+    int generic_solver;       // 1: force the un-fused reference-shaped solver (A/B tests)
+    // ---- per-state scratch written by k_prep_states (concatenated states) ----
+    uint32_t *s_start;  // [sumS] first frame of state
+    uint32_t *s_vpre;   // [sumS] voiced frames before state (compaction offset)
+    uint32_t *s_rstart; // [sumS] first frame of the voiced run containing the state
+    uint32_t *s_rend;   // [sumS] last frame of that run
+    uint8_t *s_voiced;  // [sumS]
+    // ---- per-frame scratch written by k_prep_frames (concatenated frames) ----
     uint32_t *fstate;   // [sumT] state index of frame
     uint8_t *voiced;    // [sumT]
     uint8_t *fl, *fr;   // [sumT] boundary distances clipped to 255 (mask.rs:51-82)
@@ -89,6 +96,7 @@ struct BatchDev {
     const UttDev *utt;        // device
     const uint32_t *order;    // [B] launch order (longest first)
     uint32_t maxT;
+    uint32_t maxS;
 };
 
 // launchers (all asynchronous on `stream`)

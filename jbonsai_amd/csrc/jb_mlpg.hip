@@ -22,58 +22,91 @@
 namespace jb {
 
 // --------------------------------------------------------------------------
-// A1/A2: one lane per utterance; three short serial sweeps.
-__global__ void k_prep(BatchDev bd, StreamDev sd, int si)
+// A1/A2 in two steps.  The MSD flag is constant within a state, so run boundaries,
+// compaction offsets and boundary distances are decided per STATE (serial over S,
+// one lane per utterance: S ~ 7.5k for 128 s), then expanded per FRAME in parallel.
+__global__ void k_prep_states(BatchDev bd, StreamDev sd, int si)
 {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= bd.B)
         return;
-    const UttDev u = bd.utt[b];
-    const StreamStatesDev st = u.st[si];
-    const uint64_t base = u.frame_off;
-    uint32_t t = 0;
+    const UttDev *up = bd.utt + b;
+    const StreamStatesDev st = up->st[si];
+    struct { uint32_t S, T; uint64_t frame_off, state_off; const uint32_t *dur; } u = {
+        up->S, up->T, up->frame_off, up->state_off, up->dur};
+    const uint64_t sb = u.state_off;
+    uint32_t t = 0, k = 0, gl = 0;
+    uint32_t run_start = 0;
+    bool prev_v = false;
     for (uint32_t s = 0; s < u.S; s++) {
         // msd.unwrap_or(f64::MAX) > threshold  (model/mod.rs:113, mask.rs:24)
-        double msd = st.msd ? st.msd[s] : 1.7976931348623157e308;
-        uint8_t v = msd > st.msd_threshold;
-        uint32_t d = u.dur[s];
-        for (uint32_t i = 0; i < d; i++, t++) {
-            sd.fstate[base + t] = s;
-            sd.voiced[base + t] = v;
+        const double msd = st.msd ? st.msd[s] : 1.7976931348623157e308;
+        const bool v = msd > st.msd_threshold;
+        const uint32_t d = u.dur[s];
+        if (v && !prev_v)
+            run_start = t;
+        sd.s_start[sb + s] = t;
+        sd.s_vpre[sb + s] = k;
+        sd.s_rstart[sb + s] = run_start;
+        sd.s_voiced[sb + s] = v;
+        if (v) {
+            k += d;
+            if (st.gv_switch && st.gv_switch[s])
+                gl += d;
         }
+        if (d > 0)
+            prev_v = v;
+        t += d;
     }
-    const uint32_t T = t;
-    uint32_t left = 0, k = 0, gl = 0;
-    for (uint32_t f = 0; f < T; f++) {
-        if (sd.voiced[base + f]) {
-            uint32_t dl = f - left;
-            sd.fl[base + f] = dl > 255 ? 255 : (uint8_t)dl;
-            sd.vidx[base + k] = f;
-            uint8_t sw = st.gv_switch ? st.gv_switch[sd.fstate[base + f]] : 0;
-            sd.vsw[base + k] = sw;
-            gl += sw;
-            k++;
-        } else {
-            left = f + 1;
-            sd.fl[base + f] = 0;
-        }
-    }
-    if (T > 0) {
-        uint32_t right = T - 1;
-        for (uint32_t f = T; f-- > 0;) {
-            if (sd.voiced[base + f]) {
-                uint32_t dr = right - f;
-                sd.fr[base + f] = dr > 255 ? 255 : (uint8_t)dr;
-            } else {
-                sd.fr[base + f] = 0;
-                if (f == 0)
-                    break;
-                right = f - 1;
-            }
-        }
+    // run ends: backward sweep (mask.rs:66-79)
+    uint32_t run_end = 0;
+    bool next_v = false;
+    uint32_t tt = t;
+    for (uint32_t s = u.S; s-- > 0;) {
+        const uint32_t d = u.dur[s];
+        tt -= d;
+        const bool v = sd.s_voiced[sb + s];
+        if (v && !next_v)
+            run_end = tt + d - 1; // last frame of the voiced run
+        sd.s_rend[sb + s] = run_end;
+        if (d > 0)
+            next_v = v;
     }
     sd.Tv[b] = k;
     sd.gvlen[b] = gl;
+}
+
+// thread per state: expand to frames
+__global__ void k_prep_frames(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    struct { uint32_t S, T; uint64_t frame_off, state_off; const uint32_t *dur; } u = {
+        up->S, up->T, up->frame_off, up->state_off, up->dur};
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= u.S)
+        return;
+    const uint8_t *gv_switch = up->st[si].gv_switch;
+    const uint64_t sb = u.state_off, base = u.frame_off;
+    const uint32_t t0 = sd.s_start[sb + s], d = u.dur[s];
+    const bool v = sd.s_voiced[sb + s];
+    const uint32_t k0 = sd.s_vpre[sb + s], rs = sd.s_rstart[sb + s], re = sd.s_rend[sb + s];
+    const uint8_t sw = (gv_switch && v) ? gv_switch[s] : 0;
+    for (uint32_t i = 0; i < d; i++) {
+        const uint32_t t = t0 + i;
+        sd.fstate[base + t] = s;
+        sd.voiced[base + t] = v;
+        if (v) {
+            const uint32_t dl = t - rs, dr = re - t;
+            sd.fl[base + t] = dl > 255 ? 255 : (uint8_t)dl;
+            sd.fr[base + t] = dr > 255 ? 255 : (uint8_t)dr;
+            sd.vidx[base + k0 + i] = t;
+            sd.vsw[base + k0 + i] = sw;
+        } else {
+            sd.fl[base + t] = 0;
+            sd.fr[base + t] = 0;
+        }
+    }
 }
 
 // MeanVari::with_ivar (model/mean_vari.rs:21-31)
@@ -93,7 +126,8 @@ template <int BW>
 __global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
 {
     const int b = blockIdx.y;
-    const UttDev u = bd.utt[b];
+    const UttDev *up = bd.utt + b;
+    struct { uint64_t frame_off; } u = {up->frame_off};
     const uint32_t Tv = sd.Tv[b];
     const int L = sd.L, W = sd.W;
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,7 +135,7 @@ __global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
         return;
     const uint32_t k = (uint32_t)(tid / L);
     const int m = (int)(tid % L);
-    const StreamStatesDev st = u.st[si];
+    const StreamStatesDev st = up->st[si];
     const uint64_t base = u.frame_off;
     double wuw[BW];
 #pragma unroll
@@ -160,8 +194,10 @@ __global__ void k_mlpg_solve(BatchDev bd, StreamDev sd, int si)
     const int L = sd.L;
     if (m >= L)
         return;
-    const UttDev u = bd.utt[b];
-    const StreamStatesDev st = u.st[si];
+    const UttDev *up = bd.utt + b;
+    const StreamStatesDev st = up->st[si];
+    struct { uint32_t S, T; uint64_t frame_off, state_off; const uint32_t *dur; } u = {
+        up->S, up->T, up->frame_off, up->state_off, up->dur};
     const uint32_t T = u.T;
     const uint32_t Tv = sd.Tv[b];
     const uint64_t base = u.frame_off;
@@ -334,12 +370,335 @@ __global__ void k_mlpg_solve(BatchDev bd, StreamDev sd, int si)
 #undef IX
 }
 
+// --------------------------------------------------------------------------
+// Single static window [c], no GV (the LPF stream): the band system is diagonal,
+// D = c*ivar*c, g = c*ivar*mean, par = g/D (mlpg.rs:25-115 with width 1), so the
+// whole MlpgAdjust::create is elementwise: thread per (frame, dim), no workspace.
+__global__ void k_mlpg_static(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    struct { uint32_t T; uint64_t frame_off; } u = {up->T, up->frame_off};
+    const int L = sd.L;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (uint64_t)u.T * L)
+        return;
+    const uint32_t t = (uint32_t)(tid / L);
+    const int m = (int)(tid % L);
+    const uint64_t base = u.frame_off;
+    double v = kNoData;
+    if (sd.voiced[base + t]) {
+        const StreamStatesDev st = up->st[si];
+        const uint32_t s = sd.fstate[base + t];
+        const uint64_t pi = (uint64_t)s * (uint64_t)L + (uint64_t)m;
+        const double c = sd.win_coef[0];
+        const double wu = c * with_ivar(st.var[pi]);
+        const double wum = 0.0 + wu * st.mean[pi];
+        const double d0 = 0.0 + wu * c;
+        v = wum / d0;
+    }
+    sd.out[(base + t) * (uint64_t)L + (uint64_t)m] = v;
+}
+
+// --------------------------------------------------------------------------
+// A5-A9 for band width 3 (static + delta + accel windows): same arithmetic and
+// summation order as k_mlpg_solve<3>, restructured for the memory system:
+//   * every t-loop streams its arrays in chunks of U frames, the next chunk's
+//     loads are issued before the current chunk's dependent arithmetic
+//     (a lone wave per CU has nothing else to hide HBM latency with);
+//   * passes are fused wherever the reference's order of additions allows
+//     (mean of the next GV iteration accumulates while par is updated, variance +
+//     gradient + objective in one sweep): 15 sweeps instead of 31.
+constexpr int MU = 8;
+
+template <bool NONMSD>
+__global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = sd.L;
+    if (m >= L)
+        return;
+    const UttDev *up = bd.utt + b;
+    const StreamStatesDev st = up->st[si];
+    struct { uint32_t S, T; uint64_t frame_off, state_off; const uint32_t *dur; } u = {
+        up->S, up->T, up->frame_off, up->state_off, up->dur};
+    const uint32_t T = u.T;
+    const uint32_t n = sd.Tv[b];
+    const uint64_t base = u.frame_off;
+    const uint64_t o0 = base * (uint64_t)L + (uint64_t)m;
+    const uint64_t Ls = (uint64_t)L;
+#define IX(k) (o0 + (uint64_t)(k) * Ls)
+#define LD(dst, arr, tb)                                                                         \
+    _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++)                                            \
+    {                                                                                            \
+        const uint32_t t_ = (tb) + (uint32_t)u_;                                                 \
+        dst[u_] = t_ < n ? (arr)[IX(t_)] : 0.0;                                                  \
+    }
+#define LDR(dst, arr, tb) /* descending: element n-1-(tb+u) */                                   \
+    _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++)                                            \
+    {                                                                                            \
+        const uint32_t t_ = (tb) + (uint32_t)u_;                                                 \
+        dst[u_] = t_ < n ? (arr)[IX(n - 1 - t_)] : 0.0;                                          \
+    }
+#define CP(dst, src) _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++) dst[u_] = src[u_];
+
+    const bool gv_on = sd.use_gv && st.gv_mean && sd.gvlen[b] > 0;
+    const uint8_t *sw = sd.vsw + base;
+    double *const A0 = sd.A[0], *const A1 = sd.A[1], *const A2 = sd.A[2], *const Bv = sd.bvec;
+    double *const F0 = sd.F[0], *const F1 = sd.F[1], *const F2 = sd.F[2], *const Gv = sd.g;
+    double *const Pv = sd.par, *const Ov = sd.out;
+
+    if (n > 0) {
+        // ---- pass F: ldl_factorization + forward substitution (mlpg.rs:79-105) ----
+        {
+            double a0[MU], a1[MU], a2[MU], bb[MU], a0n[MU], a1n[MU], a2n[MU], bbn[MU];
+            LD(a0, A0, 0) LD(a1, A1, 0) LD(a2, A2, 0) LD(bb, Bv, 0)
+            double p1_0 = 0, p1_1 = 0, p1_2 = 0, p2_0 = 0, p2_2 = 0, g1 = 0, g2 = 0;
+            for (uint32_t tb = 0; tb < n; tb += MU) {
+                LD(a0n, A0, tb + MU) LD(a1n, A1, tb + MU) LD(a2n, A2, tb + MU) LD(bbn, Bv, tb + MU)
+#pragma unroll
+                for (int uu = 0; uu < MU; uu++) {
+                    const uint32_t t = tb + (uint32_t)uu;
+                    if (t < n) {
+                        double r0 = a0[uu], r1 = a1[uu], r2 = a2[uu], g = bb[uu];
+                        if (t >= 1)
+                            r0 -= p1_1 * p1_1 * p1_0;
+                        if (t >= 2)
+                            r0 -= p2_2 * p2_2 * p2_0;
+                        if (t >= 1)
+                            r1 -= p1_1 * p1_2 * p1_0;
+                        r1 /= r0;
+                        r2 /= r0;
+                        if (t >= 1)
+                            g -= p1_1 * g1;
+                        if (t >= 2)
+                            g -= p2_2 * g2;
+                        F0[IX(t)] = r0;
+                        F1[IX(t)] = r1;
+                        F2[IX(t)] = r2;
+                        Gv[IX(t)] = g;
+                        p2_0 = p1_0;
+                        p2_2 = p1_2;
+                        g2 = g1;
+                        p1_0 = r0;
+                        p1_1 = r1;
+                        p1_2 = r2;
+                        g1 = g;
+                    }
+                }
+                CP(a0, a0n) CP(a1, a1n) CP(a2, a2n) CP(bb, bbn)
+            }
+        }
+        // ---- pass B: backward substitution (mlpg.rs:106-113), t descending ----
+        {
+            double f0[MU], f1[MU], f2[MU], gg[MU], f0n[MU], f1n[MU], f2n[MU], ggn[MU];
+            LDR(f0, F0, 0) LDR(f1, F1, 0) LDR(f2, F2, 0) LDR(gg, Gv, 0)
+            double q1 = 0, q2 = 0;
+            for (uint32_t tb = 0; tb < n; tb += MU) {
+                LDR(f0n, F0, tb + MU) LDR(f1n, F1, tb + MU) LDR(f2n, F2, tb + MU) LDR(ggn, Gv, tb + MU)
+#pragma unroll
+                for (int uu = 0; uu < MU; uu++) {
+                    const uint32_t r = tb + (uint32_t)uu;
+                    if (r < n) {
+                        const uint32_t t = n - 1 - r;
+                        double p = gg[uu] / f0[uu];
+                        if (t + 1 < n)
+                            p -= f1[uu] * q1;
+                        if (t + 2 < n)
+                            p -= f2[uu] * q2;
+                        if (NONMSD && !gv_on)
+                            Ov[IX(t)] = p; // scatter fused: every frame is voiced
+                        else
+                            Pv[IX(t)] = p;
+                        q2 = q1;
+                        q1 = p;
+                    }
+                }
+                CP(f0, f0n) CP(f1, f1n) CP(f2, f2n) CP(gg, ggn)
+            }
+        }
+        // ---- GV (mlpg.rs:145-292) ----
+        if (gv_on) {
+            const double gv_mean = st.gv_mean[m] * st.gv_weight; // mlpg.rs:135-137
+            const double gv_vari = st.gv_var[m];
+            const double glen = (double)sd.gvlen[b];
+            double mean, vari;
+            double pc[MU], pn[MU];
+            // conv_gv (mlpg.rs:195-203): mean, variance, rescale; the rescale sweep
+            // also accumulates the sum for iteration 1's mean (same order of additions)
+            double ssum = 0.0;
+            LD(pc, Pv, 0)
+            for (uint32_t tb = 0; tb < n; tb += MU) {
+                LD(pn, Pv, tb + MU)
+#pragma unroll
+                for (int uu = 0; uu < MU; uu++) {
+                    const uint32_t t = tb + (uint32_t)uu;
+                    if (t < n && sw[t])
+                        ssum += pc[uu];
+                }
+                CP(pc, pn)
+            }
+            mean = ssum / glen;
+            double vsum = 0.0;
+            LD(pc, Pv, 0)
+            for (uint32_t tb = 0; tb < n; tb += MU) {
+                LD(pn, Pv, tb + MU)
+#pragma unroll
+                for (int uu = 0; uu < MU; uu++) {
+                    const uint32_t t = tb + (uint32_t)uu;
+                    if (t < n && sw[t])
+                        vsum += (pc[uu] - mean) * (pc[uu] - mean);
+                }
+                CP(pc, pn)
+            }
+            vari = vsum / glen;
+            {
+                const double ratio = sqrt(gv_mean / vari);
+                ssum = 0.0;
+                LD(pc, Pv, 0)
+                for (uint32_t tb = 0; tb < n; tb += MU) {
+                    LD(pn, Pv, tb + MU)
+#pragma unroll
+                    for (int uu = 0; uu < MU; uu++) {
+                        const uint32_t t = tb + (uint32_t)uu;
+                        if (t < n && sw[t]) {
+                            const double p = ratio * (pc[uu] - mean) + mean;
+                            Pv[IX(t)] = p;
+                            ssum += p;
+                        }
+                    }
+                    CP(pc, pn)
+                }
+            }
+            double step = 0.1, prev = 0.0; // STEPINIT
+            const double length = (double)n;
+            const double wgt = 1.0 / (double)((uint64_t)sd.W * (uint64_t)n);
+            const double ll = (double)((uint64_t)n * (uint64_t)n);
+            const double lm1 = (double)(n - 1);
+            for (int it = 1; it <= 5; it++) { // GV_MAX_ITERATION
+                mean = ssum / glen; // calc_gv, first half (sum accumulated by the previous sweep)
+                // ---- sweep V: variance + calc_hmmobj_derivative (mlpg.rs:173-229) ----
+                double hmmobj = 0.0;
+                vsum = 0.0;
+                {
+                    double a0[MU], a1[MU], a2[MU], bb[MU], a0n[MU], a1n[MU], a2n[MU], bbn[MU];
+                    // par stream runs 2 frames ahead: pc[u] = par[t+2]
+                    LD(a0, A0, 0) LD(a1, A1, 0) LD(a2, A2, 0) LD(bb, Bv, 0) LD(pc, Pv, 2)
+                    double pm2 = 0, pm1 = 0, p0 = Pv[IX(0)], pp1 = n > 1 ? Pv[IX(1)] : 0.0;
+                    double a1m1 = 0, a2m1 = 0, a2m2 = 0;
+                    for (uint32_t tb = 0; tb < n; tb += MU) {
+                        LD(a0n, A0, tb + MU) LD(a1n, A1, tb + MU) LD(a2n, A2, tb + MU)
+                        LD(bbn, Bv, tb + MU) LD(pn, Pv, tb + MU + 2)
+#pragma unroll
+                        for (int uu = 0; uu < MU; uu++) {
+                            const uint32_t t = tb + (uint32_t)uu;
+                            if (t < n) {
+                                const double pp2 = pc[uu];
+                                if (sw[t])
+                                    vsum += (p0 - mean) * (p0 - mean);
+                                double g = a0[uu] * p0;
+                                if (t + 1 < n)
+                                    g += a1[uu] * pp1;
+                                if (t >= 1)
+                                    g += a1m1 * pm1;
+                                if (t + 2 < n)
+                                    g += a2[uu] * pp2;
+                                if (t >= 2)
+                                    g += a2m2 * pm2;
+                                Gv[IX(t)] = g;
+                                hmmobj += 1.0 * wgt * p0 * (bb[uu] - 0.5 * g);
+                                pm2 = pm1;
+                                pm1 = p0;
+                                p0 = pp1;
+                                pp1 = pp2;
+                                a2m2 = a2m1;
+                                a2m1 = a2[uu];
+                                a1m1 = a1[uu];
+                            }
+                        }
+                        CP(a0, a0n) CP(a1, a1n) CP(a2, a2n) CP(bb, bbn) CP(pc, pn)
+                    }
+                }
+                vari = vsum / glen;
+                const double gvobj = -0.5 * 1.0 * vari * gv_vari * (vari - 2.0 * gv_mean);
+                const double obj = -(hmmobj + gvobj);
+                if (it > 1) {
+                    if (obj > prev)
+                        step *= 0.5; // STEPDEC
+                    else if (obj < prev)
+                        step *= 1.2; // STEPINC
+                }
+                // ---- sweep N: next_step (mlpg.rs:230-258) + sum for the next mean ----
+                const double dv = -2.0 * gv_vari * (vari - gv_mean) / length;
+                ssum = 0.0;
+                {
+                    double a0[MU], bb[MU], gg[MU], a0n[MU], bbn[MU], ggn[MU];
+                    LD(a0, A0, 0) LD(bb, Bv, 0) LD(gg, Gv, 0) LD(pc, Pv, 0)
+                    for (uint32_t tb = 0; tb < n; tb += MU) {
+                        LD(a0n, A0, tb + MU) LD(bbn, Bv, tb + MU) LD(ggn, Gv, tb + MU) LD(pn, Pv, tb + MU)
+#pragma unroll
+                        for (int uu = 0; uu < MU; uu++) {
+                            const uint32_t t = tb + (uint32_t)uu;
+                            if (t < n) {
+                                const double p = pc[uu];
+                                const double h = -1.0 * wgt * a0[uu] -
+                                                 1.0 * 2.0 / ll *
+                                                     (lm1 * gv_vari * (vari - gv_mean) +
+                                                      2.0 * gv_vari * (p - mean) * (p - mean));
+                                const bool on = sw[t];
+                                double next_g;
+                                if (on)
+                                    next_g = 1.0 / h *
+                                             (1.0 * wgt * (-gg[uu] + bb[uu]) + 1.0 * dv * (p - mean));
+                                else
+                                    next_g = 1.0 / h * (1.0 * wgt * (-gg[uu] + bb[uu]));
+                                const double pnew = p + step * next_g;
+                                if (NONMSD && it == 5)
+                                    Ov[IX(t)] = pnew; // scatter fused into the last sweep
+                                else
+                                    Pv[IX(t)] = pnew;
+                                if (on)
+                                    ssum += pnew;
+                            }
+                        }
+                        CP(a0, a0n) CP(bb, bbn) CP(gg, ggn) CP(pc, pn)
+                    }
+                }
+                prev = obj;
+            }
+        }
+    }
+    // ---- A9 scatter with NODATA (mask.rs:34-49, mod.rs:89-91); MSD streams only ----
+    if (!NONMSD) {
+        uint32_t k = 0;
+        for (uint32_t t = 0; t < T; t++) {
+            double v = kNoData;
+            if (sd.voiced[base + t]) {
+                v = Pv[IX(k)];
+                k++;
+            }
+            Ov[IX(t)] = v;
+        }
+    }
+#undef IX
+#undef LD
+#undef LDR
+#undef CP
+}
+
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
 {
     if (bd.B == 0)
         return hipSuccess;
-    dim3 grid((bd.B + 63) / 64), block(64);
-    hipLaunchKernelGGL(k_prep, grid, block, 0, stream, bd, sd, si);
+    {
+        dim3 grid((bd.B + 63) / 64), block(64);
+        hipLaunchKernelGGL(k_prep_states, grid, block, 0, stream, bd, sd, si);
+    }
+    if (bd.maxS > 0) {
+        dim3 grid((bd.maxS + 127) / 128, bd.B), block(128);
+        hipLaunchKernelGGL(k_prep_frames, grid, block, 0, stream, bd, sd, si);
+    }
     return hipGetLastError();
 }
 
@@ -355,13 +714,28 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
     }
     {
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
-        hipLaunchKernelGGL(k_mlpg_solve<BW>, grid, block, 0, stream, bd, sd, si);
+        if (BW == 3 && !sd.generic_solver) {
+            if (sd.is_msd)
+                hipLaunchKernelGGL(k_mlpg_solve3<false>, grid, block, 0, stream, bd, sd, si);
+            else
+                hipLaunchKernelGGL(k_mlpg_solve3<true>, grid, block, 0, stream, bd, sd, si);
+        } else {
+            hipLaunchKernelGGL(k_mlpg_solve<BW>, grid, block, 0, stream, bd, sd, si);
+        }
     }
     return hipGetLastError();
 }
 
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
 {
+    if (sd.BW == 1 && sd.W == 1 && !sd.use_gv && !sd.generic_solver) {
+        const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
+        if (work == 0 || bd.B == 0)
+            return hipSuccess;
+        dim3 grid((unsigned)((work + 255) / 256), bd.B), block(256);
+        hipLaunchKernelGGL(k_mlpg_static, grid, block, 0, stream, bd, sd, si);
+        return hipGetLastError();
+    }
     switch (sd.BW) {
     case 1:
         return launch_mlpg_bw<1>(bd, sd, si, stream);

@@ -84,3 +84,23 @@ def test_volume_and_gv_weight(oracle_voice, have_gpu):
     ref = oracle_run(v, dur, sts, volume=0.5)[1]
     got = J.paramgen_vocode_batch(voice_info(v, volume=0.5), [to_utt(dur, sts)])[0]
     assert len(got) == len(ref) and rel_rms(got, ref) <= PCM_TOL
+
+
+def test_fused_mlpg_equals_generic_bitwise(oracle_voice, have_gpu):
+    """The chunk-prefetched / pass-fused BW=3 solver, the elementwise static-window
+    kernel and the state-level prep keep the reference's order of operations: their
+    tracks must equal the un-fused generic kernels' bit for bit, and the oracle's
+    within rel 1e-12."""
+    v = oracle_voice
+    dur, sts = oracle_states(v, SAMPLE_SENTENCE_2)
+    tracks = [O.mlpg(s, dur) for s in sts]
+    outs = []
+    for generic in (False, True):
+        with J.Batch(voice_info(v), [to_utt(dur, sts)], keep_tracks=True, generic_mlpg=generic) as b:
+            b.run()
+            b.sync()
+            outs.append([b.track(0, si) for si in range(3)])
+    for si in range(3):
+        assert np.array_equal(outs[0][si], outs[1][si]), si
+        np.testing.assert_allclose(outs[0][si], tracks[si], rtol=1e-12, atol=0)
+        print("stream", si, "bit-exact vs oracle:", np.array_equal(outs[0][si], tracks[si]))
