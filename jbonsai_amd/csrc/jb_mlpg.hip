@@ -409,7 +409,10 @@ __global__ void k_mlpg_static(BatchDev bd, StreamDev sd, int si)
 //   * passes are fused wherever the reference's order of additions allows
 //     (mean of the next GV iteration accumulates while par is updated, variance +
 //     gradient + objective in one sweep): 15 sweeps instead of 31.
-constexpr int MU = 8;
+#ifndef JB_MU
+#define JB_MU 8
+#endif
+constexpr int MU = JB_MU;
 
 template <bool NONMSD>
 __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, int si)
@@ -433,13 +436,19 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
     _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++)                                            \
     {                                                                                            \
         const uint32_t t_ = (tb) + (uint32_t)u_;                                                 \
-        dst[u_] = t_ < n ? (arr)[IX(t_)] : 0.0;                                                  \
+        dst[u_] = (arr)[IX(t_ < n ? t_ : n - 1)];                                                \
+    }
+#define LDS8(dst, arr, tb) /* u8 stream (gv switch), same chunking */                            \
+    _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++)                                            \
+    {                                                                                            \
+        const uint32_t t_ = (tb) + (uint32_t)u_;                                                 \
+        dst[u_] = (arr)[t_ < n ? t_ : n - 1];                                                    \
     }
 #define LDR(dst, arr, tb) /* descending: element n-1-(tb+u) */                                   \
     _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++)                                            \
     {                                                                                            \
         const uint32_t t_ = (tb) + (uint32_t)u_;                                                 \
-        dst[u_] = t_ < n ? (arr)[IX(n - 1 - t_)] : 0.0;                                          \
+        dst[u_] = (arr)[IX(t_ < n ? n - 1 - t_ : 0)];                                            \
     }
 #define CP(dst, src) _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++) dst[u_] = src[u_];
 
@@ -525,50 +534,51 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
             const double glen = (double)sd.gvlen[b];
             double mean, vari;
             double pc[MU], pn[MU];
+            uint8_t wc[MU], wn[MU];
             // conv_gv (mlpg.rs:195-203): mean, variance, rescale; the rescale sweep
             // also accumulates the sum for iteration 1's mean (same order of additions)
             double ssum = 0.0;
-            LD(pc, Pv, 0)
+            LD(pc, Pv, 0) LDS8(wc, sw, 0)
             for (uint32_t tb = 0; tb < n; tb += MU) {
-                LD(pn, Pv, tb + MU)
+                LD(pn, Pv, tb + MU) LDS8(wn, sw, tb + MU)
 #pragma unroll
                 for (int uu = 0; uu < MU; uu++) {
                     const uint32_t t = tb + (uint32_t)uu;
-                    if (t < n && sw[t])
+                    if (t < n && wc[uu])
                         ssum += pc[uu];
                 }
-                CP(pc, pn)
+                CP(pc, pn) CP(wc, wn)
             }
             mean = ssum / glen;
             double vsum = 0.0;
-            LD(pc, Pv, 0)
+            LD(pc, Pv, 0) LDS8(wc, sw, 0)
             for (uint32_t tb = 0; tb < n; tb += MU) {
-                LD(pn, Pv, tb + MU)
+                LD(pn, Pv, tb + MU) LDS8(wn, sw, tb + MU)
 #pragma unroll
                 for (int uu = 0; uu < MU; uu++) {
                     const uint32_t t = tb + (uint32_t)uu;
-                    if (t < n && sw[t])
+                    if (t < n && wc[uu])
                         vsum += (pc[uu] - mean) * (pc[uu] - mean);
                 }
-                CP(pc, pn)
+                CP(pc, pn) CP(wc, wn)
             }
             vari = vsum / glen;
             {
                 const double ratio = sqrt(gv_mean / vari);
                 ssum = 0.0;
-                LD(pc, Pv, 0)
+                LD(pc, Pv, 0) LDS8(wc, sw, 0)
                 for (uint32_t tb = 0; tb < n; tb += MU) {
-                    LD(pn, Pv, tb + MU)
+                    LD(pn, Pv, tb + MU) LDS8(wn, sw, tb + MU)
 #pragma unroll
                     for (int uu = 0; uu < MU; uu++) {
                         const uint32_t t = tb + (uint32_t)uu;
-                        if (t < n && sw[t]) {
+                        if (t < n && wc[uu]) {
                             const double p = ratio * (pc[uu] - mean) + mean;
                             Pv[IX(t)] = p;
                             ssum += p;
                         }
                     }
-                    CP(pc, pn)
+                    CP(pc, pn) CP(wc, wn)
                 }
             }
             double step = 0.1, prev = 0.0; // STEPINIT
@@ -584,18 +594,18 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
                 {
                     double a0[MU], a1[MU], a2[MU], bb[MU], a0n[MU], a1n[MU], a2n[MU], bbn[MU];
                     // par stream runs 2 frames ahead: pc[u] = par[t+2]
-                    LD(a0, A0, 0) LD(a1, A1, 0) LD(a2, A2, 0) LD(bb, Bv, 0) LD(pc, Pv, 2)
+                    LD(a0, A0, 0) LD(a1, A1, 0) LD(a2, A2, 0) LD(bb, Bv, 0) LD(pc, Pv, 2) LDS8(wc, sw, 0)
                     double pm2 = 0, pm1 = 0, p0 = Pv[IX(0)], pp1 = n > 1 ? Pv[IX(1)] : 0.0;
                     double a1m1 = 0, a2m1 = 0, a2m2 = 0;
                     for (uint32_t tb = 0; tb < n; tb += MU) {
                         LD(a0n, A0, tb + MU) LD(a1n, A1, tb + MU) LD(a2n, A2, tb + MU)
-                        LD(bbn, Bv, tb + MU) LD(pn, Pv, tb + MU + 2)
+                        LD(bbn, Bv, tb + MU) LD(pn, Pv, tb + MU + 2) LDS8(wn, sw, tb + MU)
 #pragma unroll
                         for (int uu = 0; uu < MU; uu++) {
                             const uint32_t t = tb + (uint32_t)uu;
                             if (t < n) {
                                 const double pp2 = pc[uu];
-                                if (sw[t])
+                                if (wc[uu])
                                     vsum += (p0 - mean) * (p0 - mean);
                                 double g = a0[uu] * p0;
                                 if (t + 1 < n)
@@ -617,7 +627,7 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
                                 a1m1 = a1[uu];
                             }
                         }
-                        CP(a0, a0n) CP(a1, a1n) CP(a2, a2n) CP(bb, bbn) CP(pc, pn)
+                        CP(a0, a0n) CP(a1, a1n) CP(a2, a2n) CP(bb, bbn) CP(pc, pn) CP(wc, wn)
                     }
                 }
                 vari = vsum / glen;
@@ -634,9 +644,10 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
                 ssum = 0.0;
                 {
                     double a0[MU], bb[MU], gg[MU], a0n[MU], bbn[MU], ggn[MU];
-                    LD(a0, A0, 0) LD(bb, Bv, 0) LD(gg, Gv, 0) LD(pc, Pv, 0)
+                    LD(a0, A0, 0) LD(bb, Bv, 0) LD(gg, Gv, 0) LD(pc, Pv, 0) LDS8(wc, sw, 0)
                     for (uint32_t tb = 0; tb < n; tb += MU) {
                         LD(a0n, A0, tb + MU) LD(bbn, Bv, tb + MU) LD(ggn, Gv, tb + MU) LD(pn, Pv, tb + MU)
+                        LDS8(wn, sw, tb + MU)
 #pragma unroll
                         for (int uu = 0; uu < MU; uu++) {
                             const uint32_t t = tb + (uint32_t)uu;
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
                                                  1.0 * 2.0 / ll *
                                                      (lm1 * gv_vari * (vari - gv_mean) +
                                                       2.0 * gv_vari * (p - mean) * (p - mean));
-                                const bool on = sw[t];
+                                const bool on = wc[uu] != 0;
                                 double next_g;
                                 if (on)
                                     next_g = 1.0 / h *
@@ -662,29 +673,42 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
                                     ssum += pnew;
                             }
                         }
-                        CP(a0, a0n) CP(bb, bbn) CP(gg, ggn) CP(pc, pn)
+                        CP(a0, a0n) CP(bb, bbn) CP(gg, ggn) CP(pc, pn) CP(wc, wn)
                     }
                 }
                 prev = obj;
             }
         }
     }
-    // ---- A9 scatter with NODATA (mask.rs:34-49, mod.rs:89-91); MSD streams only ----
-    if (!NONMSD) {
-        uint32_t k = 0;
-        for (uint32_t t = 0; t < T; t++) {
-            double v = kNoData;
-            if (sd.voiced[base + t]) {
-                v = Pv[IX(k)];
-                k++;
-            }
-            Ov[IX(t)] = v;
-        }
-    }
+    // A9 scatter for MSD streams: k_mlpg_scatter (time-parallel)
 #undef IX
 #undef LD
 #undef LDR
+#undef LDS8
 #undef CP
+}
+
+// A9 Mask::fill with NODATA (mask.rs:34-49, mod.rs:89-91) for MSD streams:
+// thread per (frame, dim); compacted index = s_vpre[state] + offset within state.
+__global__ void k_mlpg_scatter(BatchDev bd, StreamDev sd)
+{
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    const uint32_t T = up->T;
+    const uint64_t base = up->frame_off, sb = up->state_off;
+    const int L = sd.L;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (uint64_t)T * L)
+        return;
+    const uint32_t t = (uint32_t)(tid / L);
+    const int m = (int)(tid % L);
+    double v = kNoData;
+    if (sd.voiced[base + t]) {
+        const uint32_t s_ = sd.fstate[base + t];
+        const uint32_t k = sd.s_vpre[sb + s_] + (t - sd.s_start[sb + s_]);
+        v = sd.par[(base + k) * (uint64_t)L + (uint64_t)m];
+    }
+    sd.out[(base + t) * (uint64_t)L + (uint64_t)m] = v;
 }
 
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
@@ -715,9 +739,11 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
     {
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         if (BW == 3 && !sd.generic_solver) {
-            if (sd.is_msd)
+            if (sd.is_msd) {
                 hipLaunchKernelGGL(k_mlpg_solve3<false>, grid, block, 0, stream, bd, sd, si);
-            else
+                dim3 g2((unsigned)((work + 255) / 256), bd.B), b2(256);
+                hipLaunchKernelGGL(k_mlpg_scatter, g2, b2, 0, stream, bd, sd);
+            } else
                 hipLaunchKernelGGL(k_mlpg_solve3<true>, grid, block, 0, stream, bd, sd, si);
         } else {
             hipLaunchKernelGGL(k_mlpg_solve<BW>, grid, block, 0, stream, bd, sd, si);
