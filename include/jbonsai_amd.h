@@ -94,13 +94,25 @@ typedef struct jb_state_utt {
 } jb_state_utt;
 
 typedef struct jb_batch_opts {
-    int32_t device;       /* HIP device ordinal; -1 = current */
-    uint32_t flags;       /* JB_BATCH_* */
-    uint32_t reserved[6];
+    int32_t device;         /* HIP device ordinal; -1 = current */
+    uint32_t flags;         /* JB_BATCH_* */
+    uint32_t chunk_frames;  /* vocoder time-chunk length in frames; 0 = auto */
+    uint32_t warmup_frames; /* frames each chunk starts early from zero state; 0 = default (32) */
+    double verify_tol;      /* chunk hand-off check: max|state diff| <= tol*max|state|; 0 = default (1e-9) */
+    uint32_t reserved[2];
 } jb_batch_opts;
 
 #define JB_BATCH_KEEP_TRACKS 1u  /* keep MLPG parameter tracks readable (tests) */
 #define JB_BATCH_GENERIC_MLPG 2u /* un-fused, reference-shaped MLPG kernels (A/B parity tests) */
+#define JB_BATCH_SERIAL 4u       /* one wave per utterance, no time-chunking (reference-shaped recursion) */
+
+/* Time-chunked vocoder (default).  The MLSA recursion is time-serial per utterance
+ * (src/vocoder/mlsa.rs), but it forgets its initial state within ~16 frames (measured:
+ * <=2e-11 relative after 16, rounding floor after 24; tools/warmup_study.py).  Each
+ * utterance is cut into chunks that start `warmup_frames` early from zero state; a
+ * device-side check then requires every chunk's warmed-up filter state to match its
+ * predecessor's end state within verify_tol, and any chunk that fails is recomputed
+ * serially from that end state, so the result is certified against the serial one. */
 
 typedef struct jb_batch jb_batch;
 
@@ -129,6 +141,10 @@ int jb_batch_read_excitation(jb_batch *b, size_t utt, double *dst, size_t cap);
  * by the caller); utterance i starts at sample jb_batch_pcm_offset(b,i). */
 void *jb_batch_device_pcm(jb_batch *b, size_t *n_samples);
 size_t jb_batch_pcm_offset(const jb_batch *b, size_t utt);
+/* Execution facts of the last run: chunk length / warm-up actually used, number of
+ * vocoder work items, and how many chunks failed the hand-off check and were redone. */
+int jb_batch_info(const jb_batch *b, uint32_t *chunk_frames, uint32_t *warmup_frames,
+                  uint32_t *n_items, uint32_t *n_redo);
 void jb_batch_free(jb_batch *b);
 
 /* One-shot convenience: create + run + read + free.  pcm[i] must hold

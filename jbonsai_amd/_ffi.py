@@ -23,6 +23,7 @@ ERRORS = {
 }
 BATCH_KEEP_TRACKS = 1
 BATCH_GENERIC_MLPG = 2
+BATCH_SERIAL = 4
 
 
 class JbError(RuntimeError):
@@ -78,7 +79,8 @@ class StateUtt(C.Structure):
 
 
 class BatchOpts(C.Structure):
-    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 6)]
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("chunk_frames", C.c_uint32),
+                ("warmup_frames", C.c_uint32), ("verify_tol", C.c_double), ("reserved", C.c_uint32 * 2)]
 
 
 # every symbol include/jbonsai_amd.h declares (checked by tests/test_abi.py)
@@ -86,7 +88,7 @@ SYMBOLS = [
     "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_size",
     "jb_batch_num_frames", "jb_batch_num_samples", "jb_batch_total_samples", "jb_batch_read_pcm",
     "jb_batch_read_track", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
-    "jb_batch_free", "jb_paramgen_vocode_batch",
+    "jb_batch_info", "jb_batch_free", "jb_paramgen_vocode_batch",
     "jb_engine_load", "jb_engine_load_from_bytes", "jb_engine_free",
     "jb_engine_set_sampling_frequency", "jb_engine_get_sampling_frequency",
     "jb_engine_set_fperiod", "jb_engine_get_fperiod", "jb_engine_set_volume", "jb_engine_get_volume",
@@ -150,6 +152,7 @@ def lib():
     L.jb_batch_read_excitation.argtypes = [vp, sz, vp, sz]
     L.jb_batch_device_pcm.restype = vp
     L.jb_batch_device_pcm.argtypes = [vp, C.POINTER(sz)]
+    L.jb_batch_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.jb_batch_free.argtypes = [vp]
     L.jb_batch_free.restype = None
     L.jb_paramgen_vocode_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz,

@@ -96,7 +96,8 @@ class Batch:
     """A batch of utterances resident in HBM (jb_batch_*)."""
 
     def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
-                 keep_tracks: bool = False, generic_mlpg: bool = False):
+                 keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
+                 chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0):
         L = F.lib()
         self._L = L
         self.voice = voice
@@ -107,7 +108,9 @@ class Batch:
             arr[i] = u.c_struct()
         opts = F.BatchOpts()
         opts.device = device
-        opts.flags = (F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
+        opts.flags = ((F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
+                      | (F.BATCH_SERIAL if serial else 0))
+        opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
         h = C.c_void_p()
         F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
         self._h = h
@@ -126,6 +129,12 @@ class Batch:
         t, v = C.c_float(), C.c_float()
         F.check(self._L.jb_batch_run_timed(self._h, C.byref(t), C.byref(v)))
         return t.value, v.value
+
+    def info(self):
+        """(chunk_frames, warmup_frames, n_items, n_redo) of the last run."""
+        v = [C.c_uint32() for _ in range(4)]
+        F.check(self._L.jb_batch_info(self._h, *[C.byref(x) for x in v]))
+        return dict(chunk_frames=v[0].value, warmup_frames=v[1].value, n_items=v[2].value, n_redo=v[3].value)
 
     def num_samples(self, i):
         return self._L.jb_batch_num_samples(self._h, i)

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -450,10 +451,106 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         return rc;
     vd.noise = np;
     vd.noise_len = nl;
+    if ((rc = b->build_work(opts)))
+        return rc;
     e = hipDeviceSynchronize();
     if (e != hipSuccess)
         return hip_fail(e, "upload");
     *out = b.release();
+    return JB_OK;
+}
+
+// Work list of the vocoder: serial = one item per utterance; chunked = items of
+// chunk_frames output frames that start warmup_frames early from zero state.
+int Batch::build_work(const jb_batch_opts *opts)
+{
+    const bool serial = (flags & JB_BATCH_SERIAL) != 0;
+    warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 32;
+    verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
+    uint32_t ch = opts ? opts->chunk_frames : 0;
+    if (serial) {
+        ch = 0;
+    } else if (ch == 0) {
+        // auto: enough items to fill 1024 SIMDs several waves deep, chunks >= 4x the warm-up
+        uint64_t target = 24576;
+        if (const char *e = getenv("JB_CHUNK_TARGET"))
+            target = strtoull(e, nullptr, 10);
+        uint64_t c = target ? (sumT + target - 1) / target : 0;
+        ch = (uint32_t)std::max<uint64_t>(c, 4ull * warmup_frames);
+        ch = (ch + 7) / 8 * 8;
+    }
+    chunk_frames = ch;
+    work.clear();
+    const int stride = vd.state_stride;
+    for (int i = 0; i < B; i++) {
+        const uint32_t Ti = T[(size_t)i];
+        if (Ti == 0)
+            continue;
+        if (ch == 0 || Ti <= ch + warmup_frames) {
+            work.push_back(VocWork{(uint32_t)i, 0, 0, Ti, nullptr, nullptr, nullptr});
+            continue;
+        }
+        for (uint32_t t0 = 0; t0 < Ti; t0 += ch) {
+            VocWork w{};
+            w.utt = (uint32_t)i;
+            w.t_out = t0;
+            w.t_start = t0 > warmup_frames ? t0 - warmup_frames : 0;
+            w.t_end = std::min(Ti, t0 + ch);
+            work.push_back(w);
+        }
+    }
+    // longest utterances first for the serial case; chunk items are uniform
+    if (ch == 0)
+        std::stable_sort(work.begin(), work.end(), [&](const VocWork &a, const VocWork &c) {
+            return (a.t_end - a.t_start) > (c.t_end - c.t_start);
+        });
+    n_items = (uint32_t)work.size();
+    int rc;
+    if ((rc = dalloc(&work_dev, n_items, false)) || (rc = dalloc(&bad_dev, n_items, true)) ||
+        (rc = dalloc(&nbad_dev, 1, true)))
+        return rc;
+    if (ch != 0) {
+        if ((rc = dalloc(&end_state, (size_t)n_items * stride, false)) ||
+            (rc = dalloc(&warm_state, (size_t)n_items * stride, false)))
+            return rc;
+        for (uint32_t k = 0; k < n_items; k++) {
+            VocWork &w = work[k];
+            const bool first = w.t_out == 0;
+            const bool single = first && w.t_end == T[w.utt];
+            if (single)
+                continue;
+            w.save_end = end_state + (size_t)k * stride;
+            w.save_warm = first ? nullptr : warm_state + (size_t)k * stride;
+        }
+    }
+    if (n_items)
+        hipMemcpy(work_dev, work.data(), sizeof(VocWork) * n_items, hipMemcpyHostToDevice);
+    return JB_OK;
+}
+
+// Streaming generator (utterance 0 only): one work item per frame, state carried in vd.state
+int Batch::build_generator_work()
+{
+    if (gen_work_dev || B == 0 || T[0] == 0)
+        return JB_OK;
+    std::vector<VocWork> gw(T[0]);
+    for (uint32_t t = 0; t < T[0]; t++) {
+        gw[t] = VocWork{0, t, t, t + 1, t > 0 ? vd.state : nullptr, nullptr, vd.state};
+    }
+    int rc = dalloc(&gen_work_dev, gw.size(), false);
+    if (rc)
+        return rc;
+    hipError_t e = hipMemcpy(gen_work_dev, gw.data(), sizeof(VocWork) * gw.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipMemcpy(generator work)");
+    return JB_OK;
+}
+
+int Batch::enqueue_vocoder()
+{
+    hipError_t e;
+    if ((e = launch_vocoder(bd, vd, work_dev, n_items, stream)) != hipSuccess)
+        return hip_fail(e, "k_vocoder");
     return JB_OK;
 }
 
@@ -485,10 +582,58 @@ int Batch::run(bool timed)
         return rc;
     if (timed)
         hipEventRecord(ev1, stream);
-    if ((e = launch_vocoder(bd, vd, 0, maxT, 0, stream)) != hipSuccess)
-        return hip_fail(e, "k_vocoder");
-    if (timed) {
+    if ((rc = enqueue_vocoder()))
+        return rc;
+    if (timed)
         hipEventRecord(ev2, stream);
+    if (chunk_frames != 0 && n_items > 0) {
+        hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream);
+        if ((e = launch_voc_verify(work_dev, n_items, vd.state_stride, verify_tol, bad_dev, nbad_dev,
+                                   stream)) != hipSuccess)
+            return hip_fail(e, "k_voc_verify");
+        verify_pending = true;
+    }
+    if (timed)
+        hipEventRecord(ev3, stream);
+    return JB_OK;
+}
+
+// After the stream has drained: act on the chunk hand-off check.  Chunks whose
+// warmed-up state disagrees with the predecessor's end state are recomputed from that
+// end state (exact continuation), in increasing order so that each re-do starts from
+// a final state.
+int Batch::finish_verify()
+{
+    if (!verify_pending)
+        return JB_OK;
+    verify_pending = false;
+    uint32_t nbad = 0;
+    hipError_t e = hipMemcpy(&nbad, nbad_dev, sizeof nbad, hipMemcpyDeviceToHost);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipMemcpy(n_bad)");
+    n_redo = nbad;
+    if (nbad == 0)
+        return JB_OK;
+    std::vector<uint8_t> bad(n_items);
+    if ((e = hipMemcpy(bad.data(), bad_dev, n_items, hipMemcpyDeviceToHost)) != hipSuccess)
+        return hip_fail(e, "hipMemcpy(bad)");
+    VocWork *redo_dev;
+    int rc = dalloc(&redo_dev, 1, false);
+    if (rc)
+        return rc;
+    for (uint32_t k = 1; k < n_items; k++) {
+        if (!bad[k])
+            continue;
+        VocWork w = work[k];
+        w.t_start = w.t_out;
+        w.load_state = work[k - 1].save_end;
+        w.save_warm = nullptr;
+        if ((e = hipMemcpy(redo_dev, &w, sizeof w, hipMemcpyHostToDevice)) != hipSuccess)
+            return hip_fail(e, "hipMemcpy(redo)");
+        if ((e = launch_vocoder(bd, vd, redo_dev, 1, stream)) != hipSuccess)
+            return hip_fail(e, "k_vocoder(redo)");
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+            return hip_fail(e, "redo sync");
     }
     return JB_OK;
 }
@@ -498,7 +643,7 @@ int Batch::sync()
     hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess)
         return hip_fail(e, "stream sync");
-    return JB_OK;
+    return finish_verify();
 }
 
 int Batch::read(const void *dev, void *dst, size_t bytes)
@@ -645,6 +790,23 @@ int jb_batch_read_excitation(jb_batch *hb, size_t i, double *dst, size_t cap)
     if (ns == 0)
         return JB_OK;
     return b->read(b->vd.exc + (size_t)b->frame_off[i] * b->voice.fperiod, dst, ns * sizeof(double));
+}
+
+int jb_batch_info(const jb_batch *hb, uint32_t *chunk_frames, uint32_t *warmup_frames,
+                  uint32_t *n_items, uint32_t *n_redo)
+{
+    const Batch *b = (const Batch *)hb;
+    if (!b)
+        return JB_ERR_INVALID;
+    if (chunk_frames)
+        *chunk_frames = b->chunk_frames;
+    if (warmup_frames)
+        *warmup_frames = b->warmup_frames;
+    if (n_items)
+        *n_items = b->n_items;
+    if (n_redo)
+        *n_redo = b->n_redo;
+    return JB_OK;
 }
 
 void jb_batch_free(jb_batch *b) { delete (Batch *)b; }

@@ -91,6 +91,16 @@ struct VocDev {
     int state_stride;     // doubles per utterance
 };
 
+// One unit of vocoder work: output frames [t_out, t_end) of utterance `utt`, with the
+// recursion started at t_start <= t_out (frames [t_start, t_out) are warm-up: computed,
+// not stored).  load_state != nullptr resumes from a saved filter state instead of zeros.
+struct VocWork {
+    uint32_t utt, t_start, t_out, t_end;
+    const double *load_state; // exact continuation (streaming / re-do), or nullptr
+    double *save_warm;        // state on entering t_out (after warm-up), or nullptr
+    double *save_end;         // state after t_end, or nullptr
+};
+
 struct BatchDev {
     int B;
     const UttDev *utt;        // device
@@ -104,9 +114,12 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
 hipError_t launch_prologue(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
-// frames [t0, t1) of every utterance (t1 clipped to T_b); resume!=0 => load/save vd.state
-hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, uint32_t t0, uint32_t t1, int resume,
+hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                           hipStream_t stream);
+// compares save_warm of item i with save_end of item i-1 (same utterance): bad[i]=1 and
+// ++*n_bad when max|diff| > tol * max|state|
+hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, double tol,
+                             uint8_t *bad, uint32_t *n_bad, hipStream_t stream);
 int vocoder_state_doubles(int nmcp);
 
 } // namespace jb

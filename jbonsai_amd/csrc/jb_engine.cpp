@@ -716,6 +716,7 @@ int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_
     std::unique_ptr<jb::Generator> g(new jb::Generator());
     jb_batch_opts opts{};
     opts.device = -1;
+    opts.flags = JB_BATCH_SERIAL;
     jb::Batch *b = nullptr;
     if ((rc = jb::Batch::create(&CENG(e)->desc, &st.utt, 1, &opts, &b)))
         return rc;
@@ -725,7 +726,7 @@ int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_
     // Engine::generator runs all three MLPGs before returning (src/engine.rs:333-357)
     if (hipSetDevice(b->device) != hipSuccess)
         return JB_ERR_DEVICE;
-    if ((rc = b->enqueue_paramgen()) || (rc = b->sync()))
+    if ((rc = b->enqueue_paramgen()) || (rc = b->sync()) || (rc = b->build_generator_work()))
         return rc;
     *out = (jb_generator *)g.release();
     return JB_OK;
@@ -752,7 +753,7 @@ long jb_generator_step(jb_generator *hg, double *buf, size_t buf_len)
     jb::Batch *b = g->batch.get();
     if (hipSetDevice(b->device) != hipSuccess)
         return JB_ERR_DEVICE;
-    hipError_t he = launch_vocoder(b->bd, b->vd, (uint32_t)g->next, (uint32_t)g->next + 1, 1, b->stream);
+    hipError_t he = launch_vocoder(b->bd, b->vd, b->gen_work_dev + g->next, 1, b->stream);
     if (he != hipSuccess)
         return hip_fail(he, "k_vocoder");
     int rc = b->sync();

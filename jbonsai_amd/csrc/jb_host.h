@@ -33,6 +33,16 @@ struct Batch {
     BatchDev bd{};
     StreamDev sd[kMaxStream]{};
     VocDev vd{};
+    // vocoder work items
+    std::vector<VocWork> work;       // host copy
+    VocWork *work_dev = nullptr;
+    uint32_t n_items = 0, chunk_frames = 0, warmup_frames = 0, n_redo = 0;
+    double verify_tol = 1e-9;
+    double *end_state = nullptr, *warm_state = nullptr;
+    uint8_t *bad_dev = nullptr;
+    uint32_t *nbad_dev = nullptr;
+    bool verify_pending = false;
+    VocWork *gen_work_dev = nullptr; // one item per frame of utterance 0 (streaming generator)
     std::vector<void *> allocs;
     std::map<std::pair<const void *, size_t>, const void *> uploaded;
 
@@ -41,7 +51,11 @@ struct Batch {
     int upload(const void *host, size_t bytes, const void **dev);
     static int create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,
                       const jb_batch_opts *opts, Batch **out);
+    int build_work(const jb_batch_opts *opts);
+    int build_generator_work();
     int enqueue_paramgen();
+    int enqueue_vocoder();
+    int finish_verify();
     int run(bool timed);
     int sync();
     int read(const void *dev, void *dst, size_t bytes);

@@ -177,18 +177,19 @@ constexpr int kEStride = 64; // LDS slots per block of excitation source samples
 __host__ __device__ inline int voc_state_doubles(int tpl) { return 64 * tpl + 64 + 6 + 6 + 64; }
 
 template <int TPL>
-__global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t t_begin,
-                                                uint32_t t_end, int resume)
+__global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const VocWork *__restrict__ work)
 {
-    const int b = bd.order[blockIdx.x];
-    const UttDev u = bd.utt[b];
-    const uint32_t T = u.T;
+    const VocWork wk = work[blockIdx.x];
+    const int b = (int)wk.utt;
+    const uint32_t T = bd.utt[b].T;
+    const uint32_t t_begin = wk.t_start, t_out = wk.t_out;
+    uint32_t t_end = wk.t_end;
     if (t_end > T)
         t_end = T;
     if (t_begin >= t_end)
         return;
     const int lane = threadIdx.x;
-    const uint64_t base = u.frame_off;
+    const uint64_t base = bd.utt[b].frame_off;
     const int nmcp = vd.nmcp, nlpf = vd.nlpf, fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
     const int M = nmcp - 1; // live taps 1..M
     const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
@@ -246,8 +247,8 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t
     E[kEStride + lane] = 0.0;
     taps[0][lane] = 0.0;
     taps[1][lane] = 0.0;
-    if (resume && vd.state && t_begin > 0) {
-        const double *sp = vd.state + (uint64_t)b * (uint64_t)vd.state_stride;
+    if (wk.load_state) {
+        const double *sp = wk.load_state;
 #pragma unroll
         for (int k = 0; k < TPL; k++)
             d[k] = sp[64 * k + lane];
@@ -263,8 +264,26 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t
 
     const int anti = (nlpf - 1) / 2;
 
+    auto save_state = [&](double *sp) {
+#pragma unroll
+        for (int k = 0; k < TPL; k++)
+            sp[64 * k + lane] = d[k];
+        sp[64 * TPL + lane] = ulane;
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                sp[64 * TPL + 64 + i] = e11[i];
+                sp[64 * TPL + 70 + i] = e12[i];
+            }
+        }
+        sp[64 * TPL + 76 + lane] = E[lane];
+    };
+
     for (uint32_t t = t_begin; t < t_end; t++) {
         const uint64_t f = base + t;
+        const bool emit = t >= t_out; // warm-up frames are computed but not stored
+        if (t == t_out && t_out > t_begin && wk.save_warm)
+            save_state(wk.save_warm);
         // ---- frame setup (vocoder/mod.rs:116-125) ----
         // c at frame start = previous frame's cc exactly (mod.rs:140); first frame: c = cc.
         const double *bcur = vd.bcoef + f * (uint64_t)nmcp;
@@ -297,6 +316,9 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)i0; // within utterance
             // =========== Phase A: excitation for bs samples, lane = sample ===========
             double xin = 0.0;
+#ifdef JB_ABL_NO_PHASE_A
+            xin = (double)(lane + 1) * 1e-3 + c0;
+#else
             {
                 const bool lv = lane < bs;
                 const uint64_t n = n0 + (uint64_t)lane;
@@ -329,7 +351,7 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t
                         x = fma(src, tap, x);
                     }
                 }
-                if (vd.exc && lv)
+                if (vd.exc && lv && emit)
                     vd.exc[base * (uint64_t)fp + n] = x;
                 // V5 gain with the interpolated c[0] of this sample (mod.rs:129-131)
                 if (x != 0.0)
@@ -340,9 +362,15 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t
                 E[lane] = E[kEStride + lane];
                 __syncthreads();
             }
+#endif
             // =========== Phase B: bs serial filter steps ===========
             double ob = 0.0;
+#ifdef JB_ABL_NO_PHASE_B
+            ob = xin;
+            for (int i = 0; i < 0; i++) {
+#else
             for (int i = 0; i < bs; i++) {
+#endif
                 double x = readlane_f64(xin, i);
                 // ---- V6 df1 (mlsa.rs:54-66), uniform across lanes ----
                 {
@@ -403,26 +431,52 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, uint32_t
                 c1 += c1inc;
                 ob = (lane == i) ? x * vol : ob;
             }
-            if (lane < bs)
+            if (lane < bs && emit)
                 vd.pcm[base * (uint64_t)fp + n0 + (uint64_t)lane] = ob;
         }
         (void)ctgt;
     }
 
-    if (resume && vd.state) {
-        double *sp = vd.state + (uint64_t)b * (uint64_t)vd.state_stride;
-#pragma unroll
-        for (int k = 0; k < TPL; k++)
-            sp[64 * k + lane] = d[k];
-        sp[64 * TPL + lane] = ulane;
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-                sp[64 * TPL + 64 + i] = e11[i];
-                sp[64 * TPL + 70 + i] = e12[i];
-            }
-        }
-        sp[64 * TPL + 76 + lane] = E[lane];
+    if (wk.save_end)
+        save_state(wk.save_end);
+}
+
+// --------------------------------------------------------------------------
+// Certification of time-chunked execution: a chunk that started from zero state
+// W frames early must have reached the same filter state as its predecessor's end
+// state.  One wave per item; the excitation ring is feed-forward and not compared.
+__global__ __launch_bounds__(64) void k_voc_verify(const VocWork *__restrict__ work, uint32_t n_items,
+                                                    int nfilt /* doubles to compare */, double tol,
+                                                    uint8_t *bad, uint32_t *n_bad)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= n_items)
+        return;
+    const VocWork wk = work[i];
+    const int lane = threadIdx.x;
+    if (!wk.save_warm || i == 0) {
+        if (lane == 0)
+            bad[i] = 0;
+        return;
+    }
+    const double *a = wk.save_warm, *r = work[i - 1].save_end;
+    double md = 0.0, mr = 0.0;
+    for (int k = lane; k < nfilt; k += 64) {
+        const double x = a[k], y = r[k];
+        md = fmax(md, fabs(x - y));
+        mr = fmax(mr, fabs(y));
+        if (!(x == x) || !(y == y))
+            md = 1e300; // NaN anywhere => redo
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        md = fmax(md, __shfl_xor(md, o));
+        mr = fmax(mr, __shfl_xor(mr, o));
+    }
+    if (lane == 0) {
+        const bool isbad = md > tol * mr && md > 1e-300;
+        bad[i] = isbad;
+        if (isbad)
+            atomicAdd(n_bad, 1u);
     }
 }
 
@@ -453,27 +507,38 @@ hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream
     return hipGetLastError();
 }
 
-hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, uint32_t t0, uint32_t t1, int resume,
+hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, double tol,
+                             uint8_t *bad, uint32_t *n_bad, hipStream_t stream)
+{
+    if (n_items == 0)
+        return hipSuccess;
+    // filter part of the state = everything before the 64-slot excitation ring
+    hipLaunchKernelGGL(k_voc_verify, dim3(n_items), dim3(64), 0, stream, work_dev, n_items,
+                       state_doubles - 64, tol, bad, n_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                           hipStream_t stream)
 {
-    if (bd.B == 0 || bd.maxT == 0)
+    if (n_items == 0)
         return hipSuccess;
-    dim3 grid(bd.B), block(64);
+    dim3 grid(n_items), block(64);
     switch (tpl_for(vd.nmcp)) {
     case 1:
-        hipLaunchKernelGGL(k_vocoder<1>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        hipLaunchKernelGGL(k_vocoder<1>, grid, block, 0, stream, bd, vd, work_dev);
         break;
     case 2:
-        hipLaunchKernelGGL(k_vocoder<2>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        hipLaunchKernelGGL(k_vocoder<2>, grid, block, 0, stream, bd, vd, work_dev);
         break;
     case 3:
-        hipLaunchKernelGGL(k_vocoder<3>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        hipLaunchKernelGGL(k_vocoder<3>, grid, block, 0, stream, bd, vd, work_dev);
         break;
     case 4:
-        hipLaunchKernelGGL(k_vocoder<4>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        hipLaunchKernelGGL(k_vocoder<4>, grid, block, 0, stream, bd, vd, work_dev);
         break;
     case 5:
-        hipLaunchKernelGGL(k_vocoder<5>, grid, block, 0, stream, bd, vd, t0, t1, resume);
+        hipLaunchKernelGGL(k_vocoder<5>, grid, block, 0, stream, bd, vd, work_dev);
         break;
     default:
         return hipErrorInvalidValue;

@@ -104,3 +104,46 @@ def test_fused_mlpg_equals_generic_bitwise(oracle_voice, have_gpu):
         assert np.array_equal(outs[0][si], outs[1][si]), si
         np.testing.assert_allclose(outs[0][si], tracks[si], rtol=1e-12, atol=0)
         print("stream", si, "bit-exact vs oracle:", np.array_equal(outs[0][si], tracks[si]))
+
+
+def _run(v, utts, **kw):
+    with J.Batch(voice_info(v), utts, **kw) as b:
+        b.run()
+        b.sync()
+        return [b.pcm(i) for i in range(len(utts))], b.info()
+
+
+def test_chunked_equals_serial(oracle_voice, have_gpu):
+    """Time-chunked execution (zero-state start 32 frames early + device-side hand-off
+    check) against the one-wave-per-utterance serial recursion and the oracle."""
+    v = oracle_voice
+    d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
+    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+    utts = [to_utt(d2, s2), to_utt(d1, s1)]
+    ser, info_s = _run(v, utts, serial=True)
+    assert info_s["chunk_frames"] == 0 and info_s["n_items"] == 2
+    chk, info_c = _run(v, utts, chunk_frames=64, warmup_frames=32)
+    assert info_c["chunk_frames"] == 64 and info_c["n_items"] == 7 + 5 and info_c["n_redo"] == 0
+    dflt, info_d = _run(v, utts)
+    assert info_d["chunk_frames"] >= 128 and info_d["n_redo"] == 0
+    ref = [oracle_run(v, d2, s2)[1], oracle_run(v, d1, s1)[1]]
+    for i in range(2):
+        assert rel_rms(chk[i], ser[i]) <= 1e-12
+        assert rel_rms(dflt[i], ser[i]) <= 1e-12
+        assert rel_rms(chk[i], ref[i]) <= PCM_TOL and rel_rms(ser[i], ref[i]) <= PCM_TOL
+        print("chunked vs serial rel RMS", rel_rms(chk[i], ser[i]), "max abs", np.abs(chk[i] - ser[i]).max())
+
+
+def test_chunk_handoff_check_triggers_redo(oracle_voice, have_gpu):
+    """A 1-frame warm-up cannot pass the hand-off check: every failing chunk must be
+    recomputed from its predecessor's end state, which reproduces the serial result."""
+    v = oracle_voice
+    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+    utts = [to_utt(d2, s2)]
+    ser, _ = _run(v, utts, serial=True)
+    out, info = _run(v, utts, chunk_frames=64, warmup_frames=1, verify_tol=1e-9)
+    assert info["n_redo"] >= 3, info
+    assert rel_rms(out[0], ser[0]) <= 1e-13
+    # and with the check effectively disabled the truncated warm-up is visible
+    bad, info2 = _run(v, utts, chunk_frames=64, warmup_frames=1, verify_tol=1e30)
+    assert info2["n_redo"] == 0 and rel_rms(bad[0], ser[0]) > 1e-6
