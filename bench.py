@@ -145,6 +145,7 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        info = batch.info()
         out = {
             "metric": "48 kHz PCM samples/sec (whole node), batched utterances",
             "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
@@ -157,6 +158,8 @@ def main():
                             "utterance from real nitech pdfs (BASELINE config 2), nitech voice",
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
                 "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
+                "vocoder_chunk_frames": info["chunk_frames"], "vocoder_warmup_frames": info["warmup_frames"],
+                "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
             "realtime_factor": value / vi.sampling_frequency,
             "roofline": {

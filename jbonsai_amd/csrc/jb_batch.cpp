@@ -617,23 +617,39 @@ int Batch::finish_verify()
     std::vector<uint8_t> bad(n_items);
     if ((e = hipMemcpy(bad.data(), bad_dev, n_items, hipMemcpyDeviceToHost)) != hipSuccess)
         return hip_fail(e, "hipMemcpy(bad)");
-    VocWork *redo_dev;
-    int rc = dalloc(&redo_dev, 1, false);
-    if (rc)
-        return rc;
-    for (uint32_t k = 1; k < n_items; k++) {
-        if (!bad[k])
-            continue;
-        VocWork w = work[k];
-        w.t_start = w.t_out;
-        w.load_state = work[k - 1].save_end;
-        w.save_warm = nullptr;
-        if ((e = hipMemcpy(redo_dev, &w, sizeof w, hipMemcpyHostToDevice)) != hipSuccess)
+    // rounds: every failing chunk whose predecessor is final (not itself pending) is
+    // recomputed in the same launch; runs of consecutive failures take one round each
+    if (!redo_dev) {
+        int rc = dalloc(&redo_dev, n_items, false);
+        if (rc)
+            return rc;
+    }
+    std::vector<uint8_t> pending(bad);
+    pending[0] = 0;
+    for (;;) {
+        std::vector<VocWork> round;
+        std::vector<uint32_t> ids;
+        for (uint32_t k = 1; k < n_items; k++) {
+            if (!pending[k] || pending[k - 1])
+                continue;
+            VocWork w = work[k];
+            w.t_start = w.t_out;
+            w.load_state = work[k - 1].save_end;
+            w.save_warm = nullptr;
+            round.push_back(w);
+            ids.push_back(k);
+        }
+        if (round.empty())
+            break;
+        if ((e = hipMemcpy(redo_dev, round.data(), sizeof(VocWork) * round.size(),
+                           hipMemcpyHostToDevice)) != hipSuccess)
             return hip_fail(e, "hipMemcpy(redo)");
-        if ((e = launch_vocoder(bd, vd, redo_dev, 1, stream)) != hipSuccess)
+        if ((e = launch_vocoder(bd, vd, redo_dev, (uint32_t)round.size(), stream)) != hipSuccess)
             return hip_fail(e, "k_vocoder(redo)");
         if ((e = hipStreamSynchronize(stream)) != hipSuccess)
             return hip_fail(e, "redo sync");
+        for (uint32_t k : ids)
+            pending[k] = 0;
     }
     return JB_OK;
 }

@@ -42,6 +42,7 @@ struct Batch {
     uint8_t *bad_dev = nullptr;
     uint32_t *nbad_dev = nullptr;
     bool verify_pending = false;
+    VocWork *redo_dev = nullptr;
     VocWork *gen_work_dev = nullptr; // one item per frame of utterance 0 (streaming generator)
     std::vector<void *> allocs;
     std::map<std::pair<const void *, size_t>, const void *> uploaded;
