@@ -121,8 +121,12 @@ Batch::~Batch()
         hipEventDestroy(ev2);
     if (ev3)
         hipEventDestroy(ev3);
-    if (stream)
-        hipStreamDestroy(stream);
+    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf})
+        if (ev)
+            hipEventDestroy(ev);
+    for (hipStream_t st : {stream_lf0, stream_lpf, stream})
+        if (st)
+            hipStreamDestroy(st);
 }
 
 template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
@@ -270,6 +274,12 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
+    if ((e = hipStreamCreateWithFlags(&b->stream_lf0, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&b->stream_lpf, hipStreamNonBlocking)) != hipSuccess)
+        return hip_fail(e, "hipStreamCreate");
+    hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_lf0, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_lpf, hipEventDisableTiming);
     hipEventCreate(&b->ev0);
     hipEventCreate(&b->ev1);
     hipEventCreate(&b->ev2);
@@ -437,8 +447,13 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         (rc = b->dalloc(&vd.pitch, nf, false)) || (rc = b->dalloc(&vd.cur_start, nf, false)) ||
         (rc = b->dalloc(&vd.pinc, nf, false)) || (rc = b->dalloc(&vd.counter_start, nf, false)) ||
         (rc = b->dalloc(&vd.pmask, nf * (size_t)vd.nblk, false)) ||
-        (rc = b->dalloc(&vd.pcm, b->total_samples, false)))
+        (rc = b->dalloc(&vd.pcm, b->total_samples, false)) ||
+        (rc = b->dalloc(&vd.xin, b->total_samples, false)))
         return rc;
+    if (vd.nlpf - 1 > 64) {
+        set_error("nlpf > 65 is not supported");
+        return JB_ERR_UNSUPPORTED;
+    }
     if (b->flags & JB_BATCH_KEEP_TRACKS)
         if ((rc = b->dalloc(&vd.exc, b->total_samples, false)))
             return rc;
@@ -554,19 +569,45 @@ int Batch::enqueue_vocoder()
     return JB_OK;
 }
 
+// The three MlpgAdjust::create calls (src/engine.rs:333-357) are independent: MCP on the
+// main stream, LF0 -> pitch -> pulse schedule and LPF on side streams, forked after
+// whatever the main stream was doing (a previous run may still read the tracks) and
+// joined before the vocoder.
 int Batch::enqueue_paramgen()
 {
     hipError_t e;
-    for (uint32_t si = 0; si < voice.nstream; si++) {
-        if ((e = launch_prep(bd, sd[si], (int)si, stream)) != hipSuccess)
-            return hip_fail(e, "k_prep");
-        if ((e = launch_mlpg(bd, sd[si], (int)si, stream)) != hipSuccess)
-            return hip_fail(e, "k_mlpg");
-    }
-    if ((e = launch_prologue(bd, vd, stream)) != hipSuccess)
-        return hip_fail(e, "k_prologue");
-    if ((e = launch_pulse(bd, vd, stream)) != hipSuccess)
+    hipEventRecord(ev_fork, stream);
+    hipStreamWaitEvent(stream_lf0, ev_fork, 0);
+    hipStreamWaitEvent(stream_lpf, ev_fork, 0);
+    // LF0 chain
+    if ((e = launch_prep(bd, sd[1], 1, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_prep(lf0)");
+    if ((e = launch_mlpg(bd, sd[1], 1, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_mlpg(lf0)");
+    if ((e = launch_pitch(bd, vd, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_pitch");
+    if ((e = launch_pulse(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_pulse");
+    hipEventRecord(ev_lf0, stream_lf0);
+    // LPF chain
+    if (voice.nstream > 2) {
+        if ((e = launch_prep(bd, sd[2], 2, stream_lpf)) != hipSuccess)
+            return hip_fail(e, "k_prep(lpf)");
+        if ((e = launch_mlpg(bd, sd[2], 2, stream_lpf)) != hipSuccess)
+            return hip_fail(e, "k_mlpg(lpf)");
+    }
+    hipEventRecord(ev_lpf, stream_lpf);
+    // MCP chain
+    if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess)
+        return hip_fail(e, "k_prep(mcp)");
+    if ((e = launch_mlpg(bd, sd[0], 0, stream)) != hipSuccess)
+        return hip_fail(e, "k_mlpg(mcp)");
+    if ((e = launch_mc2b(bd, vd, stream)) != hipSuccess)
+        return hip_fail(e, "k_mc2b");
+    hipStreamWaitEvent(stream, ev_lf0, 0);
+    hipStreamWaitEvent(stream, ev_lpf, 0);
+    if ((e = launch_excite(bd, vd, stream)) != hipSuccess)
+        return hip_fail(e, "k_excite");
     return JB_OK;
 }
 

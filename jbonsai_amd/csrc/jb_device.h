@@ -85,6 +85,7 @@ struct VocDev {
     unsigned long long *pmask; // [sumT][nblk] pulse bit per sample of each block
     const double *noise;  // [noise_len] shared Gaussian stream
     uint64_t noise_len;
+    double *xin;          // [sumT*fperiod] excitation after the LPF mix and gain (k_excite)
     double *pcm;          // [sumT*fperiod]
     double *exc;          // optional [sumT*fperiod] excitation before gain, or nullptr
     double *state;        // optional per-utterance filter state (streaming), or nullptr
@@ -112,8 +113,10 @@ struct BatchDev {
 // launchers (all asynchronous on `stream`)
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
-hipError_t launch_prologue(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+hipError_t launch_pitch(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                           hipStream_t stream);
 // compares save_warm of item i with save_end of item i-1 (same utterance): bad[i]=1 and

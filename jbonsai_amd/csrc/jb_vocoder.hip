@@ -1,7 +1,9 @@
 // jb_vocoder.hip -- mixed excitation + MLSA cascade kernels for gfx950 (CDNA4).
 //
 // Restates /root/reference/src/vocoder (Stage::Zero) and src/speech.rs:
-//   k_prologue  V2  pitch from lf0, mc2b            (vocoder/mod.rs:73-77, cepstrum.rs:139-149)
+//   k_pitch     V2  pitch from lf0                  (vocoder/mod.rs:73-77)
+//   k_mc2b      V2  mc2b                            (cepstrum.rs:139-149)
+//   k_excite    V3+V5 mixed excitation (ring buffer as a feed-forward FIR) and gain
 //   k_pulse     V3  pulse scheduler, per voiced run (excitation.rs:25-33,73-81,102-104)
 //   k_vocoder   V3 (ring buffer as a 31-tap feed-forward FIR), V5 gain,
 //               V6 df1, V7 df2/fir, V8 coefficient interpolation, V9 frame loop.
@@ -28,15 +30,15 @@
 namespace jb {
 
 // --------------------------------------------------------------------------
-// V2: thread per frame.
-__global__ void k_prologue(BatchDev bd, VocDev vd)
+// V2a: pitch from lf0, thread per frame (vocoder/mod.rs:73-77).
+__global__ void k_pitch(BatchDev bd, VocDev vd)
 {
     const int b = blockIdx.y;
-    const UttDev u = bd.utt[b];
+    const UttDev *u = bd.utt + b;
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= u.T)
+    if (t >= u->T)
         return;
-    const uint64_t f = u.frame_off + t;
+    const uint64_t f = u->frame_off + t;
     const double MAX_LF0 = 9.903487552536127, MIN_LF0 = 2.995732273553991; // constants.rs:4-6
     const double l = vd.lf0[f];
     double p;
@@ -47,6 +49,17 @@ __global__ void k_prologue(BatchDev bd, VocDev vd)
         p = (double)vd.fs / exp(cl);
     }
     vd.pitch[f] = p;
+}
+
+// V2b: mc2b, thread per frame (cepstrum.rs:139-149).
+__global__ void k_mc2b(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.y;
+    const UttDev *u = bd.utt + b;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= u->T)
+        return;
+    const uint64_t f = u->frame_off + t;
     const int n = vd.nmcp;
     const double *mc = vd.mcp + f * (uint64_t)n;
     double *bc = vd.bcoef + f * (uint64_t)n;
@@ -125,6 +138,87 @@ __global__ void k_pulse(BatchDev bd, VocDev vd)
 }
 
 // --------------------------------------------------------------------------
+// V3 + V5: mixed excitation and gain, fully parallel over samples.
+// The reference's 31-slot ring buffer (excitation.rs:43-100) is feed-forward:
+//   x[n] = noise[n-15] + sum_k e[n-k] * lpf_{frame(n-k)}[k],
+//   e[m] = voiced(frame(m)) ? pulse[m] - noise[m] : 0          
+// followed by  x *= exp(c0(n))  with the interpolated c[0] (vocoder/mod.rs:129-131).
+// Block = 256 consecutive samples of one utterance; e[] for the block and its history is
+// staged in LDS, and so are the LPF taps of the (at most 4) frames the block touches.
+constexpr int kExcBlock = 256;
+constexpr int kExcHalo = 64; // >= nlpf-1
+
+__global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.y;
+    const UttDev *u = bd.utt + b;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk, nlpf = vd.nlpf, nmcp = vd.nmcp;
+    const uint64_t N = (uint64_t)u->T * (uint64_t)fp;
+    const uint64_t n0 = (uint64_t)blockIdx.x * kExcBlock;
+    if (n0 >= N)
+        return;
+    const uint64_t base = u->frame_off;
+    const int tid = threadIdx.x;
+    const int anti = (nlpf - 1) / 2;
+    __shared__ double e[kExcBlock + kExcHalo];
+    __shared__ double taps[4][64];
+    __shared__ int anyv;
+    // frames touched by samples [n0 - halo, n0 + 255]
+    const long mfirst = (long)n0 - (long)kExcHalo;
+    const uint32_t f_lo = mfirst > 0 ? (uint32_t)((uint64_t)mfirst / (uint64_t)fp) : 0u;
+    if (tid == 0)
+        anyv = 0;
+    {
+        const int fi = tid >> 6, k = tid & 63;
+        const uint32_t fr = f_lo + (uint32_t)fi;
+        taps[fi][k] = (fr < u->T && k < nlpf) ? vd.lpf[(base + fr) * (uint64_t)nlpf + k] : 0.0;
+    }
+    __syncthreads();
+    for (int j = tid; j < kExcBlock + kExcHalo; j += kExcBlock) {
+        const long m = (long)n0 - kExcHalo + j;
+        double ev = 0.0;
+        if (m >= 0 && (uint64_t)m < N) {
+            const uint32_t fr = (uint32_t)((uint64_t)m / (uint64_t)fp);
+            const int i = (int)((uint64_t)m - (uint64_t)fr * (uint64_t)fp);
+            const uint64_t f = base + fr;
+            if (vd.pitch[f] != 0.0) {
+                const unsigned long long pm = vd.pmask[f * (uint64_t)nblk + (uint64_t)(i / bs)];
+                double pulse = 0.0;
+                if ((pm >> (i % bs)) & 1ull)
+                    pulse = sqrt(fma((double)i, vd.pinc[f], vd.cur_start[f]));
+                ev = pulse - vd.noise[m];
+                anyv = 1;
+            }
+        }
+        e[j] = ev;
+    }
+    __syncthreads();
+    const uint64_t n = n0 + (uint64_t)tid;
+    if (n >= N)
+        return;
+    double x = n >= (uint64_t)anti ? vd.noise[n - (uint64_t)anti] : 0.0;
+    if (anyv) {
+        for (int k = 0; k < nlpf; k++) {
+            const long m = (long)n - k;
+            if (m < 0)
+                break;
+            const uint32_t fr = (uint32_t)((uint64_t)m / (uint64_t)fp);
+            x = fma(e[kExcHalo + tid - k], taps[fr - f_lo][k], x);
+        }
+    }
+    if (vd.exc)
+        vd.exc[base * (uint64_t)fp + n] = x;
+    // gain with the interpolated c[0]: c0(t-1) + i*(c0(t)-c0(t-1))/fperiod
+    const uint32_t fr = (uint32_t)(n / (uint64_t)fp);
+    const int i = (int)(n - (uint64_t)fr * (uint64_t)fp);
+    const double bc = vd.bcoef[(base + fr) * (uint64_t)nmcp];
+    const double bp = fr > 0 ? vd.bcoef[(base + fr - 1) * (uint64_t)nmcp] : bc;
+    if (x != 0.0)
+        x *= exp(fma((double)i, (bc - bp) / (double)fp, bp));
+    vd.xin[base * (uint64_t)fp + n] = x;
+}
+
+// --------------------------------------------------------------------------
 // DPP helpers (f64 moves as two 32-bit DPP movs; invalid source lanes read 0).
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v)
@@ -171,10 +265,8 @@ __device__ __forceinline__ double ipow(double x, int n)
 __device__ __constant__ double kPPade[6] = {1.00000000000, 0.49993910000, 0.11070980000,
                                             0.01369984000, 0.00095648530, 0.00003041721};
 
-constexpr int kEStride = 64; // LDS slots per block of excitation source samples
-
-// state layout (doubles): d[TPL][64] | ulane[64] | e11[6] | e12[6] | Eprev[64]
-__host__ __device__ inline int voc_state_doubles(int tpl) { return 64 * tpl + 64 + 6 + 6 + 64; }
+// filter state layout (doubles): d[TPL][64] | ulane[64] | e11[6] | e12[6] | pad[4]
+__host__ __device__ inline int voc_state_doubles(int tpl) { return 64 * tpl + 64 + 16; }
 
 template <int TPL>
 __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const VocWork *__restrict__ work)
@@ -190,7 +282,7 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
         return;
     const int lane = threadIdx.x;
     const uint64_t base = bd.utt[b].frame_off;
-    const int nmcp = vd.nmcp, nlpf = vd.nlpf, fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+    const int nmcp = vd.nmcp, fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
     const int M = nmcp - 1; // live taps 1..M
     const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
 
@@ -229,10 +321,6 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
         dotv[k] = active && tapj[k] >= 2 && tapj[k] <= M;
     }
 
-    // ---- LDS: excitation source ring + LPF taps of current / previous frame ----
-    __shared__ double E[2 * kEStride];
-    __shared__ double taps[2][64];
-
     // ---- state ----
     double d[TPL], cd[TPL], cdinc[TPL], ctgt[TPL];
 #pragma unroll
@@ -243,10 +331,6 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
 #pragma unroll
     for (int i = 0; i < 6; i++)
         e11[i] = e12[i] = 0.0;
-    E[lane] = 0.0;
-    E[kEStride + lane] = 0.0;
-    taps[0][lane] = 0.0;
-    taps[1][lane] = 0.0;
     if (wk.load_state) {
         const double *sp = wk.load_state;
 #pragma unroll
@@ -258,11 +342,7 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
             e11[i] = sp[64 * TPL + 64 + i];
             e12[i] = sp[64 * TPL + 70 + i];
         }
-        E[lane] = sp[64 * TPL + 76 + lane];
     }
-    __syncthreads();
-
-    const int anti = (nlpf - 1) / 2;
 
     auto save_state = [&](double *sp) {
 #pragma unroll
@@ -276,7 +356,6 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
                 sp[64 * TPL + 70 + i] = e12[i];
             }
         }
-        sp[64 * TPL + 76 + lane] = E[lane];
     };
 
     for (uint32_t t = t_begin; t < t_end; t++) {
@@ -298,79 +377,14 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
         }
         double c1 = bprev[1];
         const double c1inc = (bcur[1] - c1) / (double)fp;
-        const double c0 = bprev[0];
-        const double c0inc = (bcur[0] - c0) / (double)fp;
-        const double pcur = vd.pitch[f];
-        const bool voiced = pcur != 0.0;
-        const bool pvoiced = (t > 0) && vd.pitch[f - 1] != 0.0;
-        const double cur0 = vd.cur_start[f], pinc = vd.pinc[f];
-        // LPF taps of this frame into taps[t&1]; previous frame's stay in taps[(t-1)&1]
-        if (lane < nlpf)
-            taps[t & 1][lane] = vd.lpf[f * (uint64_t)nlpf + lane];
-        if (t == t_begin && t > 0 && lane < nlpf)
-            taps[(t - 1) & 1][lane] = vd.lpf[(f - 1) * (uint64_t)nlpf + lane];
-        __syncthreads();
-
         for (int q = 0; q < nblk; q++) {
             const int i0 = q * bs; // first sample of block within frame
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)i0; // within utterance
-            // =========== Phase A: excitation for bs samples, lane = sample ===========
-            double xin = 0.0;
-#ifdef JB_ABL_NO_PHASE_A
-            xin = (double)(lane + 1) * 1e-3 + c0;
-#else
-            {
-                const bool lv = lane < bs;
-                const uint64_t n = n0 + (uint64_t)lane;
-                double nz = 0.0, nz15 = 0.0;
-                if (lv) {
-                    nz = vd.noise[n];
-                    if (n >= (uint64_t)anti)
-                        nz15 = vd.noise[n - (uint64_t)anti];
-                }
-                double e = 0.0;
-                if (lv && voiced) {
-                    const unsigned long long pm = vd.pmask[f * (uint64_t)nblk + q];
-                    double pulse = 0.0;
-                    if ((pm >> lane) & 1ull)
-                        pulse = sqrt(fma((double)(i0 + lane), pinc, cur0));
-                    e = pulse - nz;
-                }
-                E[kEStride + lane] = e;
-                __syncthreads();
-                double x = nz15;
-                // previous block: same frame (q>0) or previous frame (q==0)
-                const bool prevv = (q > 0) ? voiced : pvoiced;
-                if (voiced || prevv) {
-                    const double *tc = taps[t & 1];
-                    const double *tp = (q > 0) ? tc : taps[(t - 1) & 1];
-                    for (int k = 0; k < nlpf; k++) {
-                        const int idx = lane - k;
-                        const double src = idx >= 0 ? E[kEStride + idx] : E[bs + idx];
-                        const double tap = idx >= 0 ? tc[k] : tp[k];
-                        x = fma(src, tap, x);
-                    }
-                }
-                if (vd.exc && lv && emit)
-                    vd.exc[base * (uint64_t)fp + n] = x;
-                // V5 gain with the interpolated c[0] of this sample (mod.rs:129-131)
-                if (x != 0.0)
-                    x *= exp(fma((double)(i0 + lane), c0inc, c0));
-                xin = lv ? x : 0.0;
-                __syncthreads();
-                // roll the source ring: this block becomes "previous"
-                E[lane] = E[kEStride + lane];
-                __syncthreads();
-            }
-#endif
+            // excitation (gain applied) of this block, lane = sample (k_excite)
+            const double xin = lane < bs ? vd.xin[base * (uint64_t)fp + n0 + (uint64_t)lane] : 0.0;
             // =========== Phase B: bs serial filter steps ===========
             double ob = 0.0;
-#ifdef JB_ABL_NO_PHASE_B
-            ob = xin;
-            for (int i = 0; i < 0; i++) {
-#else
             for (int i = 0; i < bs; i++) {
-#endif
                 double x = readlane_f64(xin, i);
                 // ---- V6 df1 (mlsa.rs:54-66), uniform across lanes ----
                 {
@@ -489,12 +503,31 @@ static int tpl_for(int nmcp)
 
 int vocoder_state_doubles(int nmcp) { return voc_state_doubles(tpl_for(nmcp)); }
 
-hipError_t launch_prologue(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
+hipError_t launch_pitch(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
     dim3 grid((bd.maxT + 255) / 256, bd.B), block(256);
-    hipLaunchKernelGGL(k_prologue, grid, block, 0, stream, bd, vd);
+    hipLaunchKernelGGL(k_pitch, grid, block, 0, stream, bd, vd);
+    return hipGetLastError();
+}
+
+hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
+{
+    if (bd.B == 0 || bd.maxT == 0)
+        return hipSuccess;
+    dim3 grid((bd.maxT + 255) / 256, bd.B), block(256);
+    hipLaunchKernelGGL(k_mc2b, grid, block, 0, stream, bd, vd);
+    return hipGetLastError();
+}
+
+hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
+{
+    if (bd.B == 0 || bd.maxT == 0)
+        return hipSuccess;
+    const uint64_t maxN = (uint64_t)bd.maxT * (uint64_t)vd.fperiod;
+    dim3 grid((unsigned)((maxN + kExcBlock - 1) / kExcBlock), bd.B), block(kExcBlock);
+    hipLaunchKernelGGL(k_excite, grid, block, 0, stream, bd, vd);
     return hipGetLastError();
 }
 
@@ -512,9 +545,8 @@ hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int stat
 {
     if (n_items == 0)
         return hipSuccess;
-    // filter part of the state = everything before the 64-slot excitation ring
     hipLaunchKernelGGL(k_voc_verify, dim3(n_items), dim3(64), 0, stream, work_dev, n_items,
-                       state_doubles - 64, tol, bad, n_bad);
+                       state_doubles - 4, tol, bad, n_bad);
     return hipGetLastError();
 }
 
