@@ -105,6 +105,8 @@ typedef struct jb_batch_opts {
 #define JB_BATCH_KEEP_TRACKS 1u  /* keep MLPG parameter tracks readable (tests) */
 #define JB_BATCH_GENERIC_MLPG 2u /* un-fused, reference-shaped MLPG kernels (A/B parity tests) */
 #define JB_BATCH_SERIAL 4u       /* one wave per utterance, no time-chunking (reference-shaped recursion) */
+#define JB_BATCH_WAVE_KERNEL 8u  /* always the wave-per-chunk vocoder kernel (A/B tests) */
+#define JB_BATCH_PAIR_KERNEL 16u /* always the lane-pair throughput kernel (A/B tests) */
 
 /* Time-chunked vocoder (default).  The MLSA recursion is time-serial per utterance
  * (src/vocoder/mlsa.rs), but it forgets its initial state within ~16 frames (measured:

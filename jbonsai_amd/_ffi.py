@@ -24,6 +24,8 @@ ERRORS = {
 BATCH_KEEP_TRACKS = 1
 BATCH_GENERIC_MLPG = 2
 BATCH_SERIAL = 4
+BATCH_WAVE_KERNEL = 8
+BATCH_PAIR_KERNEL = 16
 
 
 class JbError(RuntimeError):

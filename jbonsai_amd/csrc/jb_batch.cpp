@@ -483,8 +483,22 @@ int Batch::build_work(const jb_batch_opts *opts)
     warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 32;
     verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
     uint32_t ch = opts ? opts->chunk_frames : 0;
+    // lane-pair throughput kernel: worth it once the batch holds enough frames to give
+    // every SIMD 32 chunks that are long against the warm-up
+    uint64_t lp_min = 1500000;
+    if (const char *e = getenv("JB_LP_MIN_FRAMES"))
+        lp_min = strtoull(e, nullptr, 10);
+    lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vocoder_ls_supported(vd.nmcp) &&
+              (sumT >= lp_min || (flags & JB_BATCH_PAIR_KERNEL));
     if (serial) {
         ch = 0;
+    } else if (ch == 0 && lp_mode) {
+        uint64_t target = 32768; // 1024 SIMDs x 32 lane pairs
+        if (const char *e = getenv("JB_LP_TARGET"))
+            target = strtoull(e, nullptr, 10);
+        uint64_t c = (sumT + target - 1) / target;
+        ch = (uint32_t)std::max<uint64_t>(c, 2ull * warmup_frames);
+        ch = (ch + 3) / 4 * 4;
     } else if (ch == 0) {
         // auto: enough items to fill 1024 SIMDs several waves deep, chunks >= 4x the warm-up
         uint64_t target = 24576;
@@ -525,8 +539,9 @@ int Batch::build_work(const jb_batch_opts *opts)
         (rc = dalloc(&nbad_dev, 1, true)))
         return rc;
     if (ch != 0) {
-        if ((rc = dalloc(&end_state, (size_t)n_items * stride, false)) ||
-            (rc = dalloc(&warm_state, (size_t)n_items * stride, false)))
+        // zeroed: slots of the state layout that a kernel does not write must compare equal
+        if ((rc = dalloc(&end_state, (size_t)n_items * stride, true)) ||
+            (rc = dalloc(&warm_state, (size_t)n_items * stride, true)))
             return rc;
         for (uint32_t k = 0; k < n_items; k++) {
             VocWork &w = work[k];
@@ -540,6 +555,18 @@ int Batch::build_work(const jb_batch_opts *opts)
     }
     if (n_items)
         hipMemcpy(work_dev, work.data(), sizeof(VocWork) * n_items, hipMemcpyHostToDevice);
+    if (lp_mode) {
+        // launch permutation: equal-length chunks share a wave (lanes run in lock step)
+        std::vector<uint32_t> ord(n_items);
+        std::iota(ord.begin(), ord.end(), 0u);
+        std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
+            return (work[x].t_end - work[x].t_start) > (work[y].t_end - work[y].t_start);
+        });
+        if ((rc = dalloc(&order_dev, n_items, false)))
+            return rc;
+        if (n_items)
+            hipMemcpy(order_dev, ord.data(), sizeof(uint32_t) * n_items, hipMemcpyHostToDevice);
+    }
     return JB_OK;
 }
 
@@ -564,7 +591,11 @@ int Batch::build_generator_work()
 int Batch::enqueue_vocoder()
 {
     hipError_t e;
-    if ((e = launch_vocoder(bd, vd, work_dev, n_items, stream)) != hipSuccess)
+    if (lp_mode)
+        e = launch_vocoder_ls(bd, vd, work_dev, order_dev, n_items, stream);
+    else
+        e = launch_vocoder(bd, vd, work_dev, n_items, stream);
+    if (e != hipSuccess)
         return hip_fail(e, "k_vocoder");
     return JB_OK;
 }

@@ -119,6 +119,10 @@ hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream
 hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                           hipStream_t stream);
+// lane-serial throughput kernel (one chunk per lane); order_dev = launch permutation of items
+bool vocoder_ls_supported(int nmcp);
+hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
+                             const uint32_t *order_dev, uint32_t n_items, hipStream_t stream);
 // compares save_warm of item i with save_end of item i-1 (same utterance): bad[i]=1 and
 // ++*n_bad when max|diff| > tol * max|state|
 hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, double tol,

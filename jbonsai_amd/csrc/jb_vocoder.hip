@@ -456,6 +456,208 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
 }
 
 // --------------------------------------------------------------------------
+// Lane-pair throughput kernel: ONE CHUNK PER LANE PAIR.
+// With time-chunking there are tens of thousands of independent recursions per
+// batch, so the cross-lane machinery of k_vocoder (DPP scans, readlane combines:
+// ~128 VALU instructions per sample, most of them data movement) can be dropped.
+// The five Pade stages of df2 exchange data only BETWEEN samples (stage i reads
+// d22[i-1] of the previous sample, mlsa.rs:71-77), so a chunk is split over two
+// adjacent lanes: the even lane runs stages 1-3, the odd lane stages 4-5 (+ an inert
+// slot), each with its (nmcp-1)-tap state in architectural VGPRs (102 doubles), taps
+// outermost so the three slots give 3-way ILP.  Per sample the pair swaps three
+// values with quad_perm DPP; everything else is lane-local.  The interpolated
+// coefficients c(n) = c0 + i*cinc live in LDS as [tap][pair] pairs (broadcast
+// ds_read_b128).  ~17 VALU instructions per sample instead of ~128.
+// Inputs: gained excitation (k_excite) and bcoef; each pair streams its own column.
+// State dumps use k_vocoder's layout so that verification and re-do are shared
+// (slots nobody writes stay zero: the state buffers are zeroed at allocation).
+constexpr int DPP_QUAD_SWAP = 0xB1; // quad_perm:[1,0,3,2]
+
+template <int NM, int TPLW>
+__global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
+                                                       const VocWork *__restrict__ work,
+                                                       const uint32_t *__restrict__ order,
+                                                       uint32_t n_items)
+{
+    constexpr int M = NM - 1; // live taps 1..M
+    constexpr int NS = 3;     // stage slots per lane
+    const int lane = threadIdx.x;
+    const int pair = lane >> 1;
+    const bool isA = (lane & 1) == 0; // even lane: stages 0..2; odd lane: stages 3,4 + inert slot
+    const uint32_t slot = blockIdx.x * 32u + (uint32_t)pair;
+    const bool has = slot < n_items;
+    VocWork wk;
+    wk.utt = 0;
+    wk.t_start = wk.t_out = wk.t_end = 0;
+    wk.load_state = nullptr;
+    wk.save_warm = wk.save_end = nullptr;
+    if (has)
+        wk = work[order[slot]];
+    const uint32_t T = has ? bd.utt[wk.utt].T : 0;
+    if (wk.t_end > T)
+        wk.t_end = T;
+    const uint32_t nfr = wk.t_end > wk.t_start ? wk.t_end - wk.t_start : 0;
+    uint32_t maxfr = nfr;
+    for (int o = 32; o > 0; o >>= 1)
+        maxfr = max(maxfr, (uint32_t)__shfl_xor((int)maxfr, o));
+    if (maxfr == 0)
+        return;
+    const uint64_t base = has ? bd.utt[wk.utt].frame_off : 0;
+    const int fp = vd.fperiod;
+    const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
+    const int s0 = isA ? 0 : 3; // first stage of this lane
+
+    __shared__ double2 cc[NM][32]; // (c at frame start, per-sample increment) per pair
+    __shared__ double f1s[12][64]; // df1 state d11[0..5], d12[0..5], per lane (12 x 8 B, conflict-free)
+
+    double d[NS][M + 1];
+    double u[NS]; // slot inputs (d22[stage])
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+        u[q] = 0.0;
+#pragma unroll
+        for (int j = 0; j <= M; j++)
+            d[q][j] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+        f1s[i][lane] = 0.0;
+
+    // k_vocoder state layout: tap j of stage s at [64*k + 12*s + g], j-1 = g*TPLW + k
+    if (wk.load_state) {
+        const double *sp = wk.load_state;
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+            const int st = s0 + q;
+            if (st < kPade) {
+                u[q] = sp[64 * TPLW + kGroups * st];
+#pragma unroll
+                for (int j = 1; j <= M; j++)
+                    d[q][j] = sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            f1s[i][lane] = sp[64 * TPLW + 64 + i];
+    }
+    auto save_state = [&](double *sp) {
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+            const int st = s0 + q;
+            if (st < kPade) {
+                sp[64 * TPLW + kGroups * st] = u[q];
+#pragma unroll
+                for (int j = 1; j <= M; j++)
+                    sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW] = d[q][j];
+            }
+        }
+        if (isA) {
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                sp[64 * TPLW + 64 + i] = f1s[i][lane];
+        }
+    };
+
+    for (uint32_t tl = 0; tl < maxfr; tl++) {
+        const bool act = tl < nfr;
+        const uint32_t t = wk.t_start + (act ? tl : 0);
+        const uint64_t f = base + t;
+        const bool emit = act && isA && t >= wk.t_out;
+        if (act && t == wk.t_out && wk.t_out > wk.t_start && wk.save_warm)
+            save_state(wk.save_warm);
+        // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
+        // the two lanes of a pair fill alternate taps
+        __syncthreads();
+        if (has) {
+            const double *bcur = vd.bcoef + f * (uint64_t)NM;
+            const double *bprev = (t > 0) ? bcur - NM : bcur;
+            for (int k = 1 + (lane & 1); k < NM; k += 2) {
+                const double c0v = bprev[k], c1v = bcur[k];
+                cc[k][pair] = make_double2(c0v, (c1v - c0v) / (double)fp);
+            }
+        }
+        __syncthreads();
+        const double *xp = vd.xin + (base + t) * (uint64_t)fp;
+        double *op = vd.pcm + (base + t) * (uint64_t)fp;
+        double xn = act ? xp[0] : 0.0;
+        for (int i = 0; i < fp; i++) {
+            double x = xn;
+            if (i + 1 < fp)
+                xn = act ? xp[i + 1] : 0.0;
+            const double fi = (double)i;
+            // ---- V6 df1 (mlsa.rs:54-66), both lanes of the pair redundantly ----
+            {
+                const double2 c1p = cc[1][pair];
+                const double c1 = fma(fi, c1p.y, c1p.x);
+                double out = 0.0;
+#pragma unroll
+                for (int ii = 5; ii >= 1; ii--) {
+                    const double n11 = fma(iaa, f1s[6 + ii - 1][lane], a * f1s[ii][lane]);
+                    const double n12 = n11 * c1;
+                    f1s[ii][lane] = n11;
+                    f1s[6 + ii][lane] = n12;
+                    const double v = n12 * kPPade[ii];
+                    x += (ii & 1) ? v : -v;
+                    out += v;
+                }
+                f1s[6][lane] = x;
+                x += out;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- V7 df2: fir() of this lane's stage slots, taps outermost (mlsa.rs:127-163) ----
+            double r[NS], y[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                r[q] = u[q];
+                y[q] = 0.0;
+            }
+#pragma unroll
+            for (int j = 1; j <= M; j++) {
+                double cj = 0.0;
+                if (j >= 2) {
+                    const double2 cp = cc[j][pair];
+                    cj = fma(fi, cp.y, cp.x);
+                }
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    const double rn = fma(-a, r[q], d[q][j]);
+                    d[q][j] = fma(iaa, r[q], a * d[q][j]);
+                    r[q] = rn;
+                    if (j >= 2)
+                        y[q] = fma(cj, d[q][j], y[q]);
+                }
+                // keep the scheduler from hoisting all coefficient reads to the top of the
+                // sample (it would need ~140 extra VGPRs): LDS reads run 4 taps ahead at most
+                if ((j & 1) == 0)
+                    __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, swapped within the pair ----
+            // slot weights: even lane stages 1,2,3 (signs +,-,+), odd lane stages 4,5 (-,+) and 0
+            const double w0 = isA ? kPPade[1] : kPPade[4], w1 = isA ? kPPade[2] : kPPade[5],
+                         w2 = isA ? kPPade[3] : 0.0;
+            const double v0 = w0 * y[0], v1 = w1 * y[1], v2 = w2 * y[2];
+            const double sb = (v0 + v1) + v2;
+            const double sa = isA ? (v0 - v1) + v2 : v1 - v0;
+            const double oa = dpp_f64<DPP_QUAD_SWAP>(sa), ob = dpp_f64<DPP_QUAD_SWAP>(sb);
+            const double y2p = dpp_f64<DPP_QUAD_SWAP>(y[2]); // odd lane: partner's stage-2 output
+            // same order of additions in both lanes: even-lane partial first
+            const double ssum = isA ? sa + oa : oa + sa;
+            const double psum = isA ? sb + ob : ob + sb;
+            const double xmid = x + ssum; // d22[0]
+            x = xmid + psum;
+            // next-sample slot inputs: stage s+1 <- y of stage s; stage 0 <- xmid
+            u[2] = isA ? y[1] : 0.0;
+            u[1] = y[0];
+            u[0] = isA ? xmid : y2p;
+            if (emit)
+                op[i] = x * vol;
+        }
+        if (act && tl + 1 == nfr && wk.save_end)
+            save_state(wk.save_end);
+    }
+}
+
+// --------------------------------------------------------------------------
 // Certification of time-chunked execution: a chunk that started from zero state
 // W frames early must have reached the same filter state as its predecessor's end
 // state.  One wave per item; the excitation ring is feed-forward and not compared.
@@ -547,6 +749,27 @@ hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int stat
         return hipSuccess;
     hipLaunchKernelGGL(k_voc_verify, dim3(n_items), dim3(64), 0, stream, work_dev, n_items,
                        state_doubles - 4, tol, bad, n_bad);
+    return hipGetLastError();
+}
+
+bool vocoder_ls_supported(int nmcp) { return nmcp == 35 || nmcp == 25; }
+
+hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
+                             const uint32_t *order_dev, uint32_t n_items, hipStream_t stream)
+{
+    if (n_items == 0)
+        return hipSuccess;
+    dim3 grid((n_items + 31) / 32), block(64);
+    switch (vd.nmcp) {
+    case 35:
+        hipLaunchKernelGGL((k_vocoder_lp<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+        break;
+    case 25:
+        hipLaunchKernelGGL((k_vocoder_lp<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+        break;
+    default:
+        return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

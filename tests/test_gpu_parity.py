@@ -147,3 +147,28 @@ def test_chunk_handoff_check_triggers_redo(oracle_voice, have_gpu):
     # and with the check effectively disabled the truncated warm-up is visible
     bad, info2 = _run(v, utts, chunk_frames=64, warmup_frames=1, verify_tol=1e30)
     assert info2["n_redo"] == 0 and rel_rms(bad[0], ser[0]) > 1e-6
+
+
+def test_pair_kernel_equals_wave_kernel_and_oracle(oracle_voice, have_gpu):
+    """The lane-pair throughput kernel (one chunk per lane pair, state in registers) against
+    the wave-per-chunk kernel, the serial recursion and the oracle; also through the
+    re-do path, which hands its end states to the wave kernel (shared state layout)."""
+    v = oracle_voice
+    d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
+    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+    utts = [to_utt(d2, s2), to_utt(d1, s1), to_utt(d2, s2)]
+    ser, _ = _run(v, utts, serial=True)
+    wav, _ = _run(v, utts, chunk_frames=64, warmup_frames=32, kernel="wave")
+    par, info = _run(v, utts, chunk_frames=64, warmup_frames=32, kernel="pair")
+    assert info["n_redo"] == 0 and info["n_items"] == 7 + 5 + 7
+    ref = [oracle_run(v, d2, s2)[1], oracle_run(v, d1, s1)[1]]
+    for i in range(3):
+        assert rel_rms(par[i], ser[i]) <= 1e-12, i
+        assert rel_rms(par[i], wav[i]) <= 1e-12, i
+    assert rel_rms(par[0], ref[0]) <= PCM_TOL and rel_rms(par[1], ref[1]) <= PCM_TOL
+    assert np.array_equal(par[0], par[2])
+    print("pair vs serial rel RMS", rel_rms(par[0], ser[0]), rel_rms(par[1], ser[1]))
+    redo, info2 = _run(v, utts, chunk_frames=64, warmup_frames=1, verify_tol=1e-9, kernel="pair")
+    assert info2["n_redo"] >= 6
+    for i in range(3):
+        assert rel_rms(redo[i], ser[i]) <= 1e-12, i
