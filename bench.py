@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=0, help="frames per utterance (0 = 25,546 = ~128 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
+                         "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
     args = ap.parse_args()
 
     import torch  # first: so that this process uses ONE HIP runtime (same SONAME as ours)
@@ -106,7 +109,9 @@ def main():
     # every utterance of the batch is the same sequence (BASELINE config 2: "256 copies"),
     # uploaded once and aliased; outputs / workspace / filter state are per utterance
     utt = synth.synth_utterance(tab, frames, 0)
-    batch = J.Batch(vi, [utt] * args.batch, device=local_rank)
+    depth = max(1, args.pipeline)
+    batches = [J.Batch(vi, [utt] * args.batch, device=local_rank) for _ in range(depth)]
+    batch = batches[0]
     samples_per_step = batch.total_samples
 
     def barrier():
@@ -114,16 +119,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        batch.run()
-        batch.sync()
+    for _ in range(max(args.warmup, 0)):
+        for b_ in batches:
+            b_.run()
+        for b_ in batches:
+            b_.sync()
     barrier()
     t0 = time.perf_counter()
     voc_ms = []
-    for _ in range(args.steps):
-        # run_timed = run + sync with HIP events on the batch's own stream
-        tot, voc = batch.run_timed()
-        voc_ms.append(voc)
+    inflight = [False] * depth
+    for k in range(args.steps):
+        # step k runs on batch k % depth; its stream is independent of the other batch's,
+        # so parameter generation of this step overlaps the vocoder of the previous one
+        j = k % depth
+        if inflight[j]:
+            batches[j].sync()
+            voc_ms.append(batches[j].last_timing()[1])
+        batches[j].run()
+        inflight[j] = True
+    for j in range(depth):
+        if inflight[j]:
+            batches[j].sync()
+            voc_ms.append(batches[j].last_timing()[1])
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -158,6 +175,7 @@ def main():
                             "utterance from real nitech pdfs (BASELINE config 2), nitech voice",
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
                 "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
+                "batches_in_flight": depth,
                 "vocoder_chunk_frames": info["chunk_frames"], "vocoder_warmup_frames": info["warmup_frames"],
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
@@ -172,7 +190,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(utt, vi)
         print(json.dumps(out), flush=True)
-    batch.close()
+    for b_ in batches:
+        b_.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

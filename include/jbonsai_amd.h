@@ -129,6 +129,9 @@ int jb_batch_sync(jb_batch *b);
 /* run + sync, returning device time of the launch sequence in ms (HIP events on
  * the batch's own stream); vocoder_ms = the MLSA kernel alone. */
 int jb_batch_run_timed(jb_batch *b, float *total_ms, float *vocoder_ms);
+/* Device times of the last completed run (call after jb_batch_sync): whole launch
+ * sequence and the vocoder kernel alone, from HIP events on the batch's stream. */
+int jb_batch_last_timing(jb_batch *b, float *total_ms, float *vocoder_ms);
 size_t jb_batch_size(const jb_batch *b);
 size_t jb_batch_num_frames(const jb_batch *b, size_t utt);
 size_t jb_batch_num_samples(const jb_batch *b, size_t utt);

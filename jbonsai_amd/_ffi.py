@@ -87,7 +87,7 @@ class BatchOpts(C.Structure):
 
 # every symbol include/jbonsai_amd.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_size",
+    "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_last_timing", "jb_batch_size",
     "jb_batch_num_frames", "jb_batch_num_samples", "jb_batch_total_samples", "jb_batch_read_pcm",
     "jb_batch_read_track", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
     "jb_batch_info", "jb_batch_free", "jb_paramgen_vocode_batch",
@@ -143,6 +143,7 @@ def lib():
     L.jb_batch_run.argtypes = [vp]
     L.jb_batch_sync.argtypes = [vp]
     L.jb_batch_run_timed.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.jb_batch_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     for n in ("jb_batch_size", "jb_batch_total_samples"):
         getattr(L, n).restype = sz
         getattr(L, n).argtypes = [vp]

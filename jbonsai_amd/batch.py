@@ -132,6 +132,12 @@ class Batch:
         F.check(self._L.jb_batch_run_timed(self._h, C.byref(t), C.byref(v)))
         return t.value, v.value
 
+    def last_timing(self):
+        """(total_ms, vocoder_kernel_ms) of the last completed run (after sync())."""
+        t, v = C.c_float(), C.c_float()
+        F.check(self._L.jb_batch_last_timing(self._h, C.byref(t), C.byref(v)))
+        return t.value, v.value
+
     def info(self):
         """(chunk_frames, warmup_frames, n_items, n_redo) of the last run."""
         v = [C.c_uint32() for _ in range(4)]

@@ -783,7 +783,7 @@ int jb_batch_create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t
     return rc;
 }
 
-int jb_batch_run(jb_batch *b) { return b ? ((Batch *)b)->run(false) : JB_ERR_INVALID; }
+int jb_batch_run(jb_batch *b) { return b ? ((Batch *)b)->run(true) : JB_ERR_INVALID; }
 int jb_batch_sync(jb_batch *b) { return b ? ((Batch *)b)->sync() : JB_ERR_INVALID; }
 
 int jb_batch_run_timed(jb_batch *hb, float *total_ms, float *vocoder_ms)
@@ -796,9 +796,20 @@ int jb_batch_run_timed(jb_batch *hb, float *total_ms, float *vocoder_ms)
         return rc;
     if ((rc = b->sync()))
         return rc;
+    return jb_batch_last_timing(hb, total_ms, vocoder_ms);
+}
+
+int jb_batch_last_timing(jb_batch *hb, float *total_ms, float *vocoder_ms)
+{
+    if (!hb)
+        return JB_ERR_INVALID;
+    Batch *b = (Batch *)hb;
     float t = 0, v = 0;
-    hipEventElapsedTime(&t, b->ev0, b->ev2);
-    hipEventElapsedTime(&v, b->ev1, b->ev2);
+    if (hipEventElapsedTime(&t, b->ev0, b->ev3) != hipSuccess ||
+        hipEventElapsedTime(&v, b->ev1, b->ev2) != hipSuccess) {
+        jb::set_error("no completed timed run");
+        return JB_ERR_INVALID;
+    }
     if (total_ms)
         *total_ms = t;
     if (vocoder_ms)

@@ -51,29 +51,39 @@ __global__ void k_pitch(BatchDev bd, VocDev vd)
     vd.pitch[f] = p;
 }
 
-// V2b: mc2b, thread per frame (cepstrum.rs:139-149).
-__global__ void k_mc2b(BatchDev bd, VocDev vd)
+// V2b: mc2b (cepstrum.rs:139-149).  64 frames per block staged through LDS so that both
+// the read of mcp and the write of bcoef are coalesced; each thread then runs the
+// recurrence b[i] = c[i] - alpha*b[i+1] of its own frame out of LDS (row stride 65: no
+// bank conflicts for column access).
+constexpr int kMc2bFrames = 64;
+constexpr int kMc2bMax = 64; // nmcp <= 61
+
+__global__ __launch_bounds__(kMc2bFrames) void k_mc2b(BatchDev bd, VocDev vd)
 {
     const int b = blockIdx.y;
     const UttDev *u = bd.utt + b;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= u->T)
+    const uint32_t t0 = blockIdx.x * kMc2bFrames;
+    if (t0 >= u->T)
         return;
-    const uint64_t f = u->frame_off + t;
     const int n = vd.nmcp;
-    const double *mc = vd.mcp + f * (uint64_t)n;
-    double *bc = vd.bcoef + f * (uint64_t)n;
-    if (vd.alpha != 0.0) {
-        double prev = mc[n - 1];
-        bc[n - 1] = prev;
+    const uint32_t nf = min((uint32_t)kMc2bFrames, u->T - t0);
+    const uint64_t off = (u->frame_off + t0) * (uint64_t)n;
+    const uint32_t tot = nf * (uint32_t)n;
+    __shared__ double tile[kMc2bMax][kMc2bFrames + 1]; // [coef][frame]
+    const int tid = threadIdx.x;
+    for (uint32_t e = tid; e < tot; e += kMc2bFrames)
+        tile[e % n][e / n] = vd.mcp[off + e];
+    __syncthreads();
+    if ((uint32_t)tid < nf && vd.alpha != 0.0) {
+        double prev = tile[n - 1][tid];
         for (int i = n - 2; i >= 0; i--) {
-            prev = mc[i] - vd.alpha * prev;
-            bc[i] = prev;
+            prev = tile[i][tid] - vd.alpha * prev;
+            tile[i][tid] = prev;
         }
-    } else {
-        for (int i = 0; i < n; i++)
-            bc[i] = mc[i];
     }
+    __syncthreads();
+    for (uint32_t e = tid; e < tot; e += kMc2bFrames)
+        vd.bcoef[off + e] = tile[e % n][e / n];
 }
 
 // --------------------------------------------------------------------------
@@ -196,21 +206,23 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     const uint64_t n = n0 + (uint64_t)tid;
     if (n >= N)
         return;
+    const uint32_t fr = (uint32_t)(n / (uint64_t)fp);
+    const int i = (int)(n - (uint64_t)fr * (uint64_t)fp);
     double x = n >= (uint64_t)anti ? vd.noise[n - (uint64_t)anti] : 0.0;
     if (anyv) {
-        for (int k = 0; k < nlpf; k++) {
-            const long m = (long)n - k;
-            if (m < 0)
-                break;
-            const uint32_t fr = (uint32_t)((uint64_t)m / (uint64_t)fp);
-            x = fma(e[kExcHalo + tid - k], taps[fr - f_lo][k], x);
-        }
+        // source sample n-k lies in this frame while k <= i, in the previous one after that
+        // (nlpf-1 < fperiod); taps of the SOURCE sample's frame (excitation.rs:48-64)
+        const double *tc = taps[fr - f_lo];
+        const double *tp = taps[fr > f_lo ? fr - f_lo - 1 : 0];
+        const int kmax = n + 1 < (uint64_t)nlpf ? (int)n + 1 : nlpf;
+        const double *ep = e + kExcHalo + tid;
+#pragma unroll 4
+        for (int k = 0; k < kmax; k++)
+            x = fma(ep[-k], k <= i ? tc[k] : tp[k], x);
     }
     if (vd.exc)
         vd.exc[base * (uint64_t)fp + n] = x;
     // gain with the interpolated c[0]: c0(t-1) + i*(c0(t)-c0(t-1))/fperiod
-    const uint32_t fr = (uint32_t)(n / (uint64_t)fp);
-    const int i = (int)(n - (uint64_t)fr * (uint64_t)fp);
     const double bc = vd.bcoef[(base + fr) * (uint64_t)nmcp];
     const double bp = fr > 0 ? vd.bcoef[(base + fr - 1) * (uint64_t)nmcp] : bc;
     if (x != 0.0)
@@ -718,7 +730,7 @@ hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
-    dim3 grid((bd.maxT + 255) / 256, bd.B), block(256);
+    dim3 grid((bd.maxT + kMc2bFrames - 1) / kMc2bFrames, bd.B), block(kMc2bFrames);
     hipLaunchKernelGGL(k_mc2b, grid, block, 0, stream, bd, vd);
     return hipGetLastError();
 }
