@@ -423,9 +423,10 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
                 double r = fma(nh, dpp_f64<DPP_WAVE_SHR1>(I), ulane); // rem entering tap 0 of lane
 #pragma unroll
                 for (int k = 0; k < TPL; k++) {
-                    const double dn = fma(iaa, r, a * d[k]);
-                    r = fma(-a, r, d[k]);
-                    d[k] = dn;
+                    // all-pass section: rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem'
+                    const double rn = fma(-a, r, d[k]);
+                    d[k] = fma(a, rn, r);
+                    r = rn;
                 }
                 double yl = cd[0] * d[0];
 #pragma unroll
@@ -632,6 +633,8 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
                 }
 #pragma unroll
                 for (int q = 0; q < NS; q++) {
+                    // d' = (1-a^2)*rem + a*d and rem' = d - a*rem kept independent of each other:
+                    // at one wave per SIMD the shorter dependency chain beats the 2-FMA form
                     const double rn = fma(-a, r[q], d[q][j]);
                     d[q][j] = fma(iaa, r[q], a * d[q][j]);
                     r[q] = rn;
@@ -640,7 +643,10 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
                 }
                 // keep the scheduler from hoisting all coefficient reads to the top of the
                 // sample (it would need ~140 extra VGPRs): LDS reads run 4 taps ahead at most
-                if ((j & 1) == 0)
+#ifndef JB_LP_SB
+#define JB_LP_SB 2
+#endif
+                if ((j % JB_LP_SB) == 0)
                     __builtin_amdgcn_sched_barrier(0);
             }
             // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, swapped within the pair ----
