@@ -493,7 +493,7 @@ int Batch::build_work(const jb_batch_opts *opts)
     if (serial) {
         ch = 0;
     } else if (ch == 0 && lp_mode) {
-        uint64_t target = 32768; // 1024 SIMDs x 32 lane pairs
+        uint64_t target = 65536; // 1024 SIMDs x 2 waves x 32 lane pairs
         if (const char *e = getenv("JB_LP_TARGET"))
             target = strtoull(e, nullptr, 10);
         uint64_t c = (sumT + target - 1) / target;

@@ -486,8 +486,11 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
 // (slots nobody writes stay zero: the state buffers are zeroed at allocation).
 constexpr int DPP_QUAD_SWAP = 0xB1; // quad_perm:[1,0,3,2]
 
+#ifndef JB_LP_WAVES
+#define JB_LP_WAVES 2
+#endif
 template <int NM, int TPLW>
-__global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
+__global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, VocDev vd,
                                                        const VocWork *__restrict__ work,
                                                        const uint32_t *__restrict__ order,
                                                        uint32_t n_items)
@@ -520,8 +523,9 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
     const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
     const int s0 = isA ? 0 : 3; // first stage of this lane
 
-    __shared__ double2 cc[NM][32]; // (c at frame start, per-sample increment) per pair
-    __shared__ double f1s[12][64]; // df1 state d11[0..5], d12[0..5], per lane (12 x 8 B, conflict-free)
+    // 34*512 + 12*256 = 20480 B = 160 KiB / 8: two blocks per SIMD fit the CU's LDS
+    __shared__ double2 cc[NM - 1][32]; // row k-1: (c_k at frame start, per-sample increment) per pair
+    __shared__ double f1s[12][32];     // df1 state d11[0..5], d12[0..5] per pair (both lanes compute it)
 
     double d[NS][M + 1];
     double u[NS]; // slot inputs (d22[stage])
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
     }
 #pragma unroll
     for (int i = 0; i < 12; i++)
-        f1s[i][lane] = 0.0;
+        f1s[i][pair] = 0.0;
 
     // k_vocoder state layout: tap j of stage s at [64*k + 12*s + g], j-1 = g*TPLW + k
     if (wk.load_state) {
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
         }
 #pragma unroll
         for (int i = 0; i < 12; i++)
-            f1s[i][lane] = sp[64 * TPLW + 64 + i];
+            f1s[i][pair] = sp[64 * TPLW + 64 + i];
     }
     auto save_state = [&](double *sp) {
 #pragma unroll
@@ -567,7 +571,7 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
         if (isA) {
 #pragma unroll
             for (int i = 0; i < 12; i++)
-                sp[64 * TPLW + 64 + i] = f1s[i][lane];
+                sp[64 * TPLW + 64 + i] = f1s[i][pair];
         }
     };
 
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
             const double *bprev = (t > 0) ? bcur - NM : bcur;
             for (int k = 1 + (lane & 1); k < NM; k += 2) {
                 const double c0v = bprev[k], c1v = bcur[k];
-                cc[k][pair] = make_double2(c0v, (c1v - c0v) / (double)fp);
+                cc[k - 1][pair] = make_double2(c0v, (c1v - c0v) / (double)fp);
             }
         }
         __syncthreads();
@@ -600,20 +604,23 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
             const double fi = (double)i;
             // ---- V6 df1 (mlsa.rs:54-66), both lanes of the pair redundantly ----
             {
-                const double2 c1p = cc[1][pair];
+                const double2 c1p = cc[0][pair];
                 const double c1 = fma(fi, c1p.y, c1p.x);
                 double out = 0.0;
 #pragma unroll
                 for (int ii = 5; ii >= 1; ii--) {
-                    const double n11 = fma(iaa, f1s[6 + ii - 1][lane], a * f1s[ii][lane]);
+                    const double n11 = fma(iaa, f1s[6 + ii - 1][pair], a * f1s[ii][pair]);
                     const double n12 = n11 * c1;
-                    f1s[ii][lane] = n11;
-                    f1s[6 + ii][lane] = n12;
+                    if (isA) {
+                        f1s[ii][pair] = n11;
+                        f1s[6 + ii][pair] = n12;
+                    }
                     const double v = n12 * kPPade[ii];
                     x += (ii & 1) ? v : -v;
                     out += v;
                 }
-                f1s[6][lane] = x;
+                if (isA)
+                    f1s[6][pair] = x;
                 x += out;
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(64, 1) void k_vocoder_lp(BatchDev bd, VocDev vd,
             for (int j = 1; j <= M; j++) {
                 double cj = 0.0;
                 if (j >= 2) {
-                    const double2 cp = cc[j][pair];
+                    const double2 cp = cc[j - 1][pair];
                     cj = fma(fi, cp.y, cp.x);
                 }
 #pragma unroll
