@@ -181,10 +181,10 @@ def main():
             },
             "realtime_factor": value / vi.sampling_frequency,
             "roofline": {
-                "bound": "hbm", "kernel": "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "k_vocoder_lp" if info["chunk_frames"] and info["n_items"] >= 16384 else "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": voc_avg_ms, "alg_bytes_per_sample": B_ALG,
-                "note": "recursive IIR: serial-chain / VALU-issue bound, not HBM bound (DESIGN.md)",
+                "note": "recursive IIR: FP64 VALU-issue bound, not HBM bound (DESIGN.md section 4)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

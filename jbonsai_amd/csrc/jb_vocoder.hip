@@ -579,7 +579,7 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
         const bool act = tl < nfr;
         const uint32_t t = wk.t_start + (act ? tl : 0);
         const uint64_t f = base + t;
-        const bool emit = act && isA && t >= wk.t_out;
+        const bool emit = act && t >= wk.t_out;
         if (act && t == wk.t_out && wk.t_out > wk.t_start && wk.save_warm)
             save_state(wk.save_warm);
         // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
@@ -597,6 +597,11 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
         const double *xp = vd.xin + (base + t) * (uint64_t)fp;
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
+        // PCM leaves in 32-byte sectors: over 4 samples the even lane latches samples 0,1 and
+        // the odd lane 2,3 of the group, then both store 16 B (8-byte per-lane stores would
+        // cost a whole sector each: measured 4x write amplification)
+        double o0 = 0.0, o1 = 0.0;
+        const bool quad = (fp & 3) == 0;
         for (int i = 0; i < fp; i++) {
             double x = xn;
             if (i + 1 < fp)
@@ -674,8 +679,18 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
             u[2] = isA ? y[1] : 0.0;
             u[1] = y[0];
             u[0] = isA ? xmid : y2p;
-            if (emit)
-                op[i] = x * vol;
+            const double pv = x * vol;
+            if (quad) {
+                const int ph = i & 3;
+                if (ph == (isA ? 0 : 2))
+                    o0 = pv;
+                if (ph == (isA ? 1 : 3))
+                    o1 = pv;
+                if (ph == 3 && emit)
+                    *reinterpret_cast<double2 *>(op + (i - 3) + (isA ? 0 : 2)) = make_double2(o0, o1);
+            } else if (emit && isA) {
+                op[i] = pv;
+            }
         }
         if (act && tl + 1 == nfr && wk.save_end)
             save_state(wk.save_end);
