@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=0, help="frames per utterance (0 = 25,546 = ~128 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=1,
                     help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
                          "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
     args = ap.parse_args()

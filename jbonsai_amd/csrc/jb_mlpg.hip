@@ -19,6 +19,8 @@
 // Compiled with -ffp-contract=off.
 #include "jb_device.h"
 
+#include <cstdlib>
+
 namespace jb {
 
 // --------------------------------------------------------------------------
@@ -414,7 +416,7 @@ __global__ void k_mlpg_static(BatchDev bd, StreamDev sd, int si)
 #endif
 constexpr int MU = JB_MU;
 
-template <bool NONMSD>
+template <bool NONMSD, bool DOGV>
 __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, int si)
 {
     const int b = blockIdx.y;
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
             }
         }
         // ---- GV (mlpg.rs:145-292) ----
-        if (gv_on) {
+        if (DOGV && gv_on) {
             const double gv_mean = st.gv_mean[m] * st.gv_weight; // mlpg.rs:135-137
             const double gv_vari = st.gv_var[m];
             const double glen = (double)sd.gvlen[b];
@@ -688,6 +690,157 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
 #undef CP
 }
 
+// --------------------------------------------------------------------------
+// A8 GV ascent with LANES OVER TIME (mlpg.rs:145-292).  The 13 sweeps of conv_gv and the
+// five parmgen iterations are elementwise in t plus reductions; only the ORDER of the
+// additions is serial.  One wave per (utterance, dim): 64 frames per vector instruction for
+// everything elementwise (loads, gradient, Newton step, stores), and the reductions run as
+// an in-order chain acc += v[lane 0]; acc += v[lane 1]; ... with v_readlane -- the
+// reference's order of additions exactly (a switched-off frame contributes +0.0, which
+// leaves the sum bit-identical), so the result stays bit-exact while LF0 uses 64 lanes
+// instead of 1 and MCP runs 35x more waves than the lane-per-dim solver.
+__device__ __forceinline__ double rl64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double serial_add64(double acc, double v)
+{
+#pragma unroll
+    for (int u = 0; u < 64; u++)
+        acc += rl64(v, u);
+    return acc;
+}
+
+template <bool NONMSD>
+__global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, int si)
+{
+    const int m = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const UttDev *up = bd.utt + b;
+    const StreamStatesDev st = up->st[si];
+    const uint32_t n = sd.Tv[b];
+    const uint32_t gvl = sd.gvlen[b];
+    if (n == 0 || !(sd.use_gv && st.gv_mean && gvl > 0))
+        return;
+    const int L = sd.L;
+    const uint64_t base = up->frame_off;
+    const uint64_t o0 = base * (uint64_t)L + (uint64_t)m, Ls = (uint64_t)L;
+#define IX(k) (o0 + (uint64_t)(k) * Ls)
+    const uint8_t *sw = sd.vsw + base;
+    const double *A0 = sd.A[0], *A1 = sd.A[1], *A2 = sd.A[2], *Bv = sd.bvec;
+    double *Gv = sd.g, *Pv = sd.par, *Ov = sd.out;
+    const double gv_mean = st.gv_mean[m] * st.gv_weight; // mlpg.rs:135-137
+    const double gv_vari = st.gv_var[m];
+    const double glen = (double)gvl;
+
+    // conv_gv (mlpg.rs:195-203)
+    double ssum = 0.0;
+    for (uint32_t tb = 0; tb < n; tb += 64) {
+        const uint32_t t = tb + (uint32_t)lane;
+        const bool on = t < n && sw[t < n ? t : 0];
+        ssum = serial_add64(ssum, on ? Pv[IX(t)] : 0.0);
+    }
+    double mean = ssum / glen;
+    double vsum = 0.0;
+    for (uint32_t tb = 0; tb < n; tb += 64) {
+        const uint32_t t = tb + (uint32_t)lane;
+        const bool on = t < n && sw[t < n ? t : 0];
+        const double p = on ? Pv[IX(t)] : mean;
+        vsum = serial_add64(vsum, on ? (p - mean) * (p - mean) : 0.0);
+    }
+    double vari = vsum / glen;
+    {
+        const double ratio = sqrt(gv_mean / vari);
+        ssum = 0.0;
+        for (uint32_t tb = 0; tb < n; tb += 64) {
+            const uint32_t t = tb + (uint32_t)lane;
+            const bool on = t < n && sw[t < n ? t : 0];
+            double pn = 0.0;
+            if (on) {
+                pn = ratio * (Pv[IX(t)] - mean) + mean;
+                Pv[IX(t)] = pn;
+            }
+            ssum = serial_add64(ssum, pn);
+        }
+    }
+    double step = 0.1, prev = 0.0; // STEPINIT
+    const double length = (double)n;
+    const double wgt = 1.0 / (double)((uint64_t)sd.W * (uint64_t)n);
+    const double ll = (double)((uint64_t)n * (uint64_t)n);
+    const double lm1 = (double)(n - 1);
+    for (int it = 1; it <= 5; it++) { // GV_MAX_ITERATION
+        mean = ssum / glen;
+        // ---- sweep V: variance + calc_hmmobj_derivative (mlpg.rs:173-229) ----
+        double hmmobj = 0.0;
+        vsum = 0.0;
+        __syncthreads(); // par written by other lanes in the previous sweep is visible (one wave)
+        for (uint32_t tb = 0; tb < n; tb += 64) {
+            const uint32_t t = tb + (uint32_t)lane;
+            double vs = 0.0, hv = 0.0;
+            if (t < n) {
+                const double p0 = Pv[IX(t)];
+                if (sw[t])
+                    vs = (p0 - mean) * (p0 - mean);
+                double g = A0[IX(t)] * p0;
+                if (t + 1 < n)
+                    g += A1[IX(t)] * Pv[IX(t + 1)];
+                if (t >= 1)
+                    g += A1[IX(t - 1)] * Pv[IX(t - 1)];
+                if (t + 2 < n)
+                    g += A2[IX(t)] * Pv[IX(t + 2)];
+                if (t >= 2)
+                    g += A2[IX(t - 2)] * Pv[IX(t - 2)];
+                Gv[IX(t)] = g;
+                hv = 1.0 * wgt * p0 * (Bv[IX(t)] - 0.5 * g);
+            }
+            vsum = serial_add64(vsum, vs);
+            // hmmobj has no switch: frames beyond n contribute nothing (exact: + 0.0)
+            hmmobj = serial_add64(hmmobj, hv);
+        }
+        vari = vsum / glen;
+        const double gvobj = -0.5 * 1.0 * vari * gv_vari * (vari - 2.0 * gv_mean);
+        const double obj = -(hmmobj + gvobj);
+        if (it > 1) {
+            if (obj > prev)
+                step *= 0.5; // STEPDEC
+            else if (obj < prev)
+                step *= 1.2; // STEPINC
+        }
+        // ---- sweep N: next_step (mlpg.rs:230-258) + sum for the next mean ----
+        const double dv = -2.0 * gv_vari * (vari - gv_mean) / length;
+        ssum = 0.0;
+        __syncthreads();
+        for (uint32_t tb = 0; tb < n; tb += 64) {
+            const uint32_t t = tb + (uint32_t)lane;
+            double sn = 0.0;
+            if (t < n) {
+                const double p = Pv[IX(t)];
+                const double h = -1.0 * wgt * A0[IX(t)] -
+                                 1.0 * 2.0 / ll *
+                                     (lm1 * gv_vari * (vari - gv_mean) +
+                                      2.0 * gv_vari * (p - mean) * (p - mean));
+                const bool on = sw[t] != 0;
+                double next_g;
+                if (on)
+                    next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]) + 1.0 * dv * (p - mean));
+                else
+                    next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]));
+                const double pnew = p + step * next_g;
+                if (NONMSD && it == 5)
+                    Ov[IX(t)] = pnew; // scatter fused into the last sweep
+                else
+                    Pv[IX(t)] = pnew;
+                if (on)
+                    sn = pnew;
+            }
+            ssum = serial_add64(ssum, sn);
+        }
+        prev = obj;
+    }
+#undef IX
+}
+
 // A9 Mask::fill with NODATA (mask.rs:34-49, mod.rs:89-91) for MSD streams:
 // thread per (frame, dim); compacted index = s_vpre[state] + offset within state.
 __global__ void k_mlpg_scatter(BatchDev bd, StreamDev sd)
@@ -739,12 +892,25 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
     {
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         if (BW == 3 && !sd.generic_solver) {
+            // F/B recurrences lane-per-dim; the GV ascent with lanes over time (one wave per dim)
+            static const bool vt = !(getenv("JB_MLPG_VT") && atoi(getenv("JB_MLPG_VT")) == 0);
+            const bool gv_vt = vt && sd.use_gv && sd.L <= 2; // frames contiguous per lane only for tiny L
+            dim3 gvgrid(sd.L, bd.B);
             if (sd.is_msd) {
-                hipLaunchKernelGGL(k_mlpg_solve3<false>, grid, block, 0, stream, bd, sd, si);
+                if (gv_vt) {
+                    hipLaunchKernelGGL((k_mlpg_solve3<false, false>), grid, block, 0, stream, bd, sd, si);
+                    hipLaunchKernelGGL(k_mlpg_gv_vt<false>, gvgrid, block, 0, stream, bd, sd, si);
+                } else {
+                    hipLaunchKernelGGL((k_mlpg_solve3<false, true>), grid, block, 0, stream, bd, sd, si);
+                }
                 dim3 g2((unsigned)((work + 255) / 256), bd.B), b2(256);
                 hipLaunchKernelGGL(k_mlpg_scatter, g2, b2, 0, stream, bd, sd);
-            } else
-                hipLaunchKernelGGL(k_mlpg_solve3<true>, grid, block, 0, stream, bd, sd, si);
+            } else if (gv_vt) {
+                hipLaunchKernelGGL((k_mlpg_solve3<true, false>), grid, block, 0, stream, bd, sd, si);
+                hipLaunchKernelGGL(k_mlpg_gv_vt<true>, gvgrid, block, 0, stream, bd, sd, si);
+            } else {
+                hipLaunchKernelGGL((k_mlpg_solve3<true, true>), grid, block, 0, stream, bd, sd, si);
+            }
         } else {
             hipLaunchKernelGGL(k_mlpg_solve<BW>, grid, block, 0, stream, bd, sd, si);
         }
