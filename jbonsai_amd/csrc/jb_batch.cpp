@@ -619,7 +619,6 @@ int Batch::enqueue_paramgen()
         return hip_fail(e, "k_pitch");
     if ((e = launch_pulse(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_pulse");
-    hipEventRecord(ev_lf0, stream_lf0);
     // LPF chain
     if (voice.nstream > 2) {
         if ((e = launch_prep(bd, sd[2], 2, stream_lpf)) != hipSuccess)
@@ -628,6 +627,11 @@ int Batch::enqueue_paramgen()
             return hip_fail(e, "k_mlpg(lpf)");
     }
     hipEventRecord(ev_lpf, stream_lpf);
+    // mixed excitation needs pulses (LF0) and LPF taps only: it overlaps the MCP solve
+    hipStreamWaitEvent(stream_lf0, ev_lpf, 0);
+    if ((e = launch_excite(bd, vd, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_excite");
+    hipEventRecord(ev_lf0, stream_lf0);
     // MCP chain
     if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess)
         return hip_fail(e, "k_prep(mcp)");
@@ -636,9 +640,6 @@ int Batch::enqueue_paramgen()
     if ((e = launch_mc2b(bd, vd, stream)) != hipSuccess)
         return hip_fail(e, "k_mc2b");
     hipStreamWaitEvent(stream, ev_lf0, 0);
-    hipStreamWaitEvent(stream, ev_lpf, 0);
-    if ((e = launch_excite(bd, vd, stream)) != hipSuccess)
-        return hip_fail(e, "k_excite");
     return JB_OK;
 }
 

@@ -152,7 +152,8 @@ __global__ void k_pulse(BatchDev bd, VocDev vd)
 // The reference's 31-slot ring buffer (excitation.rs:43-100) is feed-forward:
 //   x[n] = noise[n-15] + sum_k e[n-k] * lpf_{frame(n-k)}[k],
 //   e[m] = voiced(frame(m)) ? pulse[m] - noise[m] : 0          
-// followed by  x *= exp(c0(n))  with the interpolated c[0] (vocoder/mod.rs:129-131).
+// The gain x *= exp(c0(n)) (vocoder/mod.rs:129-131) needs the MCP stream and is applied by
+// the vocoder kernels, so this kernel depends on the LF0 and LPF streams only.
 // Block = 256 consecutive samples of one utterance; e[] for the block and its history is
 // staged in LDS, and so are the LPF taps of the (at most 4) frames the block touches.
 constexpr int kExcBlock = 256;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
 {
     const int b = blockIdx.y;
     const UttDev *u = bd.utt + b;
-    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk, nlpf = vd.nlpf, nmcp = vd.nmcp;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk, nlpf = vd.nlpf;
     const uint64_t N = (uint64_t)u->T * (uint64_t)fp;
     const uint64_t n0 = (uint64_t)blockIdx.x * kExcBlock;
     if (n0 >= N)
@@ -222,11 +223,6 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     }
     if (vd.exc)
         vd.exc[base * (uint64_t)fp + n] = x;
-    // gain with the interpolated c[0]: c0(t-1) + i*(c0(t)-c0(t-1))/fperiod
-    const double bc = vd.bcoef[(base + fr) * (uint64_t)nmcp];
-    const double bp = fr > 0 ? vd.bcoef[(base + fr - 1) * (uint64_t)nmcp] : bc;
-    if (x != 0.0)
-        x *= exp(fma((double)i, (bc - bp) / (double)fp, bp));
     vd.xin[base * (uint64_t)fp + n] = x;
 }
 
@@ -389,6 +385,10 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
         }
         double c1 = bprev[1];
         const double c1inc = (bcur[1] - c1) / (double)fp;
+        // V5 gain exp(c[0]) with the interpolated c[0] (mod.rs:129-131): exp once per frame,
+        // then gain *= exp(cinc0) per sample (240 roundings ~ 2e-14 relative)
+        double gain = exp(bprev[0]);
+        const double gq = exp((bcur[0] - bprev[0]) / (double)fp);
         for (int q = 0; q < nblk; q++) {
             const int i0 = q * bs; // first sample of block within frame
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)i0; // within utterance
@@ -397,7 +397,8 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
             // =========== Phase B: bs serial filter steps ===========
             double ob = 0.0;
             for (int i = 0; i < bs; i++) {
-                double x = readlane_f64(xin, i);
+                double x = readlane_f64(xin, i) * gain;
+                gain *= gq;
                 // ---- V6 df1 (mlsa.rs:54-66), uniform across lanes ----
                 {
                     double out = 0.0;
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
 
     double d[NS][M + 1];
     double u[NS]; // slot inputs (d22[stage])
+    double gain = 1.0;
 #pragma unroll
     for (int q = 0; q < NS; q++) {
         u[q] = 0.0;
@@ -592,18 +594,25 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
                 const double c0v = bprev[k], c1v = bcur[k];
                 cc[k - 1][pair] = make_double2(c0v, (c1v - c0v) / (double)fp);
             }
+            // V5 gain exp(c[0]) (mod.rs:129-131): exp once per frame, gain *= exp(cinc0) per sample;
+            // the per-sample ratio sits in the unused d11[0] slot of the df1 LDS state
+            gain = exp(bprev[0]);
+            if (isA)
+                f1s[0][pair] = exp((bcur[0] - bprev[0]) / (double)fp);
         }
         __syncthreads();
         const double *xp = vd.xin + (base + t) * (uint64_t)fp;
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
+        const double gq = f1s[0][pair];
         // PCM leaves in 32-byte sectors: over 4 samples the even lane latches samples 0,1 and
         // the odd lane 2,3 of the group, then both store 16 B (8-byte per-lane stores would
         // cost a whole sector each: measured 4x write amplification)
         double o0 = 0.0, o1 = 0.0;
         const bool quad = (fp & 3) == 0;
         for (int i = 0; i < fp; i++) {
-            double x = xn;
+            double x = xn * gain;
+            gain *= gq;
             if (i + 1 < fp)
                 xn = act ? xp[i + 1] : 0.0;
             const double fi = (double)i;
