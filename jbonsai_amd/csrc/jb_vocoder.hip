@@ -503,13 +503,21 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
     const bool isA = (lane & 1) == 0; // even lane: stages 0..2; odd lane: stages 3,4 + inert slot
     const uint32_t slot = blockIdx.x * 32u + (uint32_t)pair;
     const bool has = slot < n_items;
-    VocWork wk;
-    wk.utt = 0;
-    wk.t_start = wk.t_out = wk.t_end = 0;
-    wk.load_state = nullptr;
-    wk.save_warm = wk.save_end = nullptr;
-    if (has)
-        wk = work[order[slot]];
+    // only the scalars of the work item stay live; its pointers are re-read at the rare
+    // save points (registers are the scarce resource of this kernel)
+    const uint32_t item = has ? order[slot] : 0u;
+    struct {
+        uint32_t utt, t_start, t_out, t_end;
+        const double *load_state;
+    } wk = {0, 0, 0, 0, nullptr};
+    if (has) {
+        const VocWork &w0 = work[item];
+        wk.utt = w0.utt;
+        wk.t_start = w0.t_start;
+        wk.t_out = w0.t_out;
+        wk.t_end = w0.t_end;
+        wk.load_state = w0.load_state;
+    }
     const uint32_t T = has ? bd.utt[wk.utt].T : 0;
     if (wk.t_end > T)
         wk.t_end = T;
@@ -582,8 +590,11 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
         const uint32_t t = wk.t_start + (act ? tl : 0);
         const uint64_t f = base + t;
         const bool emit = act && t >= wk.t_out;
-        if (act && t == wk.t_out && wk.t_out > wk.t_start && wk.save_warm)
-            save_state(wk.save_warm);
+        if (act && t == wk.t_out && wk.t_out > wk.t_start) {
+            double *sw_ = work[item].save_warm;
+            if (sw_)
+                save_state(sw_);
+        }
         // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
         // the two lanes of a pair fill alternate taps
         __syncthreads();
@@ -701,8 +712,11 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
                 op[i] = pv;
             }
         }
-        if (act && tl + 1 == nfr && wk.save_end)
-            save_state(wk.save_end);
+        if (act && tl + 1 == nfr) {
+            double *se_ = work[item].save_end;
+            if (se_)
+                save_state(se_);
+        }
     }
 }
 
