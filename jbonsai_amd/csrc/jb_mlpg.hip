@@ -27,55 +27,91 @@ namespace jb {
 // A1/A2 in two steps.  The MSD flag is constant within a state, so run boundaries,
 // compaction offsets and boundary distances are decided per STATE (serial over S,
 // one lane per utterance: S ~ 7.5k for 128 s), then expanded per FRAME in parallel.
-__global__ void k_prep_states(BatchDev bd, StreamDev sd, int si)
+// One wave per utterance: 64 states are loaded per instruction (coalesced); the walk itself
+// (run starts, compaction offsets) is inherently serial but runs on scalars extracted with
+// ballot/readlane, ~15 instructions per state instead of three dependent global loads.
+__global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, int si)
 {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x;
     if (b >= bd.B)
         return;
+    const int lane = threadIdx.x;
     const UttDev *up = bd.utt + b;
     const StreamStatesDev st = up->st[si];
-    struct { uint32_t S, T; uint64_t frame_off, state_off; const uint32_t *dur; } u = {
-        up->S, up->T, up->frame_off, up->state_off, up->dur};
-    const uint64_t sb = u.state_off;
-    uint32_t t = 0, k = 0, gl = 0;
-    uint32_t run_start = 0;
+    const uint32_t S = up->S;
+    const uint32_t *dur = up->dur;
+    const uint64_t sb = up->state_off;
+    uint32_t t = 0, k = 0, gl = 0, run_start = 0;
     bool prev_v = false;
-    for (uint32_t s = 0; s < u.S; s++) {
+    // forward: state start frame, compaction offset, start of the voiced run
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + (uint32_t)lane;
+        const bool ok = s < S;
+        const uint32_t d = ok ? dur[s] : 0u;
         // msd.unwrap_or(f64::MAX) > threshold  (model/mod.rs:113, mask.rs:24)
-        const double msd = st.msd ? st.msd[s] : 1.7976931348623157e308;
-        const bool v = msd > st.msd_threshold;
-        const uint32_t d = u.dur[s];
-        if (v && !prev_v)
-            run_start = t;
-        sd.s_start[sb + s] = t;
-        sd.s_vpre[sb + s] = k;
-        sd.s_rstart[sb + s] = run_start;
-        sd.s_voiced[sb + s] = v;
-        if (v) {
-            k += d;
-            if (st.gv_switch && st.gv_switch[s])
-                gl += d;
+        const double msd = (ok && st.msd) ? st.msd[s] : 1.7976931348623157e308;
+        const bool v = ok && msd > st.msd_threshold;
+        const bool g = v && st.gv_switch && st.gv_switch[s];
+        const unsigned long long vm = __ballot(v), gm = __ballot(g);
+        uint32_t my_start = 0, my_vpre = 0, my_rstart = 0;
+        const uint32_t cnt = S - s0 < 64u ? S - s0 : 64u;
+        for (uint32_t u = 0; u < cnt; u++) {
+            const uint32_t du = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)u);
+            const bool vu = (vm >> u) & 1ull;
+            if (vu && !prev_v)
+                run_start = t;
+            if ((uint32_t)lane == u) {
+                my_start = t;
+                my_vpre = k;
+                my_rstart = run_start;
+            }
+            if (vu) {
+                k += du;
+                if ((gm >> u) & 1ull)
+                    gl += du;
+            }
+            if (du > 0)
+                prev_v = vu;
+            t += du;
         }
-        if (d > 0)
-            prev_v = v;
-        t += d;
+        if (ok) {
+            sd.s_start[sb + s] = my_start;
+            sd.s_vpre[sb + s] = my_vpre;
+            sd.s_rstart[sb + s] = my_rstart;
+            sd.s_voiced[sb + s] = v;
+        }
     }
-    // run ends: backward sweep (mask.rs:66-79)
-    uint32_t run_end = 0;
+    // backward: last frame of the voiced run (mask.rs:66-79)
+    uint32_t run_end = 0, tt = t;
     bool next_v = false;
-    uint32_t tt = t;
-    for (uint32_t s = u.S; s-- > 0;) {
-        const uint32_t d = u.dur[s];
-        tt -= d;
-        const bool v = sd.s_voiced[sb + s];
-        if (v && !next_v)
-            run_end = tt + d - 1; // last frame of the voiced run
-        sd.s_rend[sb + s] = run_end;
-        if (d > 0)
-            next_v = v;
+    const uint32_t nch = (S + 63) / 64;
+    for (uint32_t c = nch; c-- > 0;) {
+        const uint32_t s0 = c * 64;
+        const uint32_t s = s0 + (uint32_t)lane;
+        const bool ok = s < S;
+        const uint32_t d = ok ? dur[s] : 0u;
+        const bool v = ok && sd.s_voiced[sb + s];
+        const unsigned long long vm = __ballot(v);
+        uint32_t my_rend = 0;
+        const uint32_t cnt = S - s0 < 64u ? S - s0 : 64u;
+        for (uint32_t u = cnt; u-- > 0;) {
+            const uint32_t du = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)u);
+            tt -= du;
+            const bool vu = (vm >> u) & 1ull;
+            if (vu && !next_v)
+                run_end = tt + du - 1;
+            if ((uint32_t)lane == u)
+                my_rend = run_end;
+            if (du > 0)
+                next_v = vu;
+        }
+        if (ok)
+            sd.s_rend[sb + s] = my_rend;
     }
-    sd.Tv[b] = k;
-    sd.gvlen[b] = gl;
+    if (lane == 0) {
+        sd.Tv[b] = k;
+        sd.gvlen[b] = gl;
+    }
 }
 
 // thread per state: expand to frames
@@ -869,7 +905,7 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
     if (bd.B == 0)
         return hipSuccess;
     {
-        dim3 grid((bd.B + 63) / 64), block(64);
+        dim3 grid(bd.B), block(64);
         hipLaunchKernelGGL(k_prep_states, grid, block, 0, stream, bd, sd, si);
     }
     if (bd.maxS > 0) {
