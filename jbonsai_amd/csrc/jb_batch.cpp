@@ -400,7 +400,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L, nst = (size_t)sumS;
         if ((rc = b->dalloc(&sd.s_start, nst, false)) || (rc = b->dalloc(&sd.s_vpre, nst, false)) ||
             (rc = b->dalloc(&sd.s_rstart, nst, false)) || (rc = b->dalloc(&sd.s_rend, nst, false)) ||
-            (rc = b->dalloc(&sd.s_voiced, nst, false)))
+            (rc = b->dalloc(&sd.s_voiced, nst, false)) || (rc = b->dalloc(&sd.run_list, nst, false)) ||
+            (rc = b->dalloc(&sd.nruns, n, true)))
             return rc;
         if ((rc = b->dalloc(&sd.fstate, nf, false)) || (rc = b->dalloc(&sd.voiced, nf, false)) ||
             (rc = b->dalloc(&sd.fl, nf, false)) || (rc = b->dalloc(&sd.fr, nf, false)) ||
@@ -438,6 +439,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.nblk = vd.fperiod / bs;
     vd.alpha = voice->alpha;
     vd.volume = voice->volume;
+    vd.run_list = b->sd[1].run_list;
+    vd.nruns = b->sd[1].nruns;
     vd.mcp = b->sd[0].out;
     vd.lf0 = b->sd[1].out;
     vd.lpf = b->sd[2].out;

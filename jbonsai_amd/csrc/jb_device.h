@@ -54,6 +54,8 @@ struct StreamDev {
     uint32_t *s_rstart; // [sumS] first frame of the voiced run containing the state
     uint32_t *s_rend;   // [sumS] last frame of that run
     uint8_t *s_voiced;  // [sumS]
+    uint32_t *run_list; // [sumS] first frame of each voiced run, compact per utterance
+    uint32_t *nruns;    // [B]
     // ---- per-frame scratch written by k_prep_frames (concatenated frames) ----
     uint32_t *fstate;   // [sumT] state index of frame
     uint8_t *voiced;    // [sumT]
@@ -83,6 +85,8 @@ struct VocDev {
     double *pinc;         // [sumT]  pitch_inc_per_point
     double *counter_start;// [sumT]  pitch_counter at frame start
     unsigned long long *pmask; // [sumT][nblk] pulse bit per sample of each block
+    const uint32_t *run_list;  // voiced runs of the LF0 stream (k_prep_states)
+    const uint32_t *nruns;
     const double *noise;  // [noise_len] shared Gaussian stream
     uint64_t noise_len;
     double *xin;          // [sumT*fperiod] excitation after the LPF mix and gain (k_excite)
@@ -109,6 +113,7 @@ struct BatchDev {
     uint32_t maxT;
     uint32_t maxS;
 };
+
 
 // launchers (all asynchronous on `stream`)
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, i
     const uint32_t S = up->S;
     const uint32_t *dur = up->dur;
     const uint64_t sb = up->state_off;
-    uint32_t t = 0, k = 0, gl = 0, run_start = 0;
+    uint32_t t = 0, k = 0, gl = 0, run_start = 0, nrun = 0;
     bool prev_v = false;
     // forward: state start frame, compaction offset, start of the voiced run
     for (uint32_t s0 = 0; s0 < S; s0 += 64) {
@@ -58,8 +58,14 @@ __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, i
         for (uint32_t u = 0; u < cnt; u++) {
             const uint32_t du = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)u);
             const bool vu = (vm >> u) & 1ull;
-            if (vu && !prev_v)
+            if (vu && !prev_v) {
                 run_start = t;
+                // compact list of run starts for the pulse scheduler (a zero-length voiced
+                // state may repeat an entry; k_pulse tolerates duplicates)
+                if (lane == 0)
+                    sd.run_list[sb + nrun] = t;
+                nrun++;
+            }
             if ((uint32_t)lane == u) {
                 my_start = t;
                 my_vpre = k;
@@ -111,6 +117,7 @@ __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, i
     if (lane == 0) {
         sd.Tv[b] = k;
         sd.gvlen[b] = gl;
+        sd.nruns[b] = nrun;
     }
 }
 

@@ -87,30 +87,28 @@ __global__ __launch_bounds__(kMc2bFrames) void k_mc2b(BatchDev bd, VocDev vd)
 }
 
 // --------------------------------------------------------------------------
-// V3 pulse scheduler.  Thread per frame; only the first frame of a voiced run
-// walks its run (the counter is the only state carried across frames: at every
+// V3 pulse scheduler.  One lane per voiced run, walking its run (the counter is the only
+// state carried across frames: at every
 // frame start pitch_of_curr_point is reset to the previous frame's pitch by
 // Excitation::end, excitation.rs:102-104).
 __global__ void k_pulse(BatchDev bd, VocDev vd)
 {
+    // one lane per voiced run (compact run list from k_prep_states of the LF0 stream); a
+    // thread per frame would leave ~2 of 64 lanes working
     const int b = blockIdx.y;
     const UttDev u = bd.utt[b];
-    const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= vd.nruns[b])
+        return;
+    const uint32_t t0 = vd.run_list[u.state_off + r];
     if (t0 >= u.T)
         return;
     const uint64_t base = u.frame_off;
-    const double p0 = vd.pitch[base + t0];
     const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
-    if (p0 == 0.0) {
-        vd.cur_start[base + t0] = 0.0;
-        vd.pinc[base + t0] = 0.0;
-        vd.counter_start[base + t0] = 0.0;
-        for (int q = 0; q < nblk; q++)
-            vd.pmask[(base + t0) * nblk + q] = 0ull;
-        return;
-    }
+    if (vd.pitch[base + t0] == 0.0)
+        return; // a zero-length voiced state followed by an unvoiced one
     if (t0 > 0 && vd.pitch[base + t0 - 1] != 0.0)
-        return; // not a run start
+        return; // continuation of the previous list entry (zero-length states in between)
     double prevp = 0.0, counter = 0.0;
     for (uint32_t t = t0; t < u.T; t++) {
         const double p = vd.pitch[base + t];
@@ -800,7 +798,7 @@ hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
-    dim3 grid((bd.maxT + 63) / 64, bd.B), block(64);
+    dim3 grid((bd.maxS + 63) / 64, bd.B), block(64);
     hipLaunchKernelGGL(k_pulse, grid, block, 0, stream, bd, vd);
     return hipGetLastError();
 }
