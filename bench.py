@@ -181,7 +181,7 @@ def main():
             },
             "realtime_factor": value / vi.sampling_frequency,
             "roofline": {
-                "bound": "hbm", "kernel": "k_vocoder_lp" if info["chunk_frames"] and info["n_items"] >= 16384 else "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": "k_vocoder_lt" if info["chunk_frames"] and info["n_items"] >= 16384 else "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": voc_avg_ms, "alg_bytes_per_sample": B_ALG,
                 "note": "recursive IIR: FP64 VALU-issue bound, not HBM bound (DESIGN.md section 4)",

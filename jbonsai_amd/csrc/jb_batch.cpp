@@ -496,7 +496,7 @@ int Batch::build_work(const jb_batch_opts *opts)
     if (serial) {
         ch = 0;
     } else if (ch == 0 && lp_mode) {
-        uint64_t target = 65536; // 1024 SIMDs x 2 waves x 32 lane pairs
+        uint64_t target = 2048ull * (uint64_t)vocoder_ls_chunks_per_wave(); // 1024 SIMDs x 2 waves
         if (const char *e = getenv("JB_LP_TARGET"))
             target = strtoull(e, nullptr, 10);
         uint64_t c = (sumT + target - 1) / target;

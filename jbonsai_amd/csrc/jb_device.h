@@ -126,6 +126,7 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
                           hipStream_t stream);
 // lane-serial throughput kernel (one chunk per lane); order_dev = launch permutation of items
 bool vocoder_ls_supported(int nmcp);
+int vocoder_ls_chunks_per_wave(); // 20 (lane triples) or 32 (lane pairs)
 hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
                              const uint32_t *order_dev, uint32_t n_items, hipStream_t stream);
 // compares save_warm of item i with save_end of item i-1 (same utterance): bad[i]=1 and

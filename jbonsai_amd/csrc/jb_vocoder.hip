@@ -27,6 +27,9 @@
 // (tolerance: see DESIGN.md; measured ~1e-13 relative).
 #include "jb_device.h"
 
+#include <cstdlib>
+#include <cstring>
+
 namespace jb {
 
 // --------------------------------------------------------------------------
@@ -719,6 +722,275 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
 }
 
 // --------------------------------------------------------------------------
+// Lane-triple throughput kernel: ONE CHUNK PER THREE ADJACENT LANES.
+// Same idea as k_vocoder_lp, but the register file is the scarce resource there (204
+// state VGPRs per lane => the compiler spills ~10 values inside the sample loop and each
+// reload is a memory round trip).  Here the five Pade stages are spread over three lanes,
+// {1,2} {3,4} {5,-}: 68 state doubles per lane, nothing spills, and there is room to keep
+// LDS reads in flight.  Five triples per 16-lane DPP row (lane 15 of each row idle), so
+// 20 chunks per wave; the per-sample exchange is one row_shr:1 (stage outputs to the next
+// lane) and two row_shl (Pade partial sums to the first lane of the triple).
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102;
+constexpr int kLtChunks = 20;
+#ifndef JB_LT_PF
+#define JB_LT_PF 4
+#endif
+
+template <int NM, int TPLW>
+__global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
+                                                       const VocWork *__restrict__ work,
+                                                       const uint32_t *__restrict__ order,
+                                                       uint32_t n_items)
+{
+    constexpr int M = NM - 1; // live taps 1..M
+    constexpr int NS = 2;     // stage slots per lane
+    const int lane = threadIdx.x;
+    const int row = lane >> 4, p16 = lane & 15;
+    const bool idle = p16 == 15;
+    // pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 15 behaves like pos 2)
+    const int tri = p16 / 3, pos = idle ? 2 : p16 % 3;
+    const int ci = row * 5 + (idle ? 4 : tri); // chunk slot of this lane within the wave
+    const uint32_t slot = blockIdx.x * (uint32_t)kLtChunks + (uint32_t)ci;
+    const bool has = !idle && slot < n_items;
+    const bool lead = has && pos == 0;
+    const uint32_t item = has ? order[slot] : 0u;
+    struct {
+        uint32_t utt, t_start, t_out, t_end;
+        const double *load_state;
+    } wk = {0, 0, 0, 0, nullptr};
+    if (has) {
+        const VocWork &w0 = work[item];
+        wk.utt = w0.utt;
+        wk.t_start = w0.t_start;
+        wk.t_out = w0.t_out;
+        wk.t_end = w0.t_end;
+        wk.load_state = w0.load_state;
+    }
+    const uint32_t T = has ? bd.utt[wk.utt].T : 0;
+    if (wk.t_end > T)
+        wk.t_end = T;
+    const uint32_t nfr = wk.t_end > wk.t_start ? wk.t_end - wk.t_start : 0;
+    uint32_t maxfr = nfr;
+    for (int o = 32; o > 0; o >>= 1)
+        maxfr = max(maxfr, (uint32_t)__shfl_xor((int)maxfr, o));
+    if (maxfr == 0)
+        return;
+    const uint64_t base = has ? bd.utt[wk.utt].frame_off : 0;
+    const int fp = vd.fperiod;
+    const double a = vd.alpha, na = -a, iaa = 1.0 - a * a, vol = vd.volume;
+    const int s0 = 2 * pos; // first stage of this lane
+    // Pade weights of the two slots: stage s -> PPADE[s+1]; slot 0 (odd i) enters the
+    // alternating sum with +, slot 1 (even i) with -; the inert slot has weight 0
+    const double w0 = kPPade[s0 + 1];
+    const double w1 = (s0 + 1 < kPade) ? kPPade[s0 + 2] : 0.0;
+
+    __shared__ double2 cc[NM - 1][kLtChunks]; // row k-1: (c_k at frame start, per-sample increment)
+    __shared__ double gqs[kLtChunks];         // per-sample gain ratio exp(cinc0) of the current frame
+
+    double d[NS][M + 1];
+    double u[NS]; // slot inputs (d22[stage])
+    double gain = 1.0;
+    double e11[6], e12[6]; // df1 state (every lane of the triple keeps an identical copy)
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+        e11[i] = e12[i] = 0.0;
+#pragma unroll
+    for (int q = 0; q < NS; q++) {
+        u[q] = 0.0;
+#pragma unroll
+        for (int j = 0; j <= M; j++)
+            d[q][j] = 0.0;
+    }
+
+    // k_vocoder state layout: tap j of stage s at [64*k + 12*s + g], j-1 = g*TPLW + k
+    if (wk.load_state) {
+        const double *sp = wk.load_state;
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+            const int st = s0 + q;
+            if (st < kPade) {
+                u[q] = sp[64 * TPLW + kGroups * st];
+#pragma unroll
+                for (int j = 1; j <= M; j++)
+                    d[q][j] = sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            e11[i] = sp[64 * TPLW + 64 + i];
+            e12[i] = sp[64 * TPLW + 70 + i];
+        }
+    }
+    auto save_state = [&](double *sp) {
+#pragma unroll
+        for (int q = 0; q < NS; q++) {
+            const int st = s0 + q;
+            if (st < kPade) {
+                sp[64 * TPLW + kGroups * st] = u[q];
+#pragma unroll
+                for (int j = 1; j <= M; j++)
+                    sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW] = d[q][j];
+            }
+        }
+        if (pos == 0) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                sp[64 * TPLW + 64 + i] = e11[i];
+                sp[64 * TPLW + 70 + i] = e12[i];
+            }
+        }
+    };
+
+    for (uint32_t tl = 0; tl < maxfr; tl++) {
+        const bool act = tl < nfr;
+        const uint32_t t = wk.t_start + (act ? tl : 0);
+        const uint64_t f = base + t;
+        const bool emit = act && lead && t >= wk.t_out;
+        if (act && t == wk.t_out && wk.t_out > wk.t_start) {
+            double *sw_ = work[item].save_warm;
+            if (sw_)
+                save_state(sw_);
+        }
+        // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
+        // the three lanes of a triple fill every third tap
+        __syncthreads();
+        if (has) {
+            const double *bcur = vd.bcoef + f * (uint64_t)NM;
+            const double *bprev = (t > 0) ? bcur - NM : bcur;
+            for (int k = 1 + pos; k < NM; k += 3) {
+                const double c0v = bprev[k], c1v = bcur[k];
+                cc[k - 1][ci] = make_double2(c0v, (c1v - c0v) / (double)fp);
+            }
+            // V5 gain exp(c[0]) (mod.rs:129-131): exp once per frame, gain *= exp(cinc0) per sample
+            gain = exp(bprev[0]);
+            if (pos == 0)
+                gqs[ci] = exp((bcur[0] - bprev[0]) / (double)fp);
+        }
+        __syncthreads();
+        const double *xp = vd.xin + (base + t) * (uint64_t)fp;
+        double *op = vd.pcm + (base + t) * (uint64_t)fp;
+        double xn = act ? xp[0] : 0.0;
+        const double gq = gqs[ci];
+        // PCM leaves the lead lane 32 bytes at a time (8-byte stores cost a sector each)
+        double o0 = 0.0, o1 = 0.0, o2 = 0.0;
+        const bool quad = (fp & 3) == 0;
+        for (int i = 0; i < fp; i++) {
+            double x = xn * gain;
+            gain *= gq;
+            if (i + 1 < fp)
+                xn = act ? xp[i + 1] : 0.0;
+            const double fi = (double)i;
+            // ---- V6 df1 (mlsa.rs:54-66): every lane runs it, the lead lane's copy is kept ----
+            {
+                const double2 c1p = cc[0][ci];
+                const double c1 = fma(fi, c1p.y, c1p.x);
+                double out = 0.0;
+#pragma unroll
+                for (int ii = 5; ii >= 1; ii--) {
+                    e11[ii] = fma(iaa, e12[ii - 1], a * e11[ii]);
+                    e12[ii] = e11[ii] * c1;
+                    const double v = e12[ii] * kPPade[ii];
+                    x += (ii & 1) ? v : -v;
+                    out += v;
+                }
+                e12[0] = x;
+                x += out;
+            }
+            // ---- V7 df2: fir() of this lane's stage slots, taps outermost (mlsa.rs:127-163) ----
+            double r[NS], y[NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                r[q] = u[q];
+                y[q] = 0.0;
+            }
+            // Coefficient reads run JB_LT_PF taps ahead of their use in rotating registers so that
+            // their LDS latency overlaps the arithmetic in between.  hipcc sinks ordinary LDS loads
+            // next to their use, so they are issued with inline asm and counted s_waitcnt
+            // lgkmcnt(N); each wait is tied to its data register ("+v"), which keeps consumers
+            // behind it.  LDS returns in order, so the compiler's own waits stay correct.
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            v2d cq[JB_LT_PF];
+            const uint32_t cca = (uint32_t)(uintptr_t)&cc[0][ci];
+#define JB_LDS_RD(dst, tapj)                                                                     \
+    asm volatile("ds_read_b128 %0, %1 offset:%2"                                                 \
+                 : "=v"(dst)                                                                     \
+                 : "v"(cca), "n"(((tapj)-1) * (int)(sizeof(double2) * kLtChunks)))
+#pragma unroll
+            for (int k = 0; k < JB_LT_PF; k++)
+                JB_LDS_RD(cq[k], 2 + k); // taps 2 .. 1+PF
+#pragma unroll
+            for (int j = 1; j <= M; j++) {
+                double cj = 0.0;
+                if (j >= 2) {
+                    const int slotq = (j - 2) % JB_LT_PF;
+                    const int inflight = (M - j) < (JB_LT_PF - 1) ? (M - j) : (JB_LT_PF - 1);
+                    switch (inflight) { // younger reads that may still be in flight
+                    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[slotq])); break;
+                    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cq[slotq])); break;
+                    case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cq[slotq])); break;
+                    case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(cq[slotq])); break;
+                    case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cq[slotq])); break;
+                    case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(cq[slotq])); break;
+                    case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cq[slotq])); break;
+                    default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(cq[slotq])); break;
+                    }
+                    cj = fma(fi, cq[slotq].y, cq[slotq].x);
+                    if (j + JB_LT_PF <= M)
+                        JB_LDS_RD(cq[slotq], j + JB_LT_PF);
+                }
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    // all-pass section: rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem'
+                    // Written as three-address v_fma_f64: hipcc otherwise selects the destructive
+                    // v_fmac_f64 for both and then needs a v_mov_b64 per tap to undo the register
+                    // rotation of the loop-carried d[] (69 moves per sample, ~19 % of the VALU work).
+                    double rn, dn;
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rn) : "s"(na), "v"(r[q]), "v"(d[q][j]));
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dn) : "s"(a), "v"(rn), "v"(r[q]));
+                    d[q][j] = dn;
+                    r[q] = rn;
+                    if (j >= 2)
+                        y[q] = fma(cj, dn, y[q]);
+                }
+            }
+#undef JB_LDS_RD
+            // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, gathered on the lead lane ----
+            const double v0 = w0 * y[0], v1 = w1 * y[1];
+            const double sb = v0 + v1, sa = v0 - v1;
+            const double ssum = (sa + dpp_f64<DPP_ROW_SHL1>(sa)) + dpp_f64<DPP_ROW_SHL2>(sa);
+            const double psum = (sb + dpp_f64<DPP_ROW_SHL1>(sb)) + dpp_f64<DPP_ROW_SHL2>(sb);
+            const double yprev = dpp_f64<DPP_ROW_SHR1>(y[1]); // previous lane's second stage
+            const double xmid = x + ssum; // d22[0] (valid on the lead lane)
+            x = xmid + psum;
+            // next-sample slot inputs: stage s+1 <- y of stage s; stage 0 <- xmid
+            u[1] = y[0];
+            u[0] = pos == 0 ? xmid : yprev;
+            const double pv = x * vol;
+            if (quad) {
+                const int ph = i & 3;
+                if (ph == 0)
+                    o0 = pv;
+                else if (ph == 1)
+                    o1 = pv;
+                else if (ph == 2)
+                    o2 = pv;
+                else if (emit) {
+                    *reinterpret_cast<double2 *>(op + (i - 3)) = make_double2(o0, o1);
+                    *reinterpret_cast<double2 *>(op + (i - 1)) = make_double2(o2, pv);
+                }
+            } else if (emit) {
+                op[i] = pv;
+            }
+        }
+        if (act && tl + 1 == nfr) {
+            double *se_ = work[item].save_end;
+            if (se_)
+                save_state(se_);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
 // Certification of time-chunked execution: a chunk that started from zero state
 // W frames early must have reached the same filter state as its predecessor's end
 // state.  One wave per item; the excitation ring is feed-forward and not compared.
@@ -815,21 +1087,41 @@ hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int stat
 
 bool vocoder_ls_supported(int nmcp) { return nmcp == 35 || nmcp == 25; }
 
+int vocoder_ls_chunks_per_wave()
+{
+    static const bool pair = getenv("JB_LP_KERNEL") && !strcmp(getenv("JB_LP_KERNEL"), "pair");
+    return pair ? 32 : kLtChunks;
+}
+
 hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
                              const uint32_t *order_dev, uint32_t n_items, hipStream_t stream)
 {
     if (n_items == 0)
         return hipSuccess;
-    dim3 grid((n_items + 31) / 32), block(64);
-    switch (vd.nmcp) {
-    case 35:
-        hipLaunchKernelGGL((k_vocoder_lp<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-        break;
-    case 25:
-        hipLaunchKernelGGL((k_vocoder_lp<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-        break;
-    default:
-        return hipErrorInvalidValue;
+    const int cpw = vocoder_ls_chunks_per_wave();
+    dim3 grid((n_items + cpw - 1) / cpw), block(64);
+    if (cpw == 32) {
+        switch (vd.nmcp) {
+        case 35:
+            hipLaunchKernelGGL((k_vocoder_lp<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+            break;
+        case 25:
+            hipLaunchKernelGGL((k_vocoder_lp<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+            break;
+        default:
+            return hipErrorInvalidValue;
+        }
+    } else {
+        switch (vd.nmcp) {
+        case 35:
+            hipLaunchKernelGGL((k_vocoder_lt<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+            break;
+        case 25:
+            hipLaunchKernelGGL((k_vocoder_lt<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+            break;
+        default:
+            return hipErrorInvalidValue;
+        }
     }
     return hipGetLastError();
 }
