@@ -107,6 +107,10 @@ typedef struct jb_batch_opts {
 #define JB_BATCH_SERIAL 4u       /* one wave per utterance, no time-chunking (reference-shaped recursion) */
 #define JB_BATCH_WAVE_KERNEL 8u  /* always the wave-per-chunk vocoder kernel (A/B tests) */
 #define JB_BATCH_PAIR_KERNEL 16u /* always the lane-pair throughput kernel (A/B tests) */
+#define JB_BATCH_SERIAL_GV 32u   /* GV sums in the reference's serial order: parameter tracks bit-exact
+                                    against src/mlpg_adjust/mlpg.rs:145-292, slower.  The default runs the
+                                    GV sweeps time-parallel with fixed-shape tree reductions (deterministic;
+                                    tracks agree to ~1e-14 relative) */
 
 /* Time-chunked vocoder (default).  The MLSA recursion is time-serial per utterance
  * (src/vocoder/mlsa.rs), but it forgets its initial state within ~16 frames (measured:

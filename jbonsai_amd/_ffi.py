@@ -26,6 +26,7 @@ BATCH_GENERIC_MLPG = 2
 BATCH_SERIAL = 4
 BATCH_WAVE_KERNEL = 8
 BATCH_PAIR_KERNEL = 16
+BATCH_SERIAL_GV = 32
 
 
 class JbError(RuntimeError):

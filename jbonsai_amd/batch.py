@@ -98,7 +98,7 @@ class Batch:
     def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
                  keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
-                 kernel: str = "auto"):
+                 kernel: str = "auto", serial_gv: bool = False):
         L = F.lib()
         self._L = L
         self.voice = voice
@@ -110,7 +110,7 @@ class Batch:
         opts = F.BatchOpts()
         opts.device = device
         opts.flags = ((F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
-                      | (F.BATCH_SERIAL if serial else 0)
+                      | (F.BATCH_SERIAL if serial else 0) | (F.BATCH_SERIAL_GV if serial_gv else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "pair": F.BATCH_PAIR_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
         h = C.c_void_p()

@@ -124,9 +124,11 @@ Batch::~Batch()
     for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf})
         if (ev)
             hipEventDestroy(ev);
-    for (hipStream_t st : {stream_lf0, stream_lpf, stream})
-        if (st)
+    for (hipStream_t st : {stream_lf0, stream_lpf})
+        if (st && st != stream)
             hipStreamDestroy(st);
+    if (stream)
+        hipStreamDestroy(stream);
 }
 
 template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
@@ -274,8 +276,12 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
-    if ((e = hipStreamCreateWithFlags(&b->stream_lf0, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&b->stream_lpf, hipStreamNonBlocking)) != hipSuccess)
+    // JB_ONE_STREAM=1 (profiling aid): the three parameter-generation chains run back to back
+    // on the main stream, so that per-kernel durations are free of overlap effects
+    if (getenv("JB_ONE_STREAM") && atoi(getenv("JB_ONE_STREAM")) != 0) {
+        b->stream_lf0 = b->stream_lpf = b->stream;
+    } else if ((e = hipStreamCreateWithFlags(&b->stream_lf0, hipStreamNonBlocking)) != hipSuccess ||
+               (e = hipStreamCreateWithFlags(&b->stream_lpf, hipStreamNonBlocking)) != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
     hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_lf0, hipEventDisableTiming);
@@ -397,6 +403,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         }
         sd.BW = (maxw / 2) * 2 + 1; // Windows::max_width()*2+1 (window.rs:19-21, mlpg.rs:27)
         sd.generic_solver = (b->flags & JB_BATCH_GENERIC_MLPG) ? 1 : 0;
+        sd.serial_gv = (b->flags & JB_BATCH_SERIAL_GV) ? 1 : 0;
+        sd.mt = (sd.BW == 3 && !sd.generic_solver && sd.L > 2 && sd.L <= mlpg_mt_max_dim()) ? 1 : 0;
         const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L, nst = (size_t)sumS;
         if ((rc = b->dalloc(&sd.s_start, nst, false)) || (rc = b->dalloc(&sd.s_vpre, nst, false)) ||
             (rc = b->dalloc(&sd.s_rstart, nst, false)) || (rc = b->dalloc(&sd.s_rend, nst, false)) ||
@@ -416,6 +424,15 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
             if ((rc = b->dalloc(&sd.bvec, nfl, false)) || (rc = b->dalloc(&sd.g, nfl, false)) ||
                 (rc = b->dalloc(&sd.par, nfl, false)))
                 return rc;
+            if (sd.mt && (rc = b->dalloc(&sd.ivar, nst * (size_t)sd.W * (size_t)sd.L, false)))
+                return rc;
+            if (sd.mt && sd.use_gv && !sd.serial_gv) {
+                sd.gv_ntile = (maxT + (uint32_t)mlpg_gv_tile_frames() - 1) / (uint32_t)mlpg_gv_tile_frames();
+                const size_t nbl = n * (size_t)sd.L;
+                if ((rc = b->dalloc(&sd.gv_part, 7 * nbl * (size_t)sd.gv_ntile * 4, false)) ||
+                    (rc = b->dalloc(&sd.gv_scal, 6 * nbl * 4, false)))
+                    return rc;
+            }
         }
         if ((rc = b->dalloc(&sd.out, nfl, false)))
             return rc;

@@ -48,6 +48,17 @@ struct StreamDev {
     int win_off[kMaxWin];
     double win_coef[kMaxCoef];
     int generic_solver;       // 1: force the un-fused reference-shaped solver (A/B tests)
+    // Workspace layout of A/bvec/F/g/par.  mt == 0: [frame][dim] (dim fastest).  mt == 1:
+    // [dim][frame] per utterance (row m of utterance b starts at frame_off*L + m*T, frames
+    // contiguous), which is what the time-parallel GV sweeps and the per-lane streams of the
+    // serial substitutions want.  `out` is always [frame][dim].
+    int mt;
+    int serial_gv;            // 1: GV reductions in the reference's serial order (bit-exact tracks)
+    // time-parallel GV (k_mlpg_gv_tp): per-tile partial sums and per-iteration scalars
+    double *ivar;             // [sumS][W*L] MeanVari::with_ivar of the state variances (k_mlpg_ivar), mt only
+    double *gv_part;          // [7 passes][B][L][gv_ntile][4]
+    double *gv_scal;          // [6][B][L][4] = {mean, step, obj, -}
+    uint32_t gv_ntile;
     // ---- per-state scratch written by k_prep_states (concatenated states) ----
     uint32_t *s_start;  // [sumS] first frame of state
     uint32_t *s_vpre;   // [sumS] voiced frames before state (compaction offset)
@@ -118,6 +129,8 @@ struct BatchDev {
 // launchers (all asynchronous on `stream`)
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
+int mlpg_mt_max_dim();      // largest vector length served by the [dim][frame] fast path
+int mlpg_gv_tile_frames();  // frames per block of the time-parallel GV sweeps
 hipError_t launch_pitch(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream);

@@ -166,27 +166,16 @@ __device__ __forceinline__ double with_ivar(double vari)
 }
 
 // --------------------------------------------------------------------------
-// A3/A4: thread per (compacted frame k, dim m) of utterance blockIdx.y.
+// A3/A4 for one (compacted frame k, dim m): the reference's order of additions.
 template <int BW>
-__global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
+__device__ __forceinline__ void build_elem(const StreamDev &sd, const StreamStatesDev &st, uint64_t base,
+                                           uint32_t Tv, uint32_t k, int m, double (&wuw)[BW], double &wum)
 {
-    const int b = blockIdx.y;
-    const UttDev *up = bd.utt + b;
-    struct { uint64_t frame_off; } u = {up->frame_off};
-    const uint32_t Tv = sd.Tv[b];
     const int L = sd.L, W = sd.W;
-    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (uint64_t)Tv * L)
-        return;
-    const uint32_t k = (uint32_t)(tid / L);
-    const int m = (int)(tid % L);
-    const StreamStatesDev st = up->st[si];
-    const uint64_t base = u.frame_off;
-    double wuw[BW];
 #pragma unroll
     for (int j = 0; j < BW; j++)
         wuw[j] = 0.0;
-    double wum = 0.0;
+    wum = 0.0;
     for (int w = 0; w < W; w++) {
         const int ww = sd.win_width[w];
         const double *coef = sd.win_coef + sd.win_off[w];
@@ -222,11 +211,148 @@ __global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
             }
         }
     }
+}
+
+// A3/A4: thread per (compacted frame k, dim m) of utterance blockIdx.y; [frame][dim] workspace.
+template <int BW>
+__global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    const uint32_t Tv = sd.Tv[b];
+    const int L = sd.L;
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (uint64_t)Tv * L)
+        return;
+    const uint32_t k = (uint32_t)(tid / L);
+    const int m = (int)(tid % L);
+    const StreamStatesDev st = up->st[si];
+    const uint64_t base = up->frame_off;
+    double wuw[BW], wum;
+    build_elem<BW>(sd, st, base, Tv, k, m, wuw, wum);
     const uint64_t o = (base + k) * (uint64_t)L + (uint64_t)m;
 #pragma unroll
     for (int j = 0; j < BW; j++)
         sd.A[j][o] = wuw[j];
     sd.bvec[o] = wum;
+}
+
+// MeanVari::with_ivar per (state, window, dim), once per batch: a frame's inverse variance is
+// its state's, and each is used by up to three neighbouring frames of every window, so the
+// table replaces ~6 f64 divisions per (frame, dim) in the build by loads.
+__global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    const uint32_t WL = (uint32_t)(sd.W * sd.L);
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)up->S * WL)
+        return;
+    sd.ivar[up->state_off * (uint64_t)WL + e] = with_ivar(up->st[si].var[e]);
+}
+
+// A3/A4 for the [dim][frame] workspace: a block computes kBuildTF frames x L dims with the
+// state tables read dim-fastest (coalesced), turns the tile in LDS and writes rows of
+// kBuildTF contiguous frames per dim.  What depends on the frame alone (state index, MSD
+// boundary distances of the frame and its +-1 neighbours) is looked up once per block.
+// Same arithmetic, in the same order, as build_elem.
+constexpr int kBuildTF = 32;
+constexpr int kMtMaxDim = 60; // (BW+1) * L * (kBuildTF+1) * 8 B <= 64 KiB of LDS for BW = 3
+template <int BW>
+__global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd, int si)
+{
+    extern __shared__ double tile[]; // [BW+1][L][kBuildTF+1]
+    constexpr int HW = BW / 2;       // frames a window can reach to either side
+    __shared__ uint32_t f_state[kBuildTF + 2 * HW];
+    __shared__ uint8_t f_l[kBuildTF + 2 * HW], f_r[kBuildTF + 2 * HW];
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    const uint32_t Tv = sd.Tv[b];
+    const uint32_t k0 = blockIdx.x * (uint32_t)kBuildTF;
+    if (k0 >= Tv)
+        return;
+    const int L = sd.L, W = sd.W;
+    const StreamStatesDev st = up->st[si];
+    const uint64_t base = up->frame_off;
+    if (threadIdx.x < kBuildTF + 2 * HW) {
+        const long k = (long)k0 - HW + (long)threadIdx.x;
+        uint32_t s = 0;
+        uint8_t dl = 0, dr = 0;
+        if (k >= 0 && k < (long)Tv) {
+            const uint32_t f = sd.vidx[base + k];
+            s = sd.fstate[base + f];
+            dl = sd.fl[base + f];
+            dr = sd.fr[base + f];
+        }
+        f_state[threadIdx.x] = s;
+        f_l[threadIdx.x] = dl;
+        f_r[threadIdx.x] = dr;
+    }
+    __syncthreads();
+    const double *ivt = sd.ivar + up->state_off * (uint64_t)(W * L);
+    const int pitch = kBuildTF + 1, plane = L * pitch;
+    for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
+        const int kl = e / L, m = e % L;
+        const uint32_t k = k0 + (uint32_t)kl;
+        if (k >= Tv)
+            continue;
+        double wuw[BW], wum = 0.0;
+#pragma unroll
+        for (int j = 0; j < BW; j++)
+            wuw[j] = 0.0;
+        for (int w = 0; w < W; w++) {
+            const int ww = sd.win_width[w];
+            const double *coef = sd.win_coef + sd.win_off[w];
+            const int lw = ww / 2, rw = ww - lw - 1;
+            for (int index = ww - 1; index >= 0; index--) {
+                const double c = coef[index];
+                if (c == 0.0)
+                    continue;
+                const int d = index - ww / 2; // source frame k - d, |d| <= HW
+                const long idx = (long)k - (long)d;
+                if (idx < 0 || idx >= (long)Tv)
+                    continue;
+                const int fi = kl - d + HW;
+                const uint64_t pi = (uint64_t)f_state[fi] * (uint64_t)(W * L) + (uint64_t)(L * w + m);
+                const double mean = st.mean[pi];
+                double ivar = ivt[pi];
+                // dynamic windows touching an MSD boundary get ivar = 0 (mod.rs:69-80)
+                if (w != 0 && ((int)f_l[fi] < lw || (int)f_r[fi] < rw))
+                    ivar = 0.0;
+                const double wu = c * ivar;
+                wum += wu * mean;
+                for (int inner = ww - 1; inner >= index; inner--) {
+                    const double c2 = coef[inner];
+                    if (c2 == 0.0)
+                        continue;
+                    const int j = inner - index;
+                    if ((uint64_t)k + (uint64_t)j >= Tv)
+                        break;
+#pragma unroll
+                    for (int jj = 0; jj < BW; jj++)
+                        if (jj == j)
+                            wuw[jj] += wu * c2;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BW; j++)
+            tile[j * plane + m * pitch + kl] = wuw[j];
+        tile[BW * plane + m * pitch + kl] = wum;
+    }
+    __syncthreads();
+    const uint64_t row0 = base * (uint64_t)L, Tu = up->T;
+    for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
+        const int m = e / kBuildTF, kl = e % kBuildTF;
+        const uint32_t k = k0 + (uint32_t)kl;
+        if (k < Tv) {
+            const uint64_t o = row0 + (uint64_t)m * Tu + k;
+#pragma unroll
+            for (int j = 0; j < BW; j++)
+                sd.A[j][o] = tile[j * plane + m * pitch + kl];
+            sd.bvec[o] = tile[BW * plane + m * pitch + kl];
+        }
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -474,8 +600,10 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
     const uint32_t T = u.T;
     const uint32_t n = sd.Tv[b];
     const uint64_t base = u.frame_off;
-    const uint64_t o0 = base * (uint64_t)L + (uint64_t)m;
-    const uint64_t Ls = (uint64_t)L;
+    // element k of this lane's dim: [frame][dim] rows (stride L) or its own [dim][frame] row
+    const uint64_t o0 = base * (uint64_t)L + (sd.mt ? (uint64_t)m * (uint64_t)T : (uint64_t)m);
+    const uint64_t Ls = sd.mt ? 1ull : (uint64_t)L;
+    const bool fuse_out = NONMSD && !sd.mt; // `out` is [frame][dim]: only then is par's slot also out's
 #define IX(k) (o0 + (uint64_t)(k) * Ls)
 #define LD(dst, arr, tb)                                                                         \
     _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++)                                            \
@@ -561,7 +689,7 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
                             p -= f1[uu] * q1;
                         if (t + 2 < n)
                             p -= f2[uu] * q2;
-                        if (NONMSD && !gv_on)
+                        if (fuse_out && !gv_on)
                             Ov[IX(t)] = p; // scatter fused: every frame is voiced
                         else
                             Pv[IX(t)] = p;
@@ -710,7 +838,7 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
                                 else
                                     next_g = 1.0 / h * (1.0 * wgt * (-gg[uu] + bb[uu]));
                                 const double pnew = p + step * next_g;
-                                if (NONMSD && it == 5)
+                                if (fuse_out && it == 5)
                                     Ov[IX(t)] = pnew; // scatter fused into the last sweep
                                 else
                                     Pv[IX(t)] = pnew;
@@ -884,6 +1012,278 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
 #undef IX
 }
 
+// --------------------------------------------------------------------------
+// A8 GV ascent, TIME-PARALLEL (mlpg.rs:145-292) for the [dim][frame] workspace.
+// conv_gv and each of the five parmgen iterations are elementwise in t apart from three
+// reductions per (utterance, dim): sum and centred sum of squares of the switched-on
+// frames, and the HMM objective.  Each launch applies one transform (rescale, or one
+// ascent step) to a tile of kGvTT frames (+2 halo frames recomputed on each side), writes
+// the tile to the other ping-pong buffer, evaluates the band product W'U^-1W * par_new on
+// the tile and leaves its three partial sums in gv_part; the next launch adds the partials
+// of all tiles in tile order.  The shape of every sum is fixed by (T, kGvTT) alone, so the
+// result is deterministic, but it is NOT the reference's serial order: tracks agree with
+// the serial-order kernel to ~1e-14 relative instead of bitwise (JB_BATCH_SERIAL_GV keeps
+// the bit-exact path).  The variance uses sums shifted by the previous iteration's mean
+// (the ascent moves the mean by ~1e-3 of a standard deviation), which loses nothing
+// against the reference's two-pass form.
+// One pass over par, A0..A2, bvec per iteration instead of the serial kernel's two sweeps
+// at one lane per dim: ~70 GB of traffic over >100k blocks instead of 13 x 25k dependent
+// steps on 256 waves.
+constexpr int kGvTT = 1024;                      // frames per tile
+constexpr int kGvNT = 256;                       // threads per block
+constexpr int kGvKX = (kGvTT + 4 + kGvNT - 1) / kGvNT; // per-thread frames incl. halo
+
+struct GvScal {
+    double mean, vari, step, obj;
+};
+
+// MODE 0: statistics of par (shift K = par[0]);  MODE 1: conv_gv rescale;  MODE 2: ascent
+// iteration `it` (1..5).  pass_in/pass_out index gv_part; stats == 0 skips the output sums.
+template <int MODE>
+__global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd, int si, int it,
+                                                       const double *__restrict__ src,
+                                                       double *__restrict__ dst, int stats)
+{
+    const int tile = blockIdx.x, m = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const UttDev *up = bd.utt + b;
+    const StreamStatesDev st = up->st[si];
+    const uint32_t n = sd.Tv[b], gvl = sd.gvlen[b];
+    if (n == 0 || !(st.gv_mean && gvl > 0))
+        return;
+    const int t0 = tile * kGvTT;
+    if ((uint32_t)t0 >= n)
+        return;
+    const int L = sd.L, B = bd.B;
+    const uint32_t NT = sd.gv_ntile;
+    const uint64_t row = up->frame_off * (uint64_t)L + (uint64_t)m * (uint64_t)up->T;
+    const uint8_t *sw = sd.vsw + up->frame_off;
+    const double *A0 = sd.A[0] + row, *A1 = sd.A[1] + row, *A2 = sd.A[2] + row, *Bv = sd.bvec + row;
+    const double *P = src + row;
+    double *Q = dst ? dst + row : nullptr;
+    const double gv_mean = st.gv_mean[m] * st.gv_weight; // mlpg.rs:135-137
+    const double gv_vari = st.gv_var[m];
+    const double glen = (double)gvl;
+    const uint32_t ntile_b = (n + kGvTT - 1) / kGvTT;
+    const uint64_t bl = (uint64_t)b * L + m;
+    auto part = [&](int pass) { return sd.gv_part + (((uint64_t)pass * B * L + bl) * NT) * 4; };
+    auto scal = [&](int k) { return sd.gv_scal + ((uint64_t)k * B * L + bl) * 4; };
+
+    // ---- scalars of this launch from the previous launch's partial sums (tile order) ----
+    double K = 0.0, mean = 0.0, vari = 0.0, ratio = 1.0, step = 0.0;
+    if (MODE == 0) {
+        K = P[0];
+    } else {
+        const double *pp = part(MODE == 1 ? 0 : it);
+        double S1 = 0.0, S2 = 0.0, H = 0.0;
+        for (uint32_t j = 0; j < ntile_b; j++) {
+            S1 += pp[4 * j + 0];
+            S2 += pp[4 * j + 1];
+            H += pp[4 * j + 2];
+        }
+        const double Kprev = (MODE == 1) ? P[0] : scal(it - 1)[0];
+        mean = Kprev + S1 / glen;
+        vari = (S2 - S1 * S1 / glen) / glen;
+        K = mean; // shift of this launch's output statistics
+        if (MODE == 1) {
+            ratio = sqrt(gv_mean / vari);
+            if (tile == 0 && tid == 0) {
+                double *sc = scal(0);
+                sc[0] = mean;
+                sc[1] = 0.1; // STEPINIT
+                sc[2] = 0.0;
+            }
+        } else {
+            const double gvobj = -0.5 * 1.0 * vari * gv_vari * (vari - 2.0 * gv_mean);
+            const double obj = -(H + gvobj);
+            step = 0.1;
+            if (it > 1) {
+                const double prev = scal(it - 1)[2];
+                step = scal(it - 1)[1];
+                if (obj > prev)
+                    step *= 0.5; // STEPDEC
+                else if (obj < prev)
+                    step *= 1.2; // STEPINC
+            }
+            if (tile == 0 && tid == 0) {
+                double *sc = scal(it);
+                sc[0] = mean;
+                sc[1] = step;
+                sc[2] = obj;
+            }
+        }
+    }
+    const double wgt = 1.0 / (double)((uint64_t)sd.W * (uint64_t)n);
+
+    double s1 = 0.0, s2 = 0.0, hh = 0.0;
+    if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < kGvTT / kGvNT; k++) {
+            const uint32_t t = (uint32_t)t0 + (uint32_t)(tid + kGvNT * k);
+            if (t < n && sw[t]) {
+                const double dlt = P[t] - K;
+                s1 += dlt;
+                s2 += dlt * dlt;
+            }
+        }
+    } else {
+        // LDS windows: po = par_old[t0-4 .. t0+TT+4), pn = par_new[t0-2 .. t0+TT+2),
+        // a1s/a2s = A1/A2[t0-4 .. t0+TT+2)
+        __shared__ double po[kGvTT + 8], pn[kGvTT + 4], a1s[kGvTT + 6], a2s[kGvTT + 6];
+        for (int i = tid; i < kGvTT + 8; i += kGvNT) {
+            const int t = t0 - 4 + i;
+            const bool ok = t >= 0 && (uint32_t)t < n;
+            po[i] = ok ? P[t] : 0.0;
+            if (i < kGvTT + 6) {
+                a1s[i] = ok ? A1[t] : 0.0;
+                a2s[i] = ok ? A2[t] : 0.0;
+            }
+        }
+        __syncthreads();
+        const double length = (double)n;
+        const double ll = (double)((uint64_t)n * (uint64_t)n);
+        const double lm1 = (double)(n - 1);
+        const double dv = -2.0 * gv_vari * (vari - gv_mean) / length;
+        double a0r[kGvKX], br[kGvKX];
+        bool onr[kGvKX];
+        // ---- transform: par_new on the tile and two halo frames each side ----
+#pragma unroll
+        for (int k = 0; k < kGvKX; k++) {
+            const int i = tid + kGvNT * k; // index into pn; frame t = t0 - 2 + i
+            const int t = t0 - 2 + i;
+            a0r[k] = br[k] = 0.0;
+            onr[k] = false;
+            if (i < kGvTT + 4 && t >= 0 && (uint32_t)t < n) {
+                const double p = po[i + 2];
+                const bool on = sw[t] != 0;
+                const double a0 = A0[t], bb = Bv[t];
+                a0r[k] = a0;
+                br[k] = bb;
+                onr[k] = on;
+                double pnew;
+                if (MODE == 1) {
+                    pnew = on ? ratio * (p - mean) + mean : p; // conv_gv (mlpg.rs:195-203)
+                } else {
+                    // calc_hmmobj_derivative (mlpg.rs:205-229), the reference's order of additions
+                    double g = a0 * p;
+                    if ((uint32_t)t + 1 < n)
+                        g += a1s[i + 2] * po[i + 3];
+                    if (t >= 1)
+                        g += a1s[i + 1] * po[i + 1];
+                    if ((uint32_t)t + 2 < n)
+                        g += a2s[i + 2] * po[i + 4];
+                    if (t >= 2)
+                        g += a2s[i] * po[i];
+                    // next_step (mlpg.rs:230-258)
+                    const double h = -1.0 * wgt * a0 -
+                                     1.0 * 2.0 / ll *
+                                         (lm1 * gv_vari * (vari - gv_mean) +
+                                          2.0 * gv_vari * (p - mean) * (p - mean));
+                    double next_g;
+                    if (on)
+                        next_g = 1.0 / h * (1.0 * wgt * (-g + bb) + 1.0 * dv * (p - mean));
+                    else
+                        next_g = 1.0 / h * (1.0 * wgt * (-g + bb));
+                    pnew = p + step * next_g;
+                }
+                pn[i] = pnew;
+            }
+        }
+        __syncthreads();
+        // ---- store the tile; statistics of par_new for the next launch ----
+#pragma unroll
+        for (int k = 0; k < kGvKX; k++) {
+            const int i = tid + kGvNT * k;
+            const int t = t0 - 2 + i;
+            if (i >= 2 && i < kGvTT + 2 && (uint32_t)t < n) {
+                const double p0 = pn[i];
+                Q[t] = p0;
+                if (stats) {
+                    if (onr[k]) {
+                        const double dlt = p0 - K;
+                        s1 += dlt;
+                        s2 += dlt * dlt;
+                    }
+                    double g = a0r[k] * p0;
+                    if ((uint32_t)t + 1 < n)
+                        g += a1s[i + 2] * pn[i + 1];
+                    if (t >= 1)
+                        g += a1s[i + 1] * pn[i - 1];
+                    if ((uint32_t)t + 2 < n)
+                        g += a2s[i + 2] * pn[i + 2];
+                    if (t >= 2)
+                        g += a2s[i] * pn[i - 2];
+                    hh += 1.0 * wgt * p0 * (br[k] - 0.5 * g);
+                }
+            }
+        }
+    }
+    if (!stats)
+        return;
+    // ---- block sums: xor butterfly inside each wave, then the four waves in order ----
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+        hh += __shfl_xor(hh, o);
+    }
+    __shared__ double red[kGvNT / 64][3];
+    if ((tid & 63) == 0) {
+        red[tid >> 6][0] = s1;
+        red[tid >> 6][1] = s2;
+        red[tid >> 6][2] = hh;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double r0 = red[0][0], r1 = red[0][1], r2 = red[0][2];
+#pragma unroll
+        for (int w = 1; w < kGvNT / 64; w++) {
+            r0 += red[w][0];
+            r1 += red[w][1];
+            r2 += red[w][2];
+        }
+        double *po_ = part(MODE == 0 ? 0 : (MODE == 1 ? 1 : it + 1)) + 4 * (uint64_t)tile;
+        po_[0] = r0;
+        po_[1] = r1;
+        po_[2] = r2;
+    }
+}
+
+// A9 for the [dim][frame] workspace: `out` is [frame][dim], so this is a tiled transpose
+// (plus the MSD compaction and NODATA fill of mask.rs:34-49).  Block = 64 frames x L dims.
+__global__ __launch_bounds__(256) void k_mlpg_scatter_mt(BatchDev bd, StreamDev sd)
+{
+    extern __shared__ double tile[]; // [L][65]
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    const uint32_t T = up->T;
+    const uint32_t t0 = blockIdx.x * 64u;
+    if (t0 >= T)
+        return;
+    const uint64_t base = up->frame_off, sb = up->state_off;
+    const int L = sd.L;
+    const uint64_t row0 = base * (uint64_t)L;
+    for (int e = threadIdx.x; e < 64 * L; e += blockDim.x) {
+        const int m = e >> 6, tl = e & 63;
+        const uint32_t t = t0 + (uint32_t)tl;
+        double v = kNoData;
+        if (t < T && sd.voiced[base + t]) {
+            uint32_t k = t;
+            if (sd.is_msd) {
+                const uint32_t s_ = sd.fstate[base + t];
+                k = sd.s_vpre[sb + s_] + (t - sd.s_start[sb + s_]);
+            }
+            v = sd.par[row0 + (uint64_t)m * T + k];
+        }
+        tile[m * 65 + tl] = v;
+    }
+    __syncthreads();
+    const uint32_t nt = T - t0 < 64u ? T - t0 : 64u;
+    for (int e = threadIdx.x; e < (int)nt * L; e += blockDim.x) {
+        const int tl = e / L, m = e % L;
+        sd.out[(base + t0 + (uint32_t)tl) * (uint64_t)L + (uint64_t)m] = tile[m * 65 + tl];
+    }
+}
+
 // A9 Mask::fill with NODATA (mask.rs:34-49, mod.rs:89-91) for MSD streams:
 // thread per (frame, dim); compacted index = s_vpre[state] + offset within state.
 __global__ void k_mlpg_scatter(BatchDev bd, StreamDev sd)
@@ -928,6 +1328,48 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
     const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
     if (work == 0 || bd.B == 0)
         return hipSuccess;
+    if (BW == 3 && sd.mt) {
+        // [dim][frame] workspace: build, lane-per-dim factor/substitution sweeps, GV, transpose
+        {
+            const uint64_t ne = (uint64_t)bd.maxS * (uint64_t)(sd.W * sd.L);
+            dim3 grid((unsigned)((ne + 255) / 256), bd.B), block(256);
+            hipLaunchKernelGGL(k_mlpg_ivar, grid, block, 0, stream, bd, sd, si);
+        }
+        {
+            dim3 grid((bd.maxT + kBuildTF - 1) / kBuildTF, bd.B), block(256);
+            const size_t lds = sizeof(double) * (size_t)(BW + 1) * sd.L * (kBuildTF + 1);
+            hipLaunchKernelGGL(k_mlpg_build_mt<BW>, grid, block, lds, stream, bd, sd, si);
+        }
+        dim3 grid((sd.L + 63) / 64, bd.B), block(64);
+        const bool tp = sd.use_gv && !sd.serial_gv && sd.gv_part;
+        if (sd.is_msd) {
+            if (tp)
+                hipLaunchKernelGGL((k_mlpg_solve3<false, false>), grid, block, 0, stream, bd, sd, si);
+            else
+                hipLaunchKernelGGL((k_mlpg_solve3<false, true>), grid, block, 0, stream, bd, sd, si);
+        } else {
+            if (tp)
+                hipLaunchKernelGGL((k_mlpg_solve3<true, false>), grid, block, 0, stream, bd, sd, si);
+            else
+                hipLaunchKernelGGL((k_mlpg_solve3<true, true>), grid, block, 0, stream, bd, sd, si);
+        }
+        if (tp) {
+            // par -> g -> par -> ... : conv_gv + five iterations = six writes, result back in par
+            dim3 gg(sd.gv_ntile, sd.L, bd.B), gb(kGvNT);
+            hipLaunchKernelGGL(k_mlpg_gv_tp<0>, gg, gb, 0, stream, bd, sd, si, 0, sd.par, (double *)nullptr, 1);
+            hipLaunchKernelGGL(k_mlpg_gv_tp<1>, gg, gb, 0, stream, bd, sd, si, 0, sd.par, sd.g, 1);
+            for (int it = 1; it <= 5; it++) { // GV_MAX_ITERATION
+                const double *src = (it & 1) ? sd.g : sd.par;
+                double *dst = (it & 1) ? sd.par : sd.g;
+                hipLaunchKernelGGL(k_mlpg_gv_tp<2>, gg, gb, 0, stream, bd, sd, si, it, src, dst, it < 5 ? 1 : 0);
+            }
+        }
+        {
+            dim3 g2((bd.maxT + 63) / 64, bd.B), b2(256);
+            hipLaunchKernelGGL(k_mlpg_scatter_mt, g2, b2, sizeof(double) * (size_t)sd.L * 65, stream, bd, sd);
+        }
+        return hipGetLastError();
+    }
     {
         dim3 grid((unsigned)((work + 255) / 256), bd.B), block(256);
         hipLaunchKernelGGL(k_mlpg_build<BW>, grid, block, 0, stream, bd, sd, si);
@@ -960,6 +1402,9 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
     }
     return hipGetLastError();
 }
+
+int mlpg_mt_max_dim() { return kMtMaxDim; }
+int mlpg_gv_tile_frames() { return kGvTT; }
 
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
 {

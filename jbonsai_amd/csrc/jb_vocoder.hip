@@ -227,6 +227,140 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     vd.xin[base * (uint64_t)fp + n] = x;
 }
 
+// Same excitation, ONE WAVE PER FRAME with FOUR CONSECUTIVE SAMPLES PER LANE (fperiod % 4 == 0,
+// fperiod <= 256, nlpf <= 33).  k_excite above reads e[] and two tap sets from LDS for every
+// (sample, tap): ~93 LDS reads per sample, which made it LDS-bound (21 ms at config 2).  Here a
+// lane keeps the 34-sample window e[4j-30 .. 4j+3] of its four outputs in registers (8.5 LDS
+// reads per sample; the LDS image is stored [sample mod 4][sample div 4] so that the window
+// reads of adjacent lanes are adjacent words) and the taps of the frame are wave-uniform.
+// The reference adds the terms of a sample in tap order k = 0..nlpf-1, and the source sample
+// n-k lies in this frame for k <= i and in the previous one (previous frame's taps) after
+// that.  Two passes in tap order reproduce that order bit for bit: the first over the frame's
+// own e (previous-frame entries read as zero: x + 0*c == x), the second over the previous
+// frame's e with its taps, executed only by the lanes that own the first 32 samples and only
+// when that frame was voiced.
+constexpr int kExw = 4;           // samples per lane
+constexpr int kExwHalo = 32;      // staged history, multiple of kExw, >= nlpf-1
+constexpr int kExwQ = (256 + kExwHalo) / kExw; // LDS row pitch (q = (m + halo) / 4)
+
+// NLPF is a template parameter: with a run-time tap count every tap becomes its own scalar
+// load + branch and the wave pays one scalar-cache latency per tap (measured 14 ms); known at
+// compile time, the taps arrive in a few wide scalar loads.
+template <int NLPF>
+__global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
+{
+    static_assert(NLPF - 1 <= kExwHalo - 2, "history window too short");
+    constexpr int kExwWin = NLPF - 1 + kExw; // window e[4j-(NLPF-1) .. 4j+3]
+    const int b = blockIdx.y;
+    const UttDev *u = bd.utt + b;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)wv));
+    // wave-private LDS images: no block barrier is needed (and a wave past the end of the
+    // utterance may leave early), only wave-level ordering of the LDS writes and reads
+    if (fr >= u->T)
+        return;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+    constexpr int nlpf = NLPF;
+    const int anti = (nlpf - 1) / 2;
+    const uint64_t base = u->frame_off;
+    const uint64_t f = base + fr;
+    const uint64_t n0 = (uint64_t)fr * (uint64_t)fp; // first sample of the frame in the utterance
+    __shared__ double ec_s[4][kExw][kExwQ]; // this frame's e, zero in the history part
+    __shared__ double ep_s[4][kExw][kExwHalo / kExw]; // previous frame's last 32 e
+    __shared__ double nz_s[4][kExw][kExwQ]; // noise[n0 - 32 ..]
+    double(*ec)[kExwQ] = ec_s[wv];
+    double(*ep)[kExwHalo / kExw] = ep_s[wv];
+    double(*nz)[kExwQ] = nz_s[wv];
+    const bool vcur = vd.pitch[f] != 0.0;
+    const bool vprev = fr > 0 && vd.pitch[f - 1] != 0.0;
+    // ---- stage noise and e for samples m = -32 .. fp-1 of this frame ----
+    for (int idx = lane; idx < fp + kExwHalo; idx += 64) {
+        const int m = idx - kExwHalo;
+        const int row = idx & (kExw - 1), q = idx >> 2;
+        const long g = (long)n0 + m; // sample index in the utterance
+        double nv = 0.0, ev = 0.0;
+        if (g >= 0) {
+            nv = vd.noise[g];
+            const bool cur = m >= 0;
+            if (cur ? vcur : vprev) {
+                const uint64_t ff = cur ? f : f - 1;
+                const int i = cur ? m : m + fp;
+                const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
+                double pulse = 0.0;
+                if ((pm >> (i % bs)) & 1ull)
+                    pulse = sqrt(fma((double)i, vd.pinc[ff], vd.cur_start[ff]));
+                ev = pulse - nv;
+            }
+        }
+        nz[row][q] = nv;
+        if (m >= 0)
+            ec[row][q] = ev;
+        else {
+            ec[row][q] = 0.0;
+            ep[row][q] = ev;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int i0 = lane * kExw;
+    if (i0 >= fp)
+        return;
+    double x[kExw];
+#pragma unroll
+    for (int r = 0; r < kExw; r++) {
+        // noise[n - anti], n = n0 + i0 + r  (zero before the utterance starts)
+        const int o = i0 + r - anti + kExwHalo;
+        x[r] = ((long)n0 + i0 + r - anti >= 0) ? nz[o & (kExw - 1)][o >> 2] : 0.0;
+    }
+    const double *tc = vd.lpf + f * (uint64_t)nlpf;
+    if (vcur) {
+        double ck[NLPF];
+#pragma unroll
+        for (int k = 0; k < NLPF; k++)
+            ck[k] = tc[k];
+        double w[kExwWin]; // w[c] = e[i0 - (NLPF-1) + c]
+#pragma unroll
+        for (int c = 0; c < kExwWin; c++) {
+            const int o = c + kExwHalo - (NLPF - 1);
+            w[c] = ec[o & (kExw - 1)][lane + (o >> 2)];
+        }
+#pragma unroll
+        for (int k = 0; k < NLPF; k++) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
+        }
+    }
+    if (vprev && i0 < kExwHalo) {
+        const double *tp = tc - nlpf;
+        double ck[NLPF];
+#pragma unroll
+        for (int k = 1; k < NLPF; k++)
+            ck[k] = tp[k];
+        double w[kExwWin]; // previous frame's e at i0 - (NLPF-1) + c (zero from this frame's start on)
+#pragma unroll
+        for (int c = 0; c < kExwWin; c++) {
+            const int o = c + kExwHalo - (NLPF - 1);
+            const int q = lane + (o >> 2);
+            w[c] = q < kExwHalo / kExw ? ep[o & (kExw - 1)][q] : 0.0;
+        }
+#pragma unroll
+        for (int k = 1; k < NLPF; k++) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
+        }
+    }
+    const uint64_t o = base * (uint64_t)fp + n0 + (uint64_t)i0;
+    *reinterpret_cast<double2 *>(vd.xin + o) = make_double2(x[0], x[1]);
+    *reinterpret_cast<double2 *>(vd.xin + o + 2) = make_double2(x[2], x[3]);
+    if (vd.exc) {
+        *reinterpret_cast<double2 *>(vd.exc + o) = make_double2(x[0], x[1]);
+        *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[2], x[3]);
+    }
+}
+
 // --------------------------------------------------------------------------
 // DPP helpers (f64 moves as two 32-bit DPP movs; invalid source lanes read 0).
 template <int CTRL>
@@ -1060,6 +1194,16 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
+    static const bool generic = getenv("JB_EXCITE_GENERIC") && atoi(getenv("JB_EXCITE_GENERIC")) != 0;
+    if (!generic && vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo &&
+        (vd.nlpf == 31 || vd.nlpf == 15)) {
+        dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
+        if (vd.nlpf == 31)
+            hipLaunchKernelGGL(k_excite_w4<31>, grid, block, 0, stream, bd, vd);
+        else
+            hipLaunchKernelGGL(k_excite_w4<15>, grid, block, 0, stream, bd, vd);
+        return hipGetLastError();
+    }
     const uint64_t maxN = (uint64_t)bd.maxT * (uint64_t)vd.fperiod;
     dim3 grid((unsigned)((maxN + kExcBlock - 1) / kExcBlock), bd.B), block(kExcBlock);
     hipLaunchKernelGGL(k_excite, grid, block, 0, stream, bd, vd);

@@ -87,16 +87,18 @@ def test_volume_and_gv_weight(oracle_voice, have_gpu):
 
 
 def test_fused_mlpg_equals_generic_bitwise(oracle_voice, have_gpu):
-    """The chunk-prefetched / pass-fused BW=3 solver, the elementwise static-window
-    kernel and the state-level prep keep the reference's order of operations: their
-    tracks must equal the un-fused generic kernels' bit for bit, and the oracle's
-    within rel 1e-12."""
+    """With the GV sums in the reference's serial order (serial_gv) the chunk-prefetched /
+    pass-fused BW=3 solver on the [dim][frame] workspace, the elementwise static-window
+    kernel and the state-level prep keep the reference's order of operations: their tracks
+    must equal the un-fused generic kernels' bit for bit, and the oracle's within rel 1e-12.
+    The default path only changes the SHAPE of the three GV reductions (time-parallel tree
+    sums): LF0 and LPF stay bit-identical, MCP agrees to 1e-12 relative."""
     v = oracle_voice
     dur, sts = oracle_states(v, SAMPLE_SENTENCE_2)
     tracks = [O.mlpg(s, dur) for s in sts]
     outs = []
-    for generic in (False, True):
-        with J.Batch(voice_info(v), [to_utt(dur, sts)], keep_tracks=True, generic_mlpg=generic) as b:
+    for kw in (dict(serial_gv=True), dict(generic_mlpg=True), dict()):
+        with J.Batch(voice_info(v), [to_utt(dur, sts)], keep_tracks=True, **kw) as b:
             b.run()
             b.sync()
             outs.append([b.track(0, si) for si in range(3)])
@@ -104,6 +106,35 @@ def test_fused_mlpg_equals_generic_bitwise(oracle_voice, have_gpu):
         assert np.array_equal(outs[0][si], outs[1][si]), si
         np.testing.assert_allclose(outs[0][si], tracks[si], rtol=1e-12, atol=0)
         print("stream", si, "bit-exact vs oracle:", np.array_equal(outs[0][si], tracks[si]))
+        if si != 0:
+            assert np.array_equal(outs[2][si], outs[0][si]), si
+        np.testing.assert_allclose(outs[2][si], tracks[si], rtol=1e-12, atol=1e-13)
+        d = np.abs(outs[2][si] - outs[0][si])
+        print("stream", si, "time-parallel GV vs serial order: max abs diff", d.max())
+
+
+def test_time_parallel_gv_is_deterministic_and_tiled(oracle_voice, have_gpu):
+    """The time-parallel GV sweeps: several tiles per utterance (T > 1024 frames), ragged
+    last tile, two utterances of different length in one batch; run-to-run identical bits and
+    within 1e-12 of the serial-order kernel."""
+    v = oracle_voice
+    dur, sts = oracle_states(v, SAMPLE_SENTENCE_2)
+    rng = np.random.default_rng(5)
+    big = [(np.asarray(dur) * 0 + rng.integers(11, 24, len(dur))).astype(np.uint32) for _ in range(2)]
+    big[1] = (big[1] * 2).astype(np.uint32)
+    assert int(big[0].sum()) > 1100 and int(big[1].sum()) > 2100
+    utts = [to_utt(d, sts) for d in big]
+    res = []
+    for kw in (dict(), dict(), dict(serial_gv=True)):
+        with J.Batch(voice_info(v), utts, keep_tracks=True, **kw) as b:
+            b.run()
+            b.sync()
+            res.append([b.track(i, 0) for i in range(2)])
+    for i in range(2):
+        assert np.array_equal(res[0][i], res[1][i])
+        np.testing.assert_allclose(res[0][i], res[2][i], rtol=1e-12, atol=1e-13)
+        ref = O.mlpg(sts[0], big[i])
+        np.testing.assert_allclose(res[0][i], ref, rtol=1e-12, atol=1e-13)
 
 
 def _run(v, utts, **kw):
