@@ -121,7 +121,7 @@ Batch::~Batch()
         hipEventDestroy(ev2);
     if (ev3)
         hipEventDestroy(ev3);
-    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf})
+    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build})
         if (ev)
             hipEventDestroy(ev);
     for (hipStream_t st : {stream_lf0, stream_lpf})
@@ -273,6 +273,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->device = dev;
     b->flags = opts ? opts->flags : 0;
     b->voice = *voice;
+    // (stream priorities were tried for the critical path and made every latency-bound kernel
+    // 2-4x slower on this stack; ordering is done with events instead)
     e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
     if (e != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
@@ -286,6 +288,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_lf0, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_lpf, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_prep, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_build, hipEventDisableTiming);
     hipEventCreate(&b->ev0);
     hipEventCreate(&b->ev1);
     hipEventCreate(&b->ev2);
@@ -456,6 +460,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.nblk = vd.fperiod / bs;
     vd.alpha = voice->alpha;
     vd.volume = voice->volume;
+    vd.voiced = b->sd[1].voiced;
     vd.run_list = b->sd[1].run_list;
     vd.nruns = b->sd[1].nruns;
     vd.mcp = b->sd[0].out;
@@ -500,7 +505,9 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
 int Batch::build_work(const jb_batch_opts *opts)
 {
     const bool serial = (flags & JB_BATCH_SERIAL) != 0;
-    warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 32;
+    warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 24;
+    if (!(opts && opts->warmup_frames) && getenv("JB_WARMUP_FRAMES")) // tuning aid
+        warmup_frames = (uint32_t)std::max(1, atoi(getenv("JB_WARMUP_FRAMES")));
     verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
     uint32_t ch = opts ? opts->chunk_frames : 0;
     // lane-pair throughput kernel: worth it once the batch holds enough frames to give
@@ -630,35 +637,44 @@ int Batch::enqueue_paramgen()
     hipEventRecord(ev_fork, stream);
     hipStreamWaitEvent(stream_lf0, ev_fork, 0);
     hipStreamWaitEvent(stream_lpf, ev_fork, 0);
-    // LF0 chain
+    // LF0 chain: state walk (voiced flags), MLPG, pitch, pulse schedule
     if ((e = launch_prep(bd, sd[1], 1, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_prep(lf0)");
-    if ((e = launch_mlpg(bd, sd[1], 1, stream_lf0)) != hipSuccess)
+    hipEventRecord(ev_prep, stream_lf0); // voiced flags of the LF0 stream
+    if ((e = launch_mlpg(bd, sd[1], 1, stream_lf0, nullptr)) != hipSuccess)
         return hip_fail(e, "k_mlpg(lf0)");
     if ((e = launch_pitch(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_pitch");
     if ((e = launch_pulse(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_pulse");
+    // MCP chain (the critical path): ev_build marks the end of its bandwidth-bound W'U^-1W build,
+    // after which the factor/substitution sweeps leave the machine nearly idle
+    if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess)
+        return hip_fail(e, "k_prep(mcp)");
+    if ((e = launch_mlpg(bd, sd[0], 0, stream, ev_build)) != hipSuccess)
+        return hip_fail(e, "k_mlpg(mcp)");
+    if ((e = launch_mc2b(bd, vd, stream)) != hipSuccess)
+        return hip_fail(e, "k_mc2b");
     // LPF chain
     if (voice.nstream > 2) {
         if ((e = launch_prep(bd, sd[2], 2, stream_lpf)) != hipSuccess)
             return hip_fail(e, "k_prep(lpf)");
-        if ((e = launch_mlpg(bd, sd[2], 2, stream_lpf)) != hipSuccess)
+        if ((e = launch_mlpg(bd, sd[2], 2, stream_lpf, nullptr)) != hipSuccess)
             return hip_fail(e, "k_mlpg(lpf)");
     }
+    // the pulse-free part of the excitation needs the LPF taps and the voiced flags only: it is
+    // held back until the MCP build is done and then runs under the latency-bound MCP/LF0
+    // sweeps, instead of after the pulse scheduler where it would compete with the GV sweeps
+    hipStreamWaitEvent(stream_lpf, ev_prep, 0);
+    hipStreamWaitEvent(stream_lpf, ev_build, 0);
+    if ((e = launch_excite_noise(bd, vd, stream_lpf)) != hipSuccess)
+        return hip_fail(e, "k_excite(noise)");
     hipEventRecord(ev_lpf, stream_lpf);
-    // mixed excitation needs pulses (LF0) and LPF taps only: it overlaps the MCP solve
+    // pulses (LF0): the samples after each pulse (split form) or the whole excitation
     hipStreamWaitEvent(stream_lf0, ev_lpf, 0);
     if ((e = launch_excite(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_excite");
     hipEventRecord(ev_lf0, stream_lf0);
-    // MCP chain
-    if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess)
-        return hip_fail(e, "k_prep(mcp)");
-    if ((e = launch_mlpg(bd, sd[0], 0, stream)) != hipSuccess)
-        return hip_fail(e, "k_mlpg(mcp)");
-    if ((e = launch_mc2b(bd, vd, stream)) != hipSuccess)
-        return hip_fail(e, "k_mc2b");
     hipStreamWaitEvent(stream, ev_lf0, 0);
     return JB_OK;
 }

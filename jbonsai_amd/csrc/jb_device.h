@@ -96,6 +96,7 @@ struct VocDev {
     double *pinc;         // [sumT]  pitch_inc_per_point
     double *counter_start;// [sumT]  pitch_counter at frame start
     unsigned long long *pmask; // [sumT][nblk] pulse bit per sample of each block
+    const uint8_t *voiced;     // [sumT] MSD voiced flag of the LF0 stream (k_prep_frames)
     const uint32_t *run_list;  // voiced runs of the LF0 stream (k_prep_states)
     const uint32_t *nruns;
     const double *noise;  // [noise_len] shared Gaussian stream
@@ -128,12 +129,20 @@ struct BatchDev {
 
 // launchers (all asynchronous on `stream`)
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
-hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
+// after_build (optional) is recorded once A/bvec are built, before the serial sweeps start
+hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream,
+                       hipEvent_t after_build);
 int mlpg_mt_max_dim();      // largest vector length served by the [dim][frame] fast path
 int mlpg_gv_tile_frames();  // frames per block of the time-parallel GV sweeps
 hipError_t launch_pitch(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+// Mixed excitation.  When excite_is_split(vd): launch_excite_noise needs only the LF0 stream's
+// voiced flags (k_prep) and the LPF track and computes every sample as if there were no pulses;
+// launch_excite (after k_pulse) then recomputes the <= nlpf samples after each pulse exactly.
+// Otherwise launch_excite does everything in one pass and launch_excite_noise is a no-op.
+bool excite_is_split(const VocDev &vd);
+hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                           hipStream_t stream);

@@ -290,9 +290,12 @@ __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd
     }
     __syncthreads();
     const double *ivt = sd.ivar + up->state_off * (uint64_t)(W * L);
+    const double *mnt = st.mean;
     const int pitch = kBuildTF + 1, plane = L * pitch;
+    const int WL = W * L;
+    static_assert(BW == 3, "window loops below are unrolled for widths <= 3");
     for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
-        const int kl = e / L, m = e % L;
+        const int kl = e / L, m = e - kl * L;
         const uint32_t k = k0 + (uint32_t)kl;
         if (k >= Tv)
             continue;
@@ -300,38 +303,45 @@ __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd
 #pragma unroll
         for (int j = 0; j < BW; j++)
             wuw[j] = 0.0;
+        // The reference's loop nest (mlpg.rs:25-70: windows, then taps from last to first, then
+        // the taps from last down to this one) with the tap loops unrolled: every branch on a
+        // coefficient or a width is wave-uniform and the band index j is a constant.
         for (int w = 0; w < W; w++) {
             const int ww = sd.win_width[w];
             const double *coef = sd.win_coef + sd.win_off[w];
             const int lw = ww / 2, rw = ww - lw - 1;
-            for (int index = ww - 1; index >= 0; index--) {
-                const double c = coef[index];
-                if (c == 0.0)
+            double cf[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                cf[i] = i < ww ? coef[i] : 0.0;
+            const uint32_t mo = (uint32_t)(L * w + m);
+#pragma unroll
+            for (int index = 2; index >= 0; index--) {
+                if (index >= ww || cf[index] == 0.0)
                     continue;
-                const int d = index - ww / 2; // source frame k - d, |d| <= HW
+                const int d = index - lw; // source frame k - d
                 const long idx = (long)k - (long)d;
                 if (idx < 0 || idx >= (long)Tv)
                     continue;
                 const int fi = kl - d + HW;
-                const uint64_t pi = (uint64_t)f_state[fi] * (uint64_t)(W * L) + (uint64_t)(L * w + m);
-                const double mean = st.mean[pi];
+                const uint64_t pi = (uint64_t)(f_state[fi] * (uint32_t)WL + mo);
+                const double mean = mnt[pi];
                 double ivar = ivt[pi];
                 // dynamic windows touching an MSD boundary get ivar = 0 (mod.rs:69-80)
                 if (w != 0 && ((int)f_l[fi] < lw || (int)f_r[fi] < rw))
                     ivar = 0.0;
-                const double wu = c * ivar;
+                const double wu = cf[index] * ivar;
                 wum += wu * mean;
-                for (int inner = ww - 1; inner >= index; inner--) {
-                    const double c2 = coef[inner];
-                    if (c2 == 0.0)
+                bool live = true; // the reference leaves the inner loop at the first tap past the end
+#pragma unroll
+                for (int inner = 2; inner >= 0; inner--) {
+                    if (inner < index || inner >= ww || cf[inner] == 0.0)
                         continue;
                     const int j = inner - index;
                     if ((uint64_t)k + (uint64_t)j >= Tv)
-                        break;
-#pragma unroll
-                    for (int jj = 0; jj < BW; jj++)
-                        if (jj == j)
-                            wuw[jj] += wu * c2;
+                        live = false;
+                    if (live)
+                        wuw[j] += wu * cf[inner];
                 }
             }
         }
@@ -585,7 +595,7 @@ __global__ void k_mlpg_static(BatchDev bd, StreamDev sd, int si)
 #endif
 constexpr int MU = JB_MU;
 
-template <bool NONMSD, bool DOGV>
+template <bool NONMSD, bool DOGV, bool MT = false>
 __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, int si)
 {
     const int b = blockIdx.y;
@@ -601,9 +611,10 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
     const uint32_t n = sd.Tv[b];
     const uint64_t base = u.frame_off;
     // element k of this lane's dim: [frame][dim] rows (stride L) or its own [dim][frame] row
-    const uint64_t o0 = base * (uint64_t)L + (sd.mt ? (uint64_t)m * (uint64_t)T : (uint64_t)m);
-    const uint64_t Ls = sd.mt ? 1ull : (uint64_t)L;
-    const bool fuse_out = NONMSD && !sd.mt; // `out` is [frame][dim]: only then is par's slot also out's
+    // (MT is a template parameter so that the stride-1 form can use wide per-lane loads)
+    const uint64_t o0 = base * (uint64_t)L + (MT ? (uint64_t)m * (uint64_t)T : (uint64_t)m);
+    const uint64_t Ls = MT ? 1ull : (uint64_t)L;
+    const bool fuse_out = NONMSD && !MT; // `out` is [frame][dim]: only then is par's slot also out's
 #define IX(k) (o0 + (uint64_t)(k) * Ls)
 #define LD(dst, arr, tb)                                                                         \
     _Pragma("unroll") for (int u_ = 0; u_ < MU; u_++)                                            \
@@ -884,6 +895,10 @@ __device__ __forceinline__ double serial_add64(double acc, double v)
     return acc;
 }
 
+// Loads of kVtNB blocks of 64 frames are issued together before their serial sums run, so a
+// lone wave pays one memory latency per 256 frames instead of one per 64.
+constexpr int kVtNB = 4;
+
 template <bool NONMSD>
 __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, int si)
 {
@@ -904,35 +919,59 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
     const double gv_mean = st.gv_mean[m] * st.gv_weight; // mlpg.rs:135-137
     const double gv_vari = st.gv_var[m];
     const double glen = (double)gvl;
+    constexpr uint32_t STEP = 64u * kVtNB;
 
     // conv_gv (mlpg.rs:195-203)
     double ssum = 0.0;
-    for (uint32_t tb = 0; tb < n; tb += 64) {
-        const uint32_t t = tb + (uint32_t)lane;
-        const bool on = t < n && sw[t < n ? t : 0];
-        ssum = serial_add64(ssum, on ? Pv[IX(t)] : 0.0);
+    for (uint32_t tb = 0; tb < n; tb += STEP) {
+        double v[kVtNB];
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++) {
+            const uint32_t t = tb + 64u * q + (uint32_t)lane;
+            v[q] = (t < n && sw[t]) ? Pv[IX(t)] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++)
+            if (tb + 64u * q < n)
+                ssum = serial_add64(ssum, v[q]);
     }
     double mean = ssum / glen;
     double vsum = 0.0;
-    for (uint32_t tb = 0; tb < n; tb += 64) {
-        const uint32_t t = tb + (uint32_t)lane;
-        const bool on = t < n && sw[t < n ? t : 0];
-        const double p = on ? Pv[IX(t)] : mean;
-        vsum = serial_add64(vsum, on ? (p - mean) * (p - mean) : 0.0);
+    for (uint32_t tb = 0; tb < n; tb += STEP) {
+        double v[kVtNB];
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++) {
+            const uint32_t t = tb + 64u * q + (uint32_t)lane;
+            const bool on = t < n && sw[t];
+            const double p = on ? Pv[IX(t)] : mean;
+            v[q] = on ? (p - mean) * (p - mean) : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++)
+            if (tb + 64u * q < n)
+                vsum = serial_add64(vsum, v[q]);
     }
     double vari = vsum / glen;
     {
         const double ratio = sqrt(gv_mean / vari);
         ssum = 0.0;
-        for (uint32_t tb = 0; tb < n; tb += 64) {
-            const uint32_t t = tb + (uint32_t)lane;
-            const bool on = t < n && sw[t < n ? t : 0];
-            double pn = 0.0;
-            if (on) {
-                pn = ratio * (Pv[IX(t)] - mean) + mean;
-                Pv[IX(t)] = pn;
+        for (uint32_t tb = 0; tb < n; tb += STEP) {
+            double v[kVtNB];
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++) {
+                const uint32_t t = tb + 64u * q + (uint32_t)lane;
+                const bool on = t < n && sw[t];
+                double pn = 0.0;
+                if (on) {
+                    pn = ratio * (Pv[IX(t)] - mean) + mean;
+                    Pv[IX(t)] = pn;
+                }
+                v[q] = pn;
             }
-            ssum = serial_add64(ssum, pn);
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++)
+                if (tb + 64u * q < n)
+                    ssum = serial_add64(ssum, v[q]);
         }
     }
     double step = 0.1, prev = 0.0; // STEPINIT
@@ -946,28 +985,36 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
         double hmmobj = 0.0;
         vsum = 0.0;
         __syncthreads(); // par written by other lanes in the previous sweep is visible (one wave)
-        for (uint32_t tb = 0; tb < n; tb += 64) {
-            const uint32_t t = tb + (uint32_t)lane;
-            double vs = 0.0, hv = 0.0;
-            if (t < n) {
-                const double p0 = Pv[IX(t)];
-                if (sw[t])
-                    vs = (p0 - mean) * (p0 - mean);
-                double g = A0[IX(t)] * p0;
-                if (t + 1 < n)
-                    g += A1[IX(t)] * Pv[IX(t + 1)];
-                if (t >= 1)
-                    g += A1[IX(t - 1)] * Pv[IX(t - 1)];
-                if (t + 2 < n)
-                    g += A2[IX(t)] * Pv[IX(t + 2)];
-                if (t >= 2)
-                    g += A2[IX(t - 2)] * Pv[IX(t - 2)];
-                Gv[IX(t)] = g;
-                hv = 1.0 * wgt * p0 * (Bv[IX(t)] - 0.5 * g);
+        for (uint32_t tb = 0; tb < n; tb += STEP) {
+            double vs[kVtNB], hv[kVtNB];
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++) {
+                const uint32_t t = tb + 64u * q + (uint32_t)lane;
+                vs[q] = hv[q] = 0.0;
+                if (t < n) {
+                    const double p0 = Pv[IX(t)];
+                    if (sw[t])
+                        vs[q] = (p0 - mean) * (p0 - mean);
+                    double g = A0[IX(t)] * p0;
+                    if (t + 1 < n)
+                        g += A1[IX(t)] * Pv[IX(t + 1)];
+                    if (t >= 1)
+                        g += A1[IX(t - 1)] * Pv[IX(t - 1)];
+                    if (t + 2 < n)
+                        g += A2[IX(t)] * Pv[IX(t + 2)];
+                    if (t >= 2)
+                        g += A2[IX(t - 2)] * Pv[IX(t - 2)];
+                    Gv[IX(t)] = g;
+                    hv[q] = 1.0 * wgt * p0 * (Bv[IX(t)] - 0.5 * g);
+                }
             }
-            vsum = serial_add64(vsum, vs);
-            // hmmobj has no switch: frames beyond n contribute nothing (exact: + 0.0)
-            hmmobj = serial_add64(hmmobj, hv);
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++)
+                if (tb + 64u * q < n) {
+                    vsum = serial_add64(vsum, vs[q]);
+                    // hmmobj has no switch: frames beyond n contribute nothing (exact: + 0.0)
+                    hmmobj = serial_add64(hmmobj, hv[q]);
+                }
         }
         vari = vsum / glen;
         const double gvobj = -0.5 * 1.0 * vari * gv_vari * (vari - 2.0 * gv_mean);
@@ -982,30 +1029,37 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
         const double dv = -2.0 * gv_vari * (vari - gv_mean) / length;
         ssum = 0.0;
         __syncthreads();
-        for (uint32_t tb = 0; tb < n; tb += 64) {
-            const uint32_t t = tb + (uint32_t)lane;
-            double sn = 0.0;
-            if (t < n) {
-                const double p = Pv[IX(t)];
-                const double h = -1.0 * wgt * A0[IX(t)] -
-                                 1.0 * 2.0 / ll *
-                                     (lm1 * gv_vari * (vari - gv_mean) +
-                                      2.0 * gv_vari * (p - mean) * (p - mean));
-                const bool on = sw[t] != 0;
-                double next_g;
-                if (on)
-                    next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]) + 1.0 * dv * (p - mean));
-                else
-                    next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]));
-                const double pnew = p + step * next_g;
-                if (NONMSD && it == 5)
-                    Ov[IX(t)] = pnew; // scatter fused into the last sweep
-                else
-                    Pv[IX(t)] = pnew;
-                if (on)
-                    sn = pnew;
+        for (uint32_t tb = 0; tb < n; tb += STEP) {
+            double sn[kVtNB];
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++) {
+                const uint32_t t = tb + 64u * q + (uint32_t)lane;
+                sn[q] = 0.0;
+                if (t < n) {
+                    const double p = Pv[IX(t)];
+                    const double h = -1.0 * wgt * A0[IX(t)] -
+                                     1.0 * 2.0 / ll *
+                                         (lm1 * gv_vari * (vari - gv_mean) +
+                                          2.0 * gv_vari * (p - mean) * (p - mean));
+                    const bool on = sw[t] != 0;
+                    double next_g;
+                    if (on)
+                        next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]) + 1.0 * dv * (p - mean));
+                    else
+                        next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]));
+                    const double pnew = p + step * next_g;
+                    if (NONMSD && it == 5)
+                        Ov[IX(t)] = pnew; // scatter fused into the last sweep
+                    else
+                        Pv[IX(t)] = pnew;
+                    if (on)
+                        sn[q] = pnew;
+                }
             }
-            ssum = serial_add64(ssum, sn);
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++)
+                if (tb + 64u * q < n)
+                    ssum = serial_add64(ssum, sn[q]);
         }
         prev = obj;
     }
@@ -1046,12 +1100,12 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
 {
     const int tile = blockIdx.x, m = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const UttDev *up = bd.utt + b;
-    const StreamStatesDev st = up->st[si];
     const uint32_t n = sd.Tv[b], gvl = sd.gvlen[b];
-    if (n == 0 || !(st.gv_mean && gvl > 0))
-        return;
     const int t0 = tile * kGvTT;
-    if ((uint32_t)t0 >= n)
+    if (n == 0 || gvl == 0 || (uint32_t)t0 >= n)
+        return;
+    const StreamStatesDev st = up->st[si];
+    if (!st.gv_mean)
         return;
     const int L = sd.L, B = bd.B;
     const uint32_t NT = sd.gv_ntile;
@@ -1060,6 +1114,43 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
     const double *A0 = sd.A[0] + row, *A1 = sd.A[1] + row, *A2 = sd.A[2] + row, *Bv = sd.bvec + row;
     const double *P = src + row;
     double *Q = dst ? dst + row : nullptr;
+
+    // ---- every global load of the block is issued before anything waits on one ----
+    // window arrays (frame t0 - 4 + i): par_old, A1, A2; own frames (t0 - 2 + i): A0, bvec, switch
+    constexpr int KW = (kGvTT + 8 + kGvNT - 1) / kGvNT;
+    double pw[KW], a1w[KW], a2w[KW], a0r[kGvKX], br[kGvKX];
+    bool onr[kGvKX];
+    double p_own[kGvTT / kGvNT];
+    bool on_own[kGvTT / kGvNT];
+    if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < kGvTT / kGvNT; k++) {
+            const uint32_t t = (uint32_t)t0 + (uint32_t)(tid + kGvNT * k);
+            const bool ok = t < n;
+            p_own[k] = ok ? P[t] : 0.0;
+            on_own[k] = ok && sw[t] != 0;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KW; k++) {
+            const int i = tid + kGvNT * k;
+            const int t = t0 - 4 + i;
+            const bool ok = i < kGvTT + 8 && t >= 0 && (uint32_t)t < n;
+            pw[k] = ok ? P[t] : 0.0;
+            a1w[k] = ok ? A1[t] : 0.0;
+            a2w[k] = ok ? A2[t] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < kGvKX; k++) {
+            const int i = tid + kGvNT * k;
+            const int t = t0 - 2 + i;
+            const bool ok = i < kGvTT + 4 && t >= 0 && (uint32_t)t < n;
+            a0r[k] = ok ? A0[t] : 0.0;
+            br[k] = ok ? Bv[t] : 0.0;
+            onr[k] = ok && sw[t] != 0;
+        }
+    }
+
     const double gv_mean = st.gv_mean[m] * st.gv_weight; // mlpg.rs:135-137
     const double gv_vari = st.gv_var[m];
     const double glen = (double)gvl;
@@ -1118,24 +1209,23 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
     if (MODE == 0) {
 #pragma unroll
         for (int k = 0; k < kGvTT / kGvNT; k++) {
-            const uint32_t t = (uint32_t)t0 + (uint32_t)(tid + kGvNT * k);
-            if (t < n && sw[t]) {
-                const double dlt = P[t] - K;
+            if (on_own[k]) {
+                const double dlt = p_own[k] - K;
                 s1 += dlt;
                 s2 += dlt * dlt;
             }
         }
     } else {
         // LDS windows: po = par_old[t0-4 .. t0+TT+4), pn = par_new[t0-2 .. t0+TT+2),
-        // a1s/a2s = A1/A2[t0-4 .. t0+TT+2)
-        __shared__ double po[kGvTT + 8], pn[kGvTT + 4], a1s[kGvTT + 6], a2s[kGvTT + 6];
-        for (int i = tid; i < kGvTT + 8; i += kGvNT) {
-            const int t = t0 - 4 + i;
-            const bool ok = t >= 0 && (uint32_t)t < n;
-            po[i] = ok ? P[t] : 0.0;
-            if (i < kGvTT + 6) {
-                a1s[i] = ok ? A1[t] : 0.0;
-                a2s[i] = ok ? A2[t] : 0.0;
+        // a1s/a2s = A1/A2[t0-4 .. t0+TT+4)
+        __shared__ double po[kGvTT + 8], pn[kGvTT + 4], a1s[kGvTT + 8], a2s[kGvTT + 8];
+#pragma unroll
+        for (int k = 0; k < KW; k++) {
+            const int i = tid + kGvNT * k;
+            if (i < kGvTT + 8) {
+                po[i] = pw[k];
+                a1s[i] = a1w[k];
+                a2s[i] = a2w[k];
             }
         }
         __syncthreads();
@@ -1143,22 +1233,15 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
         const double ll = (double)((uint64_t)n * (uint64_t)n);
         const double lm1 = (double)(n - 1);
         const double dv = -2.0 * gv_vari * (vari - gv_mean) / length;
-        double a0r[kGvKX], br[kGvKX];
-        bool onr[kGvKX];
         // ---- transform: par_new on the tile and two halo frames each side ----
 #pragma unroll
         for (int k = 0; k < kGvKX; k++) {
             const int i = tid + kGvNT * k; // index into pn; frame t = t0 - 2 + i
             const int t = t0 - 2 + i;
-            a0r[k] = br[k] = 0.0;
-            onr[k] = false;
             if (i < kGvTT + 4 && t >= 0 && (uint32_t)t < n) {
                 const double p = po[i + 2];
-                const bool on = sw[t] != 0;
-                const double a0 = A0[t], bb = Bv[t];
-                a0r[k] = a0;
-                br[k] = bb;
-                onr[k] = on;
+                const bool on = onr[k];
+                const double a0 = a0r[k], bb = br[k];
                 double pnew;
                 if (MODE == 1) {
                     pnew = on ? ratio * (p - mean) + mean : p; // conv_gv (mlpg.rs:195-203)
@@ -1323,12 +1406,13 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
 }
 
 template <int BW>
-static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
+static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
+                                 hipEvent_t after_build)
 {
     const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
     if (work == 0 || bd.B == 0)
         return hipSuccess;
-    if (BW == 3 && sd.mt) {
+    if constexpr (BW == 3) if (sd.mt) {
         // [dim][frame] workspace: build, lane-per-dim factor/substitution sweeps, GV, transpose
         {
             const uint64_t ne = (uint64_t)bd.maxS * (uint64_t)(sd.W * sd.L);
@@ -1340,18 +1424,20 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             const size_t lds = sizeof(double) * (size_t)(BW + 1) * sd.L * (kBuildTF + 1);
             hipLaunchKernelGGL(k_mlpg_build_mt<BW>, grid, block, lds, stream, bd, sd, si);
         }
+        if (after_build)
+            hipEventRecord(after_build, stream);
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         const bool tp = sd.use_gv && !sd.serial_gv && sd.gv_part;
         if (sd.is_msd) {
             if (tp)
-                hipLaunchKernelGGL((k_mlpg_solve3<false, false>), grid, block, 0, stream, bd, sd, si);
+                hipLaunchKernelGGL((k_mlpg_solve3<false, false, true>), grid, block, 0, stream, bd, sd, si);
             else
-                hipLaunchKernelGGL((k_mlpg_solve3<false, true>), grid, block, 0, stream, bd, sd, si);
+                hipLaunchKernelGGL((k_mlpg_solve3<false, true, true>), grid, block, 0, stream, bd, sd, si);
         } else {
             if (tp)
-                hipLaunchKernelGGL((k_mlpg_solve3<true, false>), grid, block, 0, stream, bd, sd, si);
+                hipLaunchKernelGGL((k_mlpg_solve3<true, false, true>), grid, block, 0, stream, bd, sd, si);
             else
-                hipLaunchKernelGGL((k_mlpg_solve3<true, true>), grid, block, 0, stream, bd, sd, si);
+                hipLaunchKernelGGL((k_mlpg_solve3<true, true, true>), grid, block, 0, stream, bd, sd, si);
         }
         if (tp) {
             // par -> g -> par -> ... : conv_gv + five iterations = six writes, result back in par
@@ -1374,6 +1460,8 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
         dim3 grid((unsigned)((work + 255) / 256), bd.B), block(256);
         hipLaunchKernelGGL(k_mlpg_build<BW>, grid, block, 0, stream, bd, sd, si);
     }
+    if (after_build)
+        hipEventRecord(after_build, stream);
     {
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         if (BW == 3 && !sd.generic_solver) {
@@ -1406,7 +1494,7 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
 int mlpg_mt_max_dim() { return kMtMaxDim; }
 int mlpg_gv_tile_frames() { return kGvTT; }
 
-hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
+hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream, hipEvent_t after_build)
 {
     if (sd.BW == 1 && sd.W == 1 && !sd.use_gv && !sd.generic_solver) {
         const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
@@ -1414,15 +1502,17 @@ hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
             return hipSuccess;
         dim3 grid((unsigned)((work + 255) / 256), bd.B), block(256);
         hipLaunchKernelGGL(k_mlpg_static, grid, block, 0, stream, bd, sd, si);
+        if (after_build)
+            hipEventRecord(after_build, stream);
         return hipGetLastError();
     }
     switch (sd.BW) {
     case 1:
-        return launch_mlpg_bw<1>(bd, sd, si, stream);
+        return launch_mlpg_bw<1>(bd, sd, si, stream, after_build);
     case 3:
-        return launch_mlpg_bw<3>(bd, sd, si, stream);
+        return launch_mlpg_bw<3>(bd, sd, si, stream, after_build);
     case 5:
-        return launch_mlpg_bw<5>(bd, sd, si, stream);
+        return launch_mlpg_bw<5>(bd, sd, si, stream, after_build);
     default:
         return hipErrorInvalidValue;
     }

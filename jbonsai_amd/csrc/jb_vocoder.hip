@@ -246,7 +246,7 @@ constexpr int kExwQ = (256 + kExwHalo) / kExw; // LDS row pitch (q = (m + halo) 
 // NLPF is a template parameter: with a run-time tap count every tap becomes its own scalar
 // load + branch and the wave pays one scalar-cache latency per tap (measured 14 ms); known at
 // compile time, the taps arrive in a few wide scalar loads.
-template <int NLPF>
+template <int NLPF, bool NOISE_ONLY>
 __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
 {
     static_assert(NLPF - 1 <= kExwHalo - 2, "history window too short");
@@ -271,8 +271,10 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
     double(*ec)[kExwQ] = ec_s[wv];
     double(*ep)[kExwHalo / kExw] = ep_s[wv];
     double(*nz)[kExwQ] = nz_s[wv];
-    const bool vcur = vd.pitch[f] != 0.0;
-    const bool vprev = fr > 0 && vd.pitch[f - 1] != 0.0;
+    // NOISE_ONLY: every sample as if no pulse fell into its window (e = -noise in voiced frames);
+    // needs the MSD voiced flags only, not the pitch track.  k_excite_fix repairs the rest.
+    const bool vcur = NOISE_ONLY ? vd.voiced[f] != 0 : vd.pitch[f] != 0.0;
+    const bool vprev = fr > 0 && (NOISE_ONLY ? vd.voiced[f - 1] != 0 : vd.pitch[f - 1] != 0.0);
     // ---- stage noise and e for samples m = -32 .. fp-1 of this frame ----
     for (int idx = lane; idx < fp + kExwHalo; idx += 64) {
         const int m = idx - kExwHalo;
@@ -285,10 +287,12 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
             if (cur ? vcur : vprev) {
                 const uint64_t ff = cur ? f : f - 1;
                 const int i = cur ? m : m + fp;
-                const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
                 double pulse = 0.0;
-                if ((pm >> (i % bs)) & 1ull)
-                    pulse = sqrt(fma((double)i, vd.pinc[ff], vd.cur_start[ff]));
+                if (!NOISE_ONLY) {
+                    const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
+                    if ((pm >> (i % bs)) & 1ull)
+                        pulse = sqrt(fma((double)i, vd.pinc[ff], vd.cur_start[ff]));
+                }
                 ev = pulse - nv;
             }
         }
@@ -358,6 +362,100 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
     if (vd.exc) {
         *reinterpret_cast<double2 *>(vd.exc + o) = make_double2(x[0], x[1]);
         *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[2], x[3]);
+    }
+}
+
+// Second half of the split excitation: one wave per frame; frames without a pulse leave at
+// once.  For every pulse (sample p of the frame) lanes 0..NLPF-1 recompute the NLPF samples
+// p .. p+NLPF-1 that see it, from the complete e[] (all pulses, both neighbouring frames) in tap
+// order -- the same chain of FMAs as k_excite_w4's two passes, so the two kernels together are
+// bit-identical to the one-pass form.  Samples covered by two pulses are written twice with the
+// same value.
+template <int NLPF>
+__global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.y;
+    const UttDev *u = bd.utt + b;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)wv));
+    const uint32_t T = u->T;
+    if (fr >= T)
+        return;
+    const uint64_t base = u->frame_off;
+    const uint64_t f = base + fr;
+    if (!vd.voiced[f])
+        return;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+    unsigned long long any = 0ull;
+    for (int q = 0; q < nblk; q++)
+        any |= vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
+    if (any == 0ull)
+        return;
+    constexpr int H = NLPF - 1;
+    static_assert(2 * H + 1 <= 64, "window must fit one wave");
+    const int anti = H / 2;
+    const long n0 = (long)fr * (long)fp;
+    const long N = (long)T * (long)fp;
+    __shared__ double es_s[4][2 * H + 1]; // e[p-H .. p+H] of the current pulse
+    __shared__ double tp_s[4][3][NLPF];   // taps of frames fr-1, fr, fr+1
+    double *es = es_s[wv];
+    double(*tp3)[NLPF] = tp_s[wv];
+    if (lane < NLPF) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const long ff = (long)fr - 1 + j;
+            tp3[j][lane] = (ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
+        }
+    }
+    for (int q = 0; q < nblk; q++) {
+        unsigned long long word = vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
+        // wave-uniform by construction; tell the compiler
+        word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(word >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
+        while (word) {
+            const int j = __builtin_ctzll(word);
+            word &= word - 1ull;
+            const int p = q * bs + j;
+            // ---- e over the window m = p-H+lane (frame-relative), lanes 0..2H ----
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane <= 2 * H) {
+                const int m = p - H + lane;
+                const long g = n0 + m;
+                double ev = 0.0;
+                if (g >= 0 && g < N) {
+                    const int df = m < 0 ? -1 : (m >= fp ? 1 : 0);
+                    const uint64_t ff = (uint64_t)((long)f + df);
+                    const int i = m - df * fp;
+                    if (vd.voiced[ff]) {
+                        const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
+                        double pulse = 0.0;
+                        if ((pm >> (i % bs)) & 1ull)
+                            pulse = sqrt(fma((double)i, vd.pinc[ff], vd.cur_start[ff]));
+                        ev = pulse - vd.noise[g];
+                    }
+                }
+                es[lane] = ev;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- targets n = n0 + p + lane, lanes 0..H ----
+            const long n = n0 + p + lane;
+            if (lane <= H && n < N) {
+                double x = n >= anti ? vd.noise[n - anti] : 0.0;
+#pragma unroll
+                for (int k = 0; k < NLPF; k++) {
+                    const int ms = p + lane - k; // frame-relative source sample
+                    const int sel = ms < 0 ? 0 : (ms >= fp ? 2 : 1);
+                    x = fma(es[lane + H - k], tp3[sel][k], x);
+                }
+                const uint64_t o = base * (uint64_t)fp + (uint64_t)n;
+                vd.xin[o] = x;
+                if (vd.exc)
+                    vd.exc[o] = x;
+            }
+        }
     }
 }
 
@@ -1190,18 +1288,46 @@ hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
     return hipGetLastError();
 }
 
+static bool excite_w4_ok(const VocDev &vd)
+{
+    static const bool generic = getenv("JB_EXCITE_GENERIC") && atoi(getenv("JB_EXCITE_GENERIC")) != 0;
+    return !generic && vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo &&
+           (vd.nlpf == 31 || vd.nlpf == 15);
+}
+
+bool excite_is_split(const VocDev &vd)
+{
+    static const bool nosplit = getenv("JB_EXCITE_SPLIT") && atoi(getenv("JB_EXCITE_SPLIT")) == 0;
+    return excite_w4_ok(vd) && !nosplit;
+}
+
+hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
+{
+    if (bd.B == 0 || bd.maxT == 0 || !excite_is_split(vd))
+        return hipSuccess;
+    dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
+    if (vd.nlpf == 31)
+        hipLaunchKernelGGL((k_excite_w4<31, true>), grid, block, 0, stream, bd, vd);
+    else
+        hipLaunchKernelGGL((k_excite_w4<15, true>), grid, block, 0, stream, bd, vd);
+    return hipGetLastError();
+}
+
 hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
-    static const bool generic = getenv("JB_EXCITE_GENERIC") && atoi(getenv("JB_EXCITE_GENERIC")) != 0;
-    if (!generic && vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo &&
-        (vd.nlpf == 31 || vd.nlpf == 15)) {
+    if (excite_w4_ok(vd)) {
         dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
-        if (vd.nlpf == 31)
-            hipLaunchKernelGGL(k_excite_w4<31>, grid, block, 0, stream, bd, vd);
+        if (excite_is_split(vd)) {
+            if (vd.nlpf == 31)
+                hipLaunchKernelGGL(k_excite_fix<31>, grid, block, 0, stream, bd, vd);
+            else
+                hipLaunchKernelGGL(k_excite_fix<15>, grid, block, 0, stream, bd, vd);
+        } else if (vd.nlpf == 31)
+            hipLaunchKernelGGL((k_excite_w4<31, false>), grid, block, 0, stream, bd, vd);
         else
-            hipLaunchKernelGGL(k_excite_w4<15>, grid, block, 0, stream, bd, vd);
+            hipLaunchKernelGGL((k_excite_w4<15, false>), grid, block, 0, stream, bd, vd);
         return hipGetLastError();
     }
     const uint64_t maxN = (uint64_t)bd.maxT * (uint64_t)vd.fperiod;
