@@ -873,6 +873,186 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
 }
 
 // --------------------------------------------------------------------------
+// A5/A6 for the [dim][frame] workspace: band LDL^T + forward substitution, then backward
+// substitution (mlpg.rs:79-115), one lane per (utterance, dim), every lane streaming its own
+// contiguous row.  Same arithmetic and order as k_mlpg_solve3's F and B passes.  A lone wave
+// per CU has nothing but its own loads in flight, so (a) each lane moves 16 bytes per memory
+// instruction (dwordx4: half the address-processing work of 8-byte accesses, which is what
+// bounds an uncoalesced wave), and (b) the loads run kFbNB-1 chunks of kFbMU frames ahead in a
+// register ring, which also keeps the sweep from stretching when other kernels load the
+// memory system.
+constexpr int kFbMU = 4; // frames per chunk (even)
+constexpr int kFbNB = 4; // ring depth in chunks: loads run (kFbNB-1)*kFbMU frames ahead
+typedef double v2d8 __attribute__((ext_vector_type(2), aligned(8)));
+
+// whole chunk [tb, tb+MU): unconditional wide loads (the caller clamps tb to a valid chunk, so
+// that no branch surrounds a load: hipcc otherwise merges wait states at the join and drains
+// the whole ring with s_waitcnt vmcnt(0) at every use)
+__device__ __forceinline__ void fb_load(double (&dst)[kFbMU], const double *arr, uint32_t tb)
+{
+#pragma unroll
+    for (int u = 0; u < kFbMU; u += 2) {
+        const v2d8 x = *reinterpret_cast<const v2d8 *>(arr + tb + u);
+        dst[u] = x.x;
+        dst[u + 1] = x.y;
+    }
+}
+__device__ __forceinline__ void fb_store2(double *arr, uint32_t t, double x0, double x1)
+{
+    v2d8 x;
+    x.x = x0;
+    x.y = x1;
+    *reinterpret_cast<v2d8 *>(arr + t) = x;
+}
+
+__global__ __launch_bounds__(64) void k_mlpg_fb_mt(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.y;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int L = sd.L;
+    if (m >= L)
+        return;
+    const UttDev *up = bd.utt + b;
+    const uint32_t n = sd.Tv[b];
+    if (n == 0)
+        return;
+    const uint64_t row = up->frame_off * (uint64_t)L + (uint64_t)m * (uint64_t)up->T;
+    const double *A0 = sd.A[0] + row, *A1 = sd.A[1] + row, *A2 = sd.A[2] + row, *Bv = sd.bvec + row;
+    double *F0 = sd.F[0] + row, *F1 = sd.F[1] + row, *F2 = sd.F[2] + row, *Gv = sd.g + row;
+    double *Pv = sd.par + row;
+    const uint32_t nfull = n / kFbMU, rem = n - nfull * kFbMU;
+    const uint32_t lastc = nfull ? nfull - 1 : 0; // prefetches past the end re-read this chunk
+
+    // ---- pass F: ldl_factorization + forward substitution (mlpg.rs:79-105) ----
+    double p1_0 = 0, p1_1 = 0, p1_2 = 0, p2_0 = 0, p2_2 = 0, g1 = 0, g2 = 0;
+    auto fstep = [&](uint32_t t, double r0, double r1, double r2, double g, double &o0, double &o1,
+                     double &o2, double &og) {
+        if (t >= 1)
+            r0 -= p1_1 * p1_1 * p1_0;
+        if (t >= 2)
+            r0 -= p2_2 * p2_2 * p2_0;
+        if (t >= 1)
+            r1 -= p1_1 * p1_2 * p1_0;
+        r1 /= r0;
+        r2 /= r0;
+        if (t >= 1)
+            g -= p1_1 * g1;
+        if (t >= 2)
+            g -= p2_2 * g2;
+        o0 = r0;
+        o1 = r1;
+        o2 = r2;
+        og = g;
+        p2_0 = p1_0;
+        p2_2 = p1_2;
+        g2 = g1;
+        p1_0 = r0;
+        p1_1 = r1;
+        p1_2 = r2;
+        g1 = g;
+    };
+    if (nfull) {
+        double ring[kFbNB][4][kFbMU];
+#pragma unroll
+        for (int s = 0; s < kFbNB - 1; s++) {
+            const uint32_t tb = ((uint32_t)s < lastc ? (uint32_t)s : lastc) * kFbMU;
+            fb_load(ring[s][0], A0, tb);
+            fb_load(ring[s][1], A1, tb);
+            fb_load(ring[s][2], A2, tb);
+            fb_load(ring[s][3], Bv, tb);
+        }
+        for (uint32_t c0 = 0; c0 < nfull; c0 += kFbNB) {
+#pragma unroll
+            for (int s = 0; s < kFbNB; s++) {
+                const uint32_t c = c0 + (uint32_t)s;
+                if (c < nfull) {
+                    const int sp = (s + kFbNB - 1) % kFbNB; // slot freed by the previous chunk
+                    const uint32_t cp = c + kFbNB - 1;
+                    const uint32_t tp = (cp < lastc ? cp : lastc) * kFbMU;
+                    fb_load(ring[sp][0], A0, tp);
+                    fb_load(ring[sp][1], A1, tp);
+                    fb_load(ring[sp][2], A2, tp);
+                    fb_load(ring[sp][3], Bv, tp);
+                    const uint32_t tb = c * kFbMU;
+#pragma unroll
+                    for (int uu = 0; uu < kFbMU; uu += 2) {
+                        double a0, a1, a2, ag, b0, b1, b2, bg;
+                        fstep(tb + uu, ring[s][0][uu], ring[s][1][uu], ring[s][2][uu], ring[s][3][uu], a0, a1,
+                              a2, ag);
+                        fstep(tb + uu + 1, ring[s][0][uu + 1], ring[s][1][uu + 1], ring[s][2][uu + 1],
+                              ring[s][3][uu + 1], b0, b1, b2, bg);
+                        fb_store2(F0, tb + uu, a0, b0);
+                        fb_store2(F1, tb + uu, a1, b1);
+                        fb_store2(F2, tb + uu, a2, b2);
+                        fb_store2(Gv, tb + uu, ag, bg);
+                    }
+                }
+            }
+        }
+    }
+    for (uint32_t t = nfull * kFbMU; t < n; t++) { // ragged tail
+        double o0, o1, o2, og;
+        fstep(t, A0[t], A1[t], A2[t], Bv[t], o0, o1, o2, og);
+        F0[t] = o0;
+        F1[t] = o1;
+        F2[t] = o2;
+        Gv[t] = og;
+    }
+
+    // ---- pass B: backward substitution (mlpg.rs:106-113), t descending ----
+    // whole chunks from the top: chunk c covers [n-(c+1)*MU, n-c*MU); the ragged part [0, rem)
+    // comes last
+    double q1 = 0, q2 = 0;
+    auto bstep = [&](uint32_t t, double f0, double f1, double f2, double g) {
+        double p = g / f0;
+        if (t + 1 < n)
+            p -= f1 * q1;
+        if (t + 2 < n)
+            p -= f2 * q2;
+        q2 = q1;
+        q1 = p;
+        return p;
+    };
+    if (nfull) {
+        double ring[kFbNB][4][kFbMU];
+#pragma unroll
+        for (int s = 0; s < kFbNB - 1; s++) {
+            const uint32_t lo = n - (((uint32_t)s < lastc ? (uint32_t)s : lastc) + 1) * kFbMU;
+            fb_load(ring[s][0], F0, lo);
+            fb_load(ring[s][1], F1, lo);
+            fb_load(ring[s][2], F2, lo);
+            fb_load(ring[s][3], Gv, lo);
+        }
+        for (uint32_t c0 = 0; c0 < nfull; c0 += kFbNB) {
+#pragma unroll
+            for (int s = 0; s < kFbNB; s++) {
+                const uint32_t c = c0 + (uint32_t)s;
+                if (c < nfull) {
+                    const int sp = (s + kFbNB - 1) % kFbNB;
+                    const uint32_t cp = c + kFbNB - 1;
+                    const uint32_t lp = n - ((cp < lastc ? cp : lastc) + 1) * kFbMU;
+                    fb_load(ring[sp][0], F0, lp);
+                    fb_load(ring[sp][1], F1, lp);
+                    fb_load(ring[sp][2], F2, lp);
+                    fb_load(ring[sp][3], Gv, lp);
+                    const uint32_t lo = n - (c + 1) * kFbMU;
+#pragma unroll
+                    for (int uu = kFbMU - 2; uu >= 0; uu -= 2) { // frames lo+uu+1, then lo+uu
+                        const double pb = bstep(lo + uu + 1, ring[s][0][uu + 1], ring[s][1][uu + 1],
+                                                ring[s][2][uu + 1], ring[s][3][uu + 1]);
+                        const double pa = bstep(lo + uu, ring[s][0][uu], ring[s][1][uu], ring[s][2][uu],
+                                                ring[s][3][uu]);
+                        fb_store2(Pv, lo + uu, pa, pb);
+                    }
+                }
+            }
+        }
+    }
+    for (uint32_t r = rem; r-- > 0;) // ragged part, frames rem-1 .. 0
+        Pv[r] = bstep(r, F0[r], F1[r], F2[r], Gv[r]);
+}
+
+// --------------------------------------------------------------------------
 // A8 GV ascent with LANES OVER TIME (mlpg.rs:145-292).  The 13 sweeps of conv_gv and the
 // five parmgen iterations are elementwise in t plus reductions; only the ORDER of the
 // additions is serial.  One wave per (utterance, dim): 64 frames per vector instruction for
@@ -1425,17 +1605,17 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             hipLaunchKernelGGL(k_mlpg_build_mt<BW>, grid, block, lds, stream, bd, sd, si);
         }
         if (after_build)
-            hipEventRecord(after_build, stream);
+            (void)hipEventRecord(after_build, stream);
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         const bool tp = sd.use_gv && !sd.serial_gv && sd.gv_part;
         if (sd.is_msd) {
             if (tp)
-                hipLaunchKernelGGL((k_mlpg_solve3<false, false, true>), grid, block, 0, stream, bd, sd, si);
+                hipLaunchKernelGGL(k_mlpg_fb_mt, grid, block, 0, stream, bd, sd, si);
             else
                 hipLaunchKernelGGL((k_mlpg_solve3<false, true, true>), grid, block, 0, stream, bd, sd, si);
         } else {
             if (tp)
-                hipLaunchKernelGGL((k_mlpg_solve3<true, false, true>), grid, block, 0, stream, bd, sd, si);
+                hipLaunchKernelGGL(k_mlpg_fb_mt, grid, block, 0, stream, bd, sd, si);
             else
                 hipLaunchKernelGGL((k_mlpg_solve3<true, true, true>), grid, block, 0, stream, bd, sd, si);
         }
@@ -1461,7 +1641,7 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
         hipLaunchKernelGGL(k_mlpg_build<BW>, grid, block, 0, stream, bd, sd, si);
     }
     if (after_build)
-        hipEventRecord(after_build, stream);
+        (void)hipEventRecord(after_build, stream);
     {
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         if (BW == 3 && !sd.generic_solver) {
@@ -1503,7 +1683,7 @@ hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
         dim3 grid((unsigned)((work + 255) / 256), bd.B), block(256);
         hipLaunchKernelGGL(k_mlpg_static, grid, block, 0, stream, bd, sd, si);
         if (after_build)
-            hipEventRecord(after_build, stream);
+            (void)hipEventRecord(after_build, stream);
         return hipGetLastError();
     }
     switch (sd.BW) {

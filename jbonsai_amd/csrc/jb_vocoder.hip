@@ -762,7 +762,7 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
         return;
     const uint64_t base = has ? bd.utt[wk.utt].frame_off : 0;
     const int fp = vd.fperiod;
-    const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
+    const double a = vd.alpha, na = -a, iaa = 1.0 - a * a, vol = vd.volume;
     const int s0 = isA ? 0 : 3; // first stage of this lane
 
     // 34*512 + 12*256 = 20480 B = 160 KiB / 8: two blocks per SIMD fit the CU's LDS
@@ -898,13 +898,16 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
                 }
 #pragma unroll
                 for (int q = 0; q < NS; q++) {
-                    // d' = (1-a^2)*rem + a*d and rem' = d - a*rem kept independent of each other:
-                    // at one wave per SIMD the shorter dependency chain beats the 2-FMA form
-                    const double rn = fma(-a, r[q], d[q][j]);
-                    d[q][j] = fma(iaa, r[q], a * d[q][j]);
+                    // all-pass section: rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem',
+                    // as three-address v_fma_f64 (hipcc's v_fmac form costs a v_mov_b64 per tap
+                    // to undo the register rotation of the loop-carried d[])
+                    double rn, dn;
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rn) : "s"(na), "v"(r[q]), "v"(d[q][j]));
+                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dn) : "s"(a), "v"(rn), "v"(r[q]));
+                    d[q][j] = dn;
                     r[q] = rn;
                     if (j >= 2)
-                        y[q] = fma(cj, d[q][j], y[q]);
+                        y[q] = fma(cj, dn, y[q]);
                 }
                 // keep the scheduler from hoisting all coefficient reads to the top of the
                 // sample (it would need ~140 extra VGPRs): LDS reads run 4 taps ahead at most

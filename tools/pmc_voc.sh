@@ -8,17 +8,17 @@ i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT" \
-           "SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC"; do
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace -d $out/p$i -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; exit 1; }
-  python3 - "$out/p$i" <<'PY'
+  python3 - "$out/p$i" "${KERNEL:-k_vocoder_l}" <<'PY'
 import sys,glob,csv,collections
 f=glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True)
 acc=collections.defaultdict(float); n=collections.Counter()
 for fn in f:
     for r in csv.DictReader(open(fn)):
         k=r["Kernel_Name"]
-        if "k_vocoder_l" in k:
+        if (sys.argv[2] if len(sys.argv) > 2 else "k_vocoder_l") in k:
             acc[r["Counter_Name"]]+=float(r["Counter_Value"]); n[r["Counter_Name"]]+=1
 for k,v in acc.items(): print(f"{k} {v:.4g} (dispatches {n[k]})")
 PY
