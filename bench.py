@@ -28,6 +28,10 @@ sys.path.insert(0, str(ROOT))
 
 B_ALG = 8.67          # algorithmic bytes per output sample, f64 PCM
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+FLOP_PER_SAMPLE = 1.39e3      # algorithmic f64 flops per output sample
+# FP64 vector peak = half the guide's 157.3 TFLOPS FP32 vector rate (1024 SIMDs x 16 lanes x 2 flop x
+# 2.4 GHz); tools/microbench/f64_rate.hip sustains 68 TFLOP/s of dependent-free v_fma_f64 on this part
+FP64_VALU_PEAK_TFLOPS = 78.6
 VOICE = ROOT / "tests" / "golden" / "voice" / "nitech_jp_atr503_m001.htsvoice"
 
 
@@ -184,7 +188,13 @@ def main():
                 "bound": "hbm", "kernel": "k_vocoder_lt" if info["chunk_frames"] and info["n_items"] >= 16384 else "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel_ms": voc_avg_ms, "alg_bytes_per_sample": B_ALG,
-                "note": "recursive IIR: FP64 VALU-issue bound, not HBM bound (DESIGN.md section 4)",
+                "note": "recursive IIR: FP64 VALU-issue bound, not HBM bound (DESIGN.md section 4); see valu_f64",
+                # the bound that actually binds: useful f64 flops of the path (1.39 kflop per
+                # output sample) over the same kernel time, against the FP64 vector peak of the guide
+                "valu_f64": {"achieved_tflops": FLOP_PER_SAMPLE * samples_per_step / (voc_avg_ms * 1e-3) / 1e12,
+                             "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                             "frac": FLOP_PER_SAMPLE * samples_per_step / (voc_avg_ms * 1e-3) / 1e12
+                                     / FP64_VALU_PEAK_TFLOPS},
             },
         }
         if world == 1 and not args.no_cpu_baseline:
