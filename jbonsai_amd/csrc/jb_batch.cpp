@@ -409,6 +409,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         sd.generic_solver = (b->flags & JB_BATCH_GENERIC_MLPG) ? 1 : 0;
         sd.serial_gv = (b->flags & JB_BATCH_SERIAL_GV) ? 1 : 0;
         sd.mt = (sd.BW == 3 && !sd.generic_solver && sd.L > 2 && sd.L <= mlpg_mt_max_dim()) ? 1 : 0;
+        // MCP, non-MSD, [dim][frame]: its transpose is fused with mc2b (enqueue_paramgen)
+        sd.defer_out = (si == 0 && sd.mt && !sd.is_msd) ? 1 : 0;
         const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L, nst = (size_t)sumS;
         if ((rc = b->dalloc(&sd.s_start, nst, false)) || (rc = b->dalloc(&sd.s_vpre, nst, false)) ||
             (rc = b->dalloc(&sd.s_rstart, nst, false)) || (rc = b->dalloc(&sd.s_rend, nst, false)) ||
@@ -653,7 +655,11 @@ int Batch::enqueue_paramgen()
         return hip_fail(e, "k_prep(mcp)");
     if ((e = launch_mlpg(bd, sd[0], 0, stream, ev_build)) != hipSuccess)
         return hip_fail(e, "k_mlpg(mcp)");
-    if ((e = launch_mc2b(bd, vd, stream)) != hipSuccess)
+    if (sd[0].defer_out)
+        e = launch_mc2b_mt(bd, sd[0], vd, (flags & JB_BATCH_KEEP_TRACKS) != 0, stream);
+    else
+        e = launch_mc2b(bd, vd, stream);
+    if (e != hipSuccess)
         return hip_fail(e, "k_mc2b");
     // LPF chain
     if (voice.nstream > 2) {
@@ -903,6 +909,10 @@ int jb_batch_read_track(jb_batch *hb, size_t i, uint32_t si, double *dst, size_t
     Batch *b = (Batch *)hb;
     if (!b || i >= (size_t)b->B || si >= b->voice.nstream)
         return JB_ERR_INVALID;
+    if (!(b->flags & JB_BATCH_KEEP_TRACKS)) {
+        jb::set_error("parameter tracks need JB_BATCH_KEEP_TRACKS");
+        return JB_ERR_INVALID;
+    }
     size_t L = (size_t)b->sd[si].L, ne = (size_t)b->T[i] * L;
     if (cap < ne)
         return JB_ERR_BUFFER;

@@ -54,6 +54,7 @@ struct StreamDev {
     // serial substitutions want.  `out` is always [frame][dim].
     int mt;
     int serial_gv;            // 1: GV reductions in the reference's serial order (bit-exact tracks)
+    int defer_out;            // 1: launch_mlpg leaves `par` ([dim][frame]) and launch_mc2b_mt produces out/bcoef
     // time-parallel GV (k_mlpg_gv_tp): per-tile partial sums and per-iteration scalars
     double *ivar;             // [sumS][W*L] MeanVari::with_ivar of the state variances (k_mlpg_ivar), mt only
     double *gv_part;          // [7 passes][B][L][gv_ntile][4]
@@ -136,6 +137,10 @@ int mlpg_mt_max_dim();      // largest vector length served by the [dim][frame] 
 int mlpg_gv_tile_frames();  // frames per block of the time-parallel GV sweeps
 hipError_t launch_pitch(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+// MCP stream on the [dim][frame] workspace: transpose + mc2b in one pass over `par`
+// (write_out: also materialise the [frame][dim] parameter track for jb_batch_read_track)
+hipError_t launch_mc2b_mt(const BatchDev &bd, const StreamDev &sd, const VocDev &vd, bool write_out,
+                          hipStream_t stream);
 hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 // Mixed excitation.  When excite_is_split(vd): launch_excite_noise needs only the LF0 stream's
 // voiced flags (k_prep) and the LPF track and computes every sample as if there were no pulses;

@@ -121,6 +121,55 @@ __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, i
     }
 }
 
+// Non-MSD streams (msd = f64::MAX, model/mod.rs:113): every state is voiced, so the walk
+// degenerates to an exclusive prefix sum of the durations (wave-level scan, 64 states per step)
+// -- 20 us instead of 2 ms at the head of the MCP chain.
+__global__ __launch_bounds__(64) void k_prep_states_dense(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.x;
+    if (b >= bd.B)
+        return;
+    const int lane = threadIdx.x;
+    const UttDev *up = bd.utt + b;
+    const uint32_t S = up->S, T = up->T;
+    const uint32_t *dur = up->dur;
+    const uint8_t *gsw = up->st[si].gv_switch;
+    const uint64_t sb = up->state_off;
+    uint32_t t = 0, gl = 0;
+    for (uint32_t s0 = 0; s0 < S; s0 += 64) {
+        const uint32_t s = s0 + (uint32_t)lane;
+        const bool ok = s < S;
+        const uint32_t d = ok ? dur[s] : 0u;
+        uint32_t incl = d, g = (ok && gsw && gsw[s]) ? d : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, o);
+            if (lane >= o)
+                incl += v;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            g += (uint32_t)__shfl_xor((int)g, o);
+        if (ok) {
+            const uint32_t st = t + incl - d;
+            sd.s_start[sb + s] = st;
+            sd.s_vpre[sb + s] = st;
+            sd.s_rstart[sb + s] = 0;
+            sd.s_rend[sb + s] = T ? T - 1 : 0;
+            sd.s_voiced[sb + s] = 1;
+        }
+        t += (uint32_t)__shfl((int)incl, 63);
+        gl += g;
+    }
+    if (lane == 0) {
+        sd.Tv[b] = t;
+        sd.gvlen[b] = gl;
+        sd.nruns[b] = t ? 1u : 0u;
+        if (S)
+            sd.run_list[sb] = 0;
+    }
+}
+
 // thread per state: expand to frames
 __global__ void k_prep_frames(BatchDev bd, StreamDev sd, int si)
 {
@@ -1576,7 +1625,11 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
         return hipSuccess;
     {
         dim3 grid(bd.B), block(64);
-        hipLaunchKernelGGL(k_prep_states, grid, block, 0, stream, bd, sd, si);
+        static const bool dense_ok = !(getenv("JB_PREP_DENSE") && atoi(getenv("JB_PREP_DENSE")) == 0);
+        if (!sd.is_msd && dense_ok)
+            hipLaunchKernelGGL(k_prep_states_dense, grid, block, 0, stream, bd, sd, si);
+        else
+            hipLaunchKernelGGL(k_prep_states, grid, block, 0, stream, bd, sd, si);
     }
     if (bd.maxS > 0) {
         dim3 grid((bd.maxS + 127) / 128, bd.B), block(128);
@@ -1630,7 +1683,7 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
                 hipLaunchKernelGGL(k_mlpg_gv_tp<2>, gg, gb, 0, stream, bd, sd, si, it, src, dst, it < 5 ? 1 : 0);
             }
         }
-        {
+        if (!sd.defer_out) {
             dim3 g2((bd.maxT + 63) / 64, bd.B), b2(256);
             hipLaunchKernelGGL(k_mlpg_scatter_mt, g2, b2, sizeof(double) * (size_t)sd.L * 65, stream, bd, sd);
         }
@@ -1668,6 +1721,57 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             hipLaunchKernelGGL(k_mlpg_solve<BW>, grid, block, 0, stream, bd, sd, si);
         }
     }
+    return hipGetLastError();
+}
+
+// A9 + V2 (mask.rs:34-49, cepstrum.rs:139-149) for the non-MSD MCP stream on the [dim][frame]
+// workspace: a block turns 64 frames x L dims of `par` in LDS, optionally writes the
+// [frame][dim] track, runs b[m] = c[m] - alpha*b[m+1] down each frame's column and writes
+// bcoef -- one pass over par instead of transpose (read+write) followed by mc2b (read+write).
+__global__ __launch_bounds__(256) void k_mc2b_mt(BatchDev bd, StreamDev sd, VocDev vd, int write_out)
+{
+    extern __shared__ double tile[]; // [L][65]
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    const uint32_t T = up->T;
+    const uint32_t t0 = blockIdx.x * 64u;
+    if (t0 >= T)
+        return;
+    const uint64_t base = up->frame_off;
+    const int L = sd.L;
+    const uint64_t row0 = base * (uint64_t)L;
+    const uint32_t nt = T - t0 < 64u ? T - t0 : 64u;
+    for (int e = threadIdx.x; e < 64 * L; e += blockDim.x) {
+        const int m = e >> 6, tl = e & 63;
+        tile[m * 65 + tl] = (uint32_t)tl < nt ? sd.par[row0 + (uint64_t)m * T + t0 + (uint32_t)tl] : 0.0;
+    }
+    __syncthreads();
+    const uint64_t o0 = (base + t0) * (uint64_t)L;
+    if (write_out)
+        for (int e = threadIdx.x; e < (int)nt * L; e += blockDim.x)
+            sd.out[o0 + (uint64_t)e] = tile[(e % L) * 65 + e / L];
+    __syncthreads();
+    if (threadIdx.x < nt && vd.alpha != 0.0) {
+        const int tl = threadIdx.x;
+        double prev = tile[(L - 1) * 65 + tl];
+        for (int i = L - 2; i >= 0; i--) {
+            prev = tile[i * 65 + tl] - vd.alpha * prev;
+            tile[i * 65 + tl] = prev;
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < (int)nt * L; e += blockDim.x)
+        vd.bcoef[o0 + (uint64_t)e] = tile[(e % L) * 65 + e / L];
+}
+
+hipError_t launch_mc2b_mt(const BatchDev &bd, const StreamDev &sd, const VocDev &vd, bool write_out,
+                          hipStream_t stream)
+{
+    if (bd.B == 0 || bd.maxT == 0)
+        return hipSuccess;
+    dim3 grid((bd.maxT + 63) / 64, bd.B), block(256);
+    hipLaunchKernelGGL(k_mc2b_mt, grid, block, sizeof(double) * (size_t)sd.L * 65, stream, bd, sd, vd,
+                       write_out ? 1 : 0);
     return hipGetLastError();
 }
 
