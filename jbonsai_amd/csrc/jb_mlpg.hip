@@ -1312,8 +1312,14 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
 // One pass over par, A0..A2, bvec per iteration instead of the serial kernel's two sweeps
 // at one lane per dim: ~70 GB of traffic over >100k blocks instead of 13 x 25k dependent
 // steps on 256 waves.
-constexpr int kGvTT = 1024;                      // frames per tile
-constexpr int kGvNT = 256;                       // threads per block
+#ifndef JB_GV_TT
+#define JB_GV_TT 2048
+#endif
+#ifndef JB_GV_NT
+#define JB_GV_NT 512
+#endif
+constexpr int kGvTT = JB_GV_TT;                  // frames per tile
+constexpr int kGvNT = JB_GV_NT;                  // threads per block
 constexpr int kGvKX = (kGvTT + 4 + kGvNT - 1) / kGvNT; // per-thread frames incl. halo
 
 struct GvScal {

@@ -266,23 +266,39 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
     const uint64_t f = base + fr;
     const uint64_t n0 = (uint64_t)fr * (uint64_t)fp; // first sample of the frame in the utterance
     __shared__ double ec_s[4][kExw][kExwQ]; // this frame's e, zero in the history part
-    __shared__ double ep_s[4][kExw][kExwHalo / kExw]; // previous frame's last 32 e
+    __shared__ double ep_s[4][2 * kExwHalo]; // previous frame's last 32 e, then 32 zeros (linear)
+    __shared__ double xs_s[4][kExwHalo];     // first 32 outputs, turned sample-per-lane for pass 2
     __shared__ double nz_s[4][kExw][kExwQ]; // noise[n0 - 32 ..]
     double(*ec)[kExwQ] = ec_s[wv];
-    double(*ep)[kExwHalo / kExw] = ep_s[wv];
+    double *ep = ep_s[wv];
+    double *xs = xs_s[wv];
     double(*nz)[kExwQ] = nz_s[wv];
     // NOISE_ONLY: every sample as if no pulse fell into its window (e = -noise in voiced frames);
     // needs the MSD voiced flags only, not the pitch track.  k_excite_fix repairs the rest.
     const bool vcur = NOISE_ONLY ? vd.voiced[f] != 0 : vd.pitch[f] != 0.0;
     const bool vprev = fr > 0 && (NOISE_ONLY ? vd.voiced[f - 1] != 0 : vd.pitch[f - 1] != 0.0);
     // ---- stage noise and e for samples m = -32 .. fp-1 of this frame ----
-    for (int idx = lane; idx < fp + kExwHalo; idx += 64) {
+    // (all noise loads of the wave are issued before the first one is consumed: the wave is
+    // latency-bound otherwise, one memory round trip per 64 samples)
+    constexpr int kIt = (256 + kExwHalo + 63) / 64;
+    double nvr[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; it++) {
+        const int idx = lane + 64 * it;
+        const long g = (long)n0 + idx - kExwHalo;
+        nvr[it] = (idx < fp + kExwHalo && g >= 0) ? vd.noise[g] : 0.0;
+    }
+#pragma unroll
+    for (int it = 0; it < kIt; it++) {
+        const int idx = lane + 64 * it;
+        if (idx >= fp + kExwHalo)
+            break;
         const int m = idx - kExwHalo;
         const int row = idx & (kExw - 1), q = idx >> 2;
         const long g = (long)n0 + m; // sample index in the utterance
-        double nv = 0.0, ev = 0.0;
+        const double nv = nvr[it];
+        double ev = 0.0;
         if (g >= 0) {
-            nv = vd.noise[g];
             const bool cur = m >= 0;
             if (cur ? vcur : vprev) {
                 const uint64_t ff = cur ? f : f - 1;
@@ -301,9 +317,11 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
             ec[row][q] = ev;
         else {
             ec[row][q] = 0.0;
-            ep[row][q] = ev;
+            ep[idx] = ev;
         }
     }
+    if (lane < kExwHalo)
+        ep[kExwHalo + lane] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -336,24 +354,35 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
                 x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
         }
     }
-    if (vprev && i0 < kExwHalo) {
+    if (vprev) {
+        // pass 2: sources in the previous frame (taps k > i), previous frame's taps.  Only the first
+        // NLPF-1 samples have any; they are turned to one sample per lane through LDS so that the
+        // pass costs NLPF-1 FMAs per wave instead of 4*(NLPF-1) on eight busy lanes.  ep[] continues
+        // with zeros where this frame starts: x + 0*c == x, the order of the remaining terms is the
+        // tap order.
         const double *tp = tc - nlpf;
-        double ck[NLPF];
-#pragma unroll
-        for (int k = 1; k < NLPF; k++)
-            ck[k] = tp[k];
-        double w[kExwWin]; // previous frame's e at i0 - (NLPF-1) + c (zero from this frame's start on)
-#pragma unroll
-        for (int c = 0; c < kExwWin; c++) {
-            const int o = c + kExwHalo - (NLPF - 1);
-            const int q = lane + (o >> 2);
-            w[c] = q < kExwHalo / kExw ? ep[o & (kExw - 1)][q] : 0.0;
-        }
-#pragma unroll
-        for (int k = 1; k < NLPF; k++) {
+        if (i0 < kExwHalo) {
 #pragma unroll
             for (int r = 0; r < kExw; r++)
-                x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
+                xs[i0 + r] = x[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < NLPF - 1) {
+            double xv = xs[lane];
+#pragma unroll
+            for (int k = 1; k < NLPF; k++)
+                xv = fma(ep[lane - k + kExwHalo], tp[k], xv);
+            xs[lane] = xv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (i0 < kExwHalo) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                x[r] = xs[i0 + r];
         }
     }
     const uint64_t o = base * (uint64_t)fp + n0 + (uint64_t)i0;

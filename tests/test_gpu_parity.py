@@ -114,7 +114,7 @@ def test_fused_mlpg_equals_generic_bitwise(oracle_voice, have_gpu):
 
 
 def test_time_parallel_gv_is_deterministic_and_tiled(oracle_voice, have_gpu):
-    """The time-parallel GV sweeps: several tiles per utterance (T > 1024 frames), ragged
+    """The time-parallel GV sweeps: several tiles per utterance (T > 2048 frames for the second one), ragged
     last tile, two utterances of different length in one batch; run-to-run identical bits and
     within 1e-12 of the serial-order kernel."""
     v = oracle_voice
