@@ -107,6 +107,10 @@ typedef struct jb_batch_opts {
 #define JB_BATCH_SERIAL 4u       /* one wave per utterance, no time-chunking (reference-shaped recursion) */
 #define JB_BATCH_WAVE_KERNEL 8u  /* always the wave-per-chunk vocoder kernel (A/B tests) */
 #define JB_BATCH_PAIR_KERNEL 16u /* always the lane-pair throughput kernel (A/B tests) */
+#define JB_BATCH_PCM_I16 64u     /* fused 16-bit sink: the vocoder writes clamped i16 PCM (value.min(32767).max(-32768)
+                                    as i16, examples/is-bonsai/main.rs:44-48) instead of f64: 2 B/sample leave
+                                    the GPU instead of 8.  jb_batch_read_pcm / device_pcm then fail; use the
+                                    _i16 forms */
 #define JB_BATCH_SERIAL_GV 32u   /* GV sums in the reference's serial order: parameter tracks bit-exact
                                     against src/mlpg_adjust/mlpg.rs:145-292, slower.  The default runs the
                                     GV sweeps time-parallel with fixed-shape tree reductions (deterministic;
@@ -142,12 +146,16 @@ size_t jb_batch_num_samples(const jb_batch *b, size_t utt);
 size_t jb_batch_total_samples(const jb_batch *b);
 /* Copy utterance `utt`'s PCM (f64, un-clipped, as Vec<f64> of src/engine.rs:294). */
 int jb_batch_read_pcm(jb_batch *b, size_t utt, double *dst, size_t cap);
+/* Same for a batch created with JB_BATCH_PCM_I16 (16-bit PCM as written to WAV by the reference's
+ * examples, examples/is-bonsai/main.rs:37-49). */
+int jb_batch_read_pcm_i16(jb_batch *b, size_t utt, int16_t *dst, size_t cap);
 /* Parameter track of stream s ([T][L], NODATA in unvoiced frames); needs KEEP_TRACKS. */
 int jb_batch_read_track(jb_batch *b, size_t utt, uint32_t stream, double *dst, size_t cap);
 /* Debug/parity taps: excitation before gain [N]; needs KEEP_TRACKS. */
 int jb_batch_read_excitation(jb_batch *b, size_t utt, double *dst, size_t cap);
-/* Device pointer + byte size of the batch's contiguous PCM slab (for an RCCL gather
- * by the caller); utterance i starts at sample jb_batch_pcm_offset(b,i). */
+/* Device pointer + sample count of the batch's contiguous PCM slab (for an RCCL gather
+ * by the caller); utterance i starts at sample jb_batch_pcm_offset(b,i).  f64 samples, or
+ * i16 for a JB_BATCH_PCM_I16 batch. */
 void *jb_batch_device_pcm(jb_batch *b, size_t *n_samples);
 size_t jb_batch_pcm_offset(const jb_batch *b, size_t utt);
 /* Execution facts of the last run: chunk length / warm-up actually used, number of

@@ -98,7 +98,7 @@ class Batch:
     def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
                  keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
-                 kernel: str = "auto", serial_gv: bool = False):
+                 kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False):
         L = F.lib()
         self._L = L
         self.voice = voice
@@ -111,6 +111,7 @@ class Batch:
         opts.device = device
         opts.flags = ((F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
                       | (F.BATCH_SERIAL if serial else 0) | (F.BATCH_SERIAL_GV if serial_gv else 0)
+                      | (F.BATCH_PCM_I16 if pcm_i16 else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "pair": F.BATCH_PAIR_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
         h = C.c_void_p()
@@ -158,6 +159,13 @@ class Batch:
         n = self.num_samples(i)
         out = np.empty(n, dtype=np.float64)
         F.check(self._L.jb_batch_read_pcm(self._h, i, out.ctypes.data, n))
+        return out
+
+    def pcm_i16(self, i) -> np.ndarray:
+        """16-bit PCM of a batch created with pcm_i16=True (fused clamp + truncate sink)."""
+        n = self.num_samples(i)
+        out = np.empty(n, dtype=np.int16)
+        F.check(self._L.jb_batch_read_pcm_i16(self._h, i, out.ctypes.data, n))
         return out
 
     def track(self, i, stream) -> np.ndarray:

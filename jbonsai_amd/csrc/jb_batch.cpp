@@ -474,8 +474,13 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         (rc = b->dalloc(&vd.pitch, nf, false)) || (rc = b->dalloc(&vd.cur_start, nf, false)) ||
         (rc = b->dalloc(&vd.pinc, nf, false)) || (rc = b->dalloc(&vd.counter_start, nf, false)) ||
         (rc = b->dalloc(&vd.pmask, nf * (size_t)vd.nblk, false)) ||
-        (rc = b->dalloc(&vd.pcm, b->total_samples, false)) ||
         (rc = b->dalloc(&vd.xin, b->total_samples, false)))
+        return rc;
+    if (b->flags & JB_BATCH_PCM_I16)
+        rc = b->dalloc(&vd.pcm16, b->total_samples, false);
+    else
+        rc = b->dalloc(&vd.pcm, b->total_samples, false);
+    if (rc)
         return rc;
     if (vd.nlpf - 1 > 64) {
         set_error("nlpf > 65 is not supported");
@@ -884,7 +889,7 @@ void *jb_batch_device_pcm(jb_batch *hb, size_t *n)
         return nullptr;
     if (n)
         *n = b->total_samples;
-    return b->vd.pcm;
+    return b->vd.pcm ? (void *)b->vd.pcm : (void *)b->vd.pcm16; // i16 slab for JB_BATCH_PCM_I16 batches
 }
 
 int jb_batch_read_pcm(jb_batch *hb, size_t i, double *dst, size_t cap)
@@ -901,7 +906,32 @@ int jb_batch_read_pcm(jb_batch *hb, size_t i, double *dst, size_t cap)
         return JB_OK;
     if (!dst)
         return JB_ERR_INVALID;
+    if (!b->vd.pcm) {
+        jb::set_error("batch was created with JB_BATCH_PCM_I16: use jb_batch_read_pcm_i16");
+        return JB_ERR_INVALID;
+    }
     return b->read(b->vd.pcm + (size_t)b->frame_off[i] * b->voice.fperiod, dst, ns * sizeof(double));
+}
+
+int jb_batch_read_pcm_i16(jb_batch *hb, size_t i, int16_t *dst, size_t cap)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || i >= (size_t)b->B)
+        return JB_ERR_INVALID;
+    if (!b->vd.pcm16) {
+        jb::set_error("batch was created without JB_BATCH_PCM_I16");
+        return JB_ERR_INVALID;
+    }
+    size_t ns = (size_t)b->T[i] * b->voice.fperiod;
+    if (cap < ns) {
+        jb::set_error("pcm buffer too small");
+        return JB_ERR_BUFFER;
+    }
+    if (ns == 0)
+        return JB_OK;
+    if (!dst)
+        return JB_ERR_INVALID;
+    return b->read(b->vd.pcm16 + (size_t)b->frame_off[i] * b->voice.fperiod, dst, ns * sizeof(int16_t));
 }
 
 int jb_batch_read_track(jb_batch *hb, size_t i, uint32_t si, double *dst, size_t cap)

@@ -103,7 +103,8 @@ struct VocDev {
     const double *noise;  // [noise_len] shared Gaussian stream
     uint64_t noise_len;
     double *xin;          // [sumT*fperiod] excitation after the LPF mix and gain (k_excite)
-    double *pcm;          // [sumT*fperiod]
+    double *pcm;          // [sumT*fperiod] f64 PCM, or nullptr when the i16 sink is selected
+    int16_t *pcm16;       // [sumT*fperiod] clamped i16 PCM (JB_BATCH_PCM_I16), or nullptr
     double *exc;          // optional [sumT*fperiod] excitation before gain, or nullptr
     double *state;        // optional per-utterance filter state (streaming), or nullptr
     int state_stride;     // doubles per utterance

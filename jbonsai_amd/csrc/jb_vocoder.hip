@@ -508,6 +508,19 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
     return __hiloint2double(hi, lo);
 }
 
+// PCM sink of the reference's callers (examples/is-bonsai/main.rs:44-48, hound 16-bit WAV):
+// value.min(i16::MAX).max(i16::MIN) as i16 -- clamp, then truncate toward zero.
+__device__ __forceinline__ int pcm_i16(double v)
+{
+    v = fmin(v, 32767.0);
+    v = fmax(v, -32768.0);
+    return (int)v;
+}
+__device__ __forceinline__ uint32_t pcm_i16x2(double a, double b)
+{
+    return ((uint32_t)pcm_i16(a) & 0xffffu) | ((uint32_t)pcm_i16(b) << 16);
+}
+
 struct ScanCoef {
     double c1, c2, c4, c8, cb;
 };
@@ -721,8 +734,12 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
                 c1 += c1inc;
                 ob = (lane == i) ? x * vol : ob;
             }
-            if (lane < bs && emit)
-                vd.pcm[base * (uint64_t)fp + n0 + (uint64_t)lane] = ob;
+            if (lane < bs && emit) {
+                if (vd.pcm16)
+                    vd.pcm16[base * (uint64_t)fp + n0 + (uint64_t)lane] = (int16_t)pcm_i16(ob);
+                else
+                    vd.pcm[base * (uint64_t)fp + n0 + (uint64_t)lane] = ob;
+            }
         }
         (void)ctgt;
     }
@@ -971,10 +988,18 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
                     o0 = pv;
                 if (ph == (isA ? 1 : 3))
                     o1 = pv;
-                if (ph == 3 && emit)
-                    *reinterpret_cast<double2 *>(op + (i - 3) + (isA ? 0 : 2)) = make_double2(o0, o1);
+                if (ph == 3 && emit) {
+                    if (vd.pcm16)
+                        *reinterpret_cast<uint32_t *>(vd.pcm16 + (base + t) * (uint64_t)fp + (i - 3) +
+                                                      (isA ? 0 : 2)) = pcm_i16x2(o0, o1);
+                    else
+                        *reinterpret_cast<double2 *>(op + (i - 3) + (isA ? 0 : 2)) = make_double2(o0, o1);
+                }
             } else if (emit && isA) {
-                op[i] = pv;
+                if (vd.pcm16)
+                    vd.pcm16[(base + t) * (uint64_t)fp + i] = (int16_t)pcm_i16(pv);
+                else
+                    op[i] = pv;
             }
         }
         if (act && tl + 1 == nfr) {
@@ -1239,11 +1264,19 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 else if (ph == 2)
                     o2 = pv;
                 else if (emit) {
-                    *reinterpret_cast<double2 *>(op + (i - 3)) = make_double2(o0, o1);
-                    *reinterpret_cast<double2 *>(op + (i - 1)) = make_double2(o2, pv);
+                    if (vd.pcm16) {
+                        *reinterpret_cast<uint2 *>(vd.pcm16 + (base + t) * (uint64_t)fp + (i - 3)) =
+                            make_uint2(pcm_i16x2(o0, o1), pcm_i16x2(o2, pv));
+                    } else {
+                        *reinterpret_cast<double2 *>(op + (i - 3)) = make_double2(o0, o1);
+                        *reinterpret_cast<double2 *>(op + (i - 1)) = make_double2(o2, pv);
+                    }
                 }
             } else if (emit) {
-                op[i] = pv;
+                if (vd.pcm16)
+                    vd.pcm16[(base + t) * (uint64_t)fp + i] = (int16_t)pcm_i16(pv);
+                else
+                    op[i] = pv;
             }
         }
         if (act && tl + 1 == nfr) {

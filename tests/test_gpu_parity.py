@@ -203,3 +203,28 @@ def test_pair_kernel_equals_wave_kernel_and_oracle(oracle_voice, have_gpu):
     assert info2["n_redo"] >= 6
     for i in range(3):
         assert rel_rms(redo[i], ser[i]) <= 1e-12, i
+
+
+def test_i16_sink_equals_clamped_cast_of_f64(oracle_voice, have_gpu):
+    """Fused 16-bit sink (examples/is-bonsai/main.rs:44-48: min/max clamp, `as i16`):
+    every vocoder kernel must write exactly clip(f64).astype(int16) of its own f64 output, with a
+    volume that makes the clamp bite."""
+    v = oracle_voice
+    d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
+    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+    utts = [to_utt(d2, s2), to_utt(d1, s1)] * 4
+    for kw in (dict(serial=True), dict(chunk_frames=64, kernel="wave"), dict(chunk_frames=64, kernel="pair"),
+               dict(chunk_frames=64)):
+        res = []
+        for i16 in (False, True):
+            with J.Batch(voice_info(v, volume=9.0), utts, pcm_i16=i16, **kw) as b:
+                b.run()
+                b.sync()
+                res.append([b.pcm_i16(i) if i16 else b.pcm(i) for i in range(len(utts))])
+                if i16:
+                    with pytest.raises(J.JbError):
+                        b.pcm(0)
+        for f, q in zip(*res):
+            want = np.clip(f, -32768.0, 32767.0).astype(np.int16)  # astype truncates toward zero
+            assert q.dtype == np.int16 and np.array_equal(q, want)
+            assert (np.abs(f) > 32768).any() and (want == 32767).any() and (want == -32768).any()
