@@ -20,6 +20,7 @@
 #include "jb_device.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace jb {
 
@@ -1102,6 +1103,240 @@ __global__ __launch_bounds__(64) void k_mlpg_fb_mt(BatchDev bd, StreamDev sd, in
 }
 
 // --------------------------------------------------------------------------
+// A5/A6 again, LDS-STAGED: k_mlpg_fb_mt's per-lane row streams are bound by the texture
+// addresser (an uncoalesced wave access costs ~150 cycles whatever its width), not by latency.
+// Here one block owns an utterance: wave 0 is the SOLVER (lane = dim, the same recurrences in the
+// same order, operands and results in LDS as [frame][dim] tiles, so its accesses are
+// conflict-free), waves 1-3 are MOVERS that stream the [dim][frame] rows between HBM and LDS with
+// coalesced accesses (16 consecutive frames of a row = 128 B per 16 lanes).  Chunks of kFlCT
+// frames, one __syncthreads per chunk: while the solver works on chunk p, the movers fetch chunk
+// p+2 into registers, drain the results of chunk p-1 from LDS to HBM, then park chunk p+2 in its
+// LDS slot.  Three input slots, two output slots.  The solver is then bound by its dependency
+// chain (two f64 divisions per frame in the factorisation) and the kernel as a whole by HBM.
+constexpr int kFlCT = 16;  // frames per chunk
+constexpr int kFlIn = 3;   // input slots (chunk p being solved, p+1 parked, p+2 arriving)
+constexpr int kFlOut = 2;  // output slots (chunk p being written, p-1 draining)
+constexpr int kFlNT = 256; // threads per block
+constexpr int kFlMovers = kFlNT - 64;
+
+// One pass (NIN input arrays, NOUT output arrays).  lo(c) = first frame of chunk c (may be
+// negative / the chunk may run past n: those frames are skipped); the solver visits the frames of
+// a chunk ascending (forward) or descending (backward).  LMAX bounds the vector length, so that
+// the movers' per-thread element lists are as short as the stream allows (1 for LF0, 12 for MCP).
+template <int LMAX, int NIN, int NOUT, bool BACKWARD, class Step>
+__device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[NIN], double *const (&out)[NOUT],
+                                        uint32_t n, int L, uint64_t rs, Step step)
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool solver = tid < 64;
+    const int mt = tid - 64;
+    const int LP = L;
+    const int nch = (int)((n + kFlCT - 1) / kFlCT);
+    double *inb = lds;                                // [kFlIn][NIN][kFlCT][LP]
+    double *outb = lds + kFlIn * 4 * kFlCT * LP;      // [kFlOut][NOUT][kFlCT][LP]
+    auto lo = [&](int c) { return BACKWARD ? (long)n - (long)(c + 1) * kFlCT : (long)c * kFlCT; };
+    // mover element list, fixed per thread for the whole pass: element e = mt + 192k ->
+    // (array a, dim m, frame-in-chunk tt); the same decomposition serves inputs (e < NIN*L*CT)
+    // and outputs (e < NOUT*L*CT).  Pointers to frame tt of the row are formed once.
+    constexpr int KI = (NIN * LMAX * kFlCT + kFlMovers - 1) / kFlMovers;
+    constexpr int KO = (NOUT * LMAX * kFlCT + kFlMovers - 1) / kFlMovers;
+    const int nei = NIN * L * kFlCT, neo = NOUT * L * kFlCT;
+    const double *pin[KI];
+    double *pout[KO];
+    uint32_t e_l[KI], e_tt[KI];
+    if (!solver) {
+#pragma unroll
+        for (int k = 0; k < KI; k++) {
+            const int e = mt + kFlMovers * k;
+            const int tt = e % kFlCT, am = e / kFlCT, m = am % L, a = am / L;
+            e_l[k] = (uint32_t)((a * kFlCT + tt) * LP + m);
+            e_tt[k] = (uint32_t)tt;
+            const double *src = in[0];
+#pragma unroll
+            for (int q = 1; q < NIN; q++)
+                src = a == q ? in[q] : src;
+            pin[k] = src + (uint64_t)m * rs + (uint64_t)tt;
+            if (k < KO) {
+                double *dst = out[0];
+#pragma unroll
+                for (int q = 1; q < NOUT; q++)
+                    dst = a == q ? out[q] : dst;
+                pout[k] = dst + (uint64_t)m * rs + (uint64_t)tt;
+            }
+        }
+    }
+    double regs[KI];
+#pragma unroll
+    for (int k = 0; k < KI; k++)
+        regs[k] = 0.0;
+    // Phase p: the solver works on chunk p.  A mover (1) parks chunk p+2 -- loaded during the
+    // previous phase, so its latency is already paid -- in its LDS slot, (2) issues the loads of
+    // chunk p+3 into the same registers, (3) drains the results of chunk p-1 to HBM.  The phase
+    // barrier is a raw s_barrier behind lgkmcnt(0) only: __syncthreads() would also wait for the
+    // stores of (3) (vmcnt(0)) and with them for the loads of (2).
+    for (int p = -3; p <= nch; p++) {
+        if (!solver) {
+            const int cw = p + 2;
+            if (cw >= 0 && cw < nch) {
+                double *ib = inb + (cw % kFlIn) * NIN * kFlCT * LP;
+#pragma unroll
+                for (int k = 0; k < KI; k++)
+                    if (mt + kFlMovers * k < nei)
+                        ib[e_l[k]] = regs[k];
+            }
+            const int cl = p + 3;
+            if (cl < nch) {
+                const long l0 = lo(cl);
+                if (l0 >= 0 && l0 + kFlCT <= (long)n) { // interior chunk: no per-frame checks
+#pragma unroll
+                    for (int k = 0; k < KI; k++)
+                        if (mt + kFlMovers * k < nei)
+                            regs[k] = pin[k][l0];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KI; k++) {
+                        const long t = l0 + (long)e_tt[k];
+                        regs[k] = (mt + kFlMovers * k < nei && t >= 0 && t < (long)n) ? pin[k][l0] : 0.0;
+                    }
+                }
+            }
+            const int cs = p - 1;
+            if (cs >= 0 && cs < nch) {
+                const long l0 = lo(cs);
+                const double *ob = outb + (cs % kFlOut) * NOUT * kFlCT * LP;
+                if (l0 >= 0 && l0 + kFlCT <= (long)n) {
+#pragma unroll
+                    for (int k = 0; k < KO; k++)
+                        if (mt + kFlMovers * k < neo)
+                            pout[k][l0] = ob[e_l[k]];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < KO; k++) {
+                        const long t = l0 + (long)e_tt[k];
+                        if (mt + kFlMovers * k < neo && t >= 0 && t < (long)n)
+                            pout[k][l0] = ob[e_l[k]];
+                    }
+                }
+            }
+        } else if (p >= 0 && p < nch && lane < L) {
+            const long l0 = lo(p);
+            const double *ib = inb + (p % kFlIn) * NIN * kFlCT * LP;
+            double *ob = outb + (p % kFlOut) * NOUT * kFlCT * LP;
+            // the chunk's operands come out of LDS first: the compiler cannot tell the input
+            // tiles from the output tiles, so reads interleaved with the result writes would each
+            // wait out a full LDS round trip inside the dependency chain
+            double ivs[kFlCT][NIN];
+#pragma unroll
+            for (int u = 0; u < kFlCT; u++) {
+                const int tt = BACKWARD ? kFlCT - 1 - u : u;
+#pragma unroll
+                for (int a = 0; a < NIN; a++)
+                    ivs[u][a] = ib[(a * kFlCT + tt) * LP + lane];
+            }
+            if (l0 >= 2 && l0 + kFlCT + 2 <= (long)n) {
+                // interior chunk: every frame exists and has both neighbours on either side, so
+                // the recurrences run without their edge guards (same operations, same order)
+#pragma unroll
+                for (int u = 0; u < kFlCT; u++) {
+                    const int tt = BACKWARD ? kFlCT - 1 - u : u;
+                    double ov[NOUT];
+                    step(std::true_type{}, (uint32_t)(l0 + tt), ivs[u], ov);
+#pragma unroll
+                    for (int a = 0; a < NOUT; a++)
+                        ob[(a * kFlCT + tt) * LP + lane] = ov[a];
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < kFlCT; u++) {
+                    const int tt = BACKWARD ? kFlCT - 1 - u : u;
+                    const long t = l0 + tt;
+                    if (t >= 0 && t < (long)n) {
+                        double ov[NOUT];
+                        step(std::false_type{}, (uint32_t)t, ivs[u], ov);
+#pragma unroll
+                        for (int a = 0; a < NOUT; a++)
+                            ob[(a * kFlCT + tt) * LP + lane] = ov[a];
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+template <int LMAX>
+__global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd, int si)
+{
+    extern __shared__ double lds[];
+    const int b = blockIdx.x;
+    const UttDev *up = bd.utt + b;
+    const uint32_t n = sd.Tv[b];
+    if (n == 0)
+        return;
+    const int L = sd.L;
+    const uint64_t row0 = up->frame_off * (uint64_t)L;
+    const uint64_t rs = up->T; // row stride of the [dim][frame] workspace
+    // ---- pass F: ldl_factorization + forward substitution (mlpg.rs:79-105) ----
+    {
+        const double *const in[4] = {sd.A[0] + row0, sd.A[1] + row0, sd.A[2] + row0, sd.bvec + row0};
+        double *const out[4] = {sd.F[0] + row0, sd.F[1] + row0, sd.F[2] + row0, sd.g + row0};
+        double p1_0 = 0, p1_1 = 0, p1_2 = 0, p2_0 = 0, p2_2 = 0, g1 = 0, g2 = 0;
+        fl_pass<LMAX, 4, 4, false>(lds, in, out, n, L, rs,
+                                   [&](auto interior, uint32_t t, const double (&iv)[4], double (&ov)[4]) {
+            constexpr bool IN = decltype(interior)::value;
+            double r0 = iv[0], r1 = iv[1], r2 = iv[2], g = iv[3];
+            if (IN || t >= 1)
+                r0 -= p1_1 * p1_1 * p1_0;
+            if (IN || t >= 2)
+                r0 -= p2_2 * p2_2 * p2_0;
+            if (IN || t >= 1)
+                r1 -= p1_1 * p1_2 * p1_0;
+            r1 /= r0;
+            r2 /= r0;
+            if (IN || t >= 1)
+                g -= p1_1 * g1;
+            if (IN || t >= 2)
+                g -= p2_2 * g2;
+            ov[0] = r0;
+            ov[1] = r1;
+            ov[2] = r2;
+            ov[3] = g;
+            p2_0 = p1_0;
+            p2_2 = p1_2;
+            g2 = g1;
+            p1_0 = r0;
+            p1_1 = r1;
+            p1_2 = r2;
+            g1 = g;
+        });
+    }
+    // the factors were stored by the mover waves; the backward pass reads them back through the
+    // same waves in the opposite order
+    __threadfence();
+    __syncthreads();
+    // ---- pass B: backward substitution (mlpg.rs:106-113), t descending ----
+    {
+        const double *const in[4] = {sd.F[0] + row0, sd.F[1] + row0, sd.F[2] + row0, sd.g + row0};
+        double *const out[1] = {sd.par + row0};
+        double q1 = 0, q2 = 0;
+        fl_pass<LMAX, 4, 1, true>(lds, in, out, n, L, rs,
+                                  [&](auto interior, uint32_t t, const double (&iv)[4], double (&ov)[1]) {
+            constexpr bool IN = decltype(interior)::value;
+            double p = iv[3] / iv[0];
+            if (IN || t + 1 < n)
+                p -= iv[1] * q1;
+            if (IN || t + 2 < n)
+                p -= iv[2] * q2;
+            ov[0] = p;
+            q2 = q1;
+            q1 = p;
+        });
+    }
+}
+
+// --------------------------------------------------------------------------
 // A8 GV ascent with LANES OVER TIME (mlpg.rs:145-292).  The 13 sweeps of conv_gv and the
 // five parmgen iterations are elementwise in t plus reductions; only the ORDER of the
 // additions is serial.  One wave per (utterance, dim): 64 frames per vector instruction for
@@ -1644,6 +1879,36 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
     return hipGetLastError();
 }
 
+// F/B sweeps of the [dim][frame] workspace: LDS-staged block per utterance, or lane-per-row
+template <int LMAX>
+static void launch_fb_lds(const BatchDev &bd, const StreamDev &sd, int si, size_t lds, hipStream_t stream)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_mlpg_fb_lds<LMAX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_mlpg_fb_lds<LMAX>, dim3(bd.B), dim3(kFlNT), lds, stream, bd, sd, si);
+}
+
+static void launch_fb(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
+{
+    static const bool use_lds = !(getenv("JB_FB_LDS") && atoi(getenv("JB_FB_LDS")) == 0);
+    const size_t lds = sizeof(double) * (size_t)(kFlIn * 4 + kFlOut * 4) * kFlCT * (size_t)sd.L;
+    if (use_lds && sd.L <= 64 && lds <= 160 * 1024) {
+        if (sd.L == 1)
+            launch_fb_lds<1>(bd, sd, si, lds, stream);
+        else if (sd.L <= 36)
+            launch_fb_lds<36>(bd, sd, si, lds, stream);
+        else
+            launch_fb_lds<64>(bd, sd, si, lds, stream);
+    } else {
+        dim3 grid((sd.L + 63) / 64, bd.B), block(64);
+        hipLaunchKernelGGL(k_mlpg_fb_mt, grid, block, 0, stream, bd, sd, si);
+    }
+}
+
 template <int BW>
 static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
                                  hipEvent_t after_build)
@@ -1669,12 +1934,12 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
         const bool tp = sd.use_gv && !sd.serial_gv && sd.gv_part;
         if (sd.is_msd) {
             if (tp)
-                hipLaunchKernelGGL(k_mlpg_fb_mt, grid, block, 0, stream, bd, sd, si);
+                launch_fb(bd, sd, si, stream);
             else
                 hipLaunchKernelGGL((k_mlpg_solve3<false, true, true>), grid, block, 0, stream, bd, sd, si);
         } else {
             if (tp)
-                hipLaunchKernelGGL(k_mlpg_fb_mt, grid, block, 0, stream, bd, sd, si);
+                launch_fb(bd, sd, si, stream);
             else
                 hipLaunchKernelGGL((k_mlpg_solve3<true, true, true>), grid, block, 0, stream, bd, sd, si);
         }
@@ -1710,7 +1975,11 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             dim3 gvgrid(sd.L, bd.B);
             if (sd.is_msd) {
                 if (gv_vt) {
-                    hipLaunchKernelGGL((k_mlpg_solve3<false, false>), grid, block, 0, stream, bd, sd, si);
+                    // L == 1: [frame][1] is [1][frame]; the LDS-staged sweeps run the same arithmetic
+                    if (sd.L == 1)
+                        launch_fb(bd, sd, si, stream);
+                    else
+                        hipLaunchKernelGGL((k_mlpg_solve3<false, false>), grid, block, 0, stream, bd, sd, si);
                     hipLaunchKernelGGL(k_mlpg_gv_vt<false>, gvgrid, block, 0, stream, bd, sd, si);
                 } else {
                     hipLaunchKernelGGL((k_mlpg_solve3<false, true>), grid, block, 0, stream, bd, sd, si);

@@ -400,26 +400,32 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
 // order -- the same chain of FMAs as k_excite_w4's two passes, so the two kernels together are
 // bit-identical to the one-pass form.  Samples covered by two pulses are written twice with the
 // same value.
+constexpr int kFixFrames = 8;
+
 template <int NLPF>
 __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
 {
     const int b = blockIdx.y;
     const UttDev *u = bd.utt + b;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)wv));
     const uint32_t T = u->T;
-    if (fr >= T)
-        return;
     const uint64_t base = u->frame_off;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+    // a wave walks kFixFrames frames (most leave at once): 8x fewer workgroups for the dispatcher,
+    // which otherwise spends the launch slots of concurrently running kernels on empty blocks
+    for (int jf = 0; jf < kFixFrames; jf++) {
+    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
+    if (fr >= T)
+        break;
     const uint64_t f = base + fr;
     if (!vd.voiced[f])
-        return;
-    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+        continue;
     unsigned long long any = 0ull;
     for (int q = 0; q < nblk; q++)
         any |= vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
     if (any == 0ull)
-        return;
+        continue;
     constexpr int H = NLPF - 1;
     static_assert(2 * H + 1 <= 64, "window must fit one wave");
     const int anti = H / 2;
@@ -486,6 +492,7 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             }
         }
     }
+    } // frames of this wave
 }
 
 // --------------------------------------------------------------------------
@@ -1385,10 +1392,11 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
     if (excite_w4_ok(vd)) {
         dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
         if (excite_is_split(vd)) {
+            dim3 gfix((bd.maxT + 4 * kFixFrames - 1) / (4 * kFixFrames), bd.B);
             if (vd.nlpf == 31)
-                hipLaunchKernelGGL(k_excite_fix<31>, grid, block, 0, stream, bd, vd);
+                hipLaunchKernelGGL(k_excite_fix<31>, gfix, block, 0, stream, bd, vd);
             else
-                hipLaunchKernelGGL(k_excite_fix<15>, grid, block, 0, stream, bd, vd);
+                hipLaunchKernelGGL(k_excite_fix<15>, gfix, block, 0, stream, bd, vd);
         } else if (vd.nlpf == 31)
             hipLaunchKernelGGL((k_excite_w4<31, false>), grid, block, 0, stream, bd, vd);
         else
