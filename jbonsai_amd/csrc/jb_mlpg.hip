@@ -1278,6 +1278,13 @@ __global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd
     const int L = sd.L;
     const uint64_t row0 = up->frame_off * (uint64_t)L;
     const uint64_t rs = up->T; // row stride of the [dim][frame] workspace
+    // The solver's dependent chain is the critical path of the kernel (and of the step): it gets
+    // the highest issue priority on its SIMD, the movers the next one, so that throughput kernels
+    // sharing the CU (the excitation pass runs concurrently) fill the gaps instead of taking turns.
+    if (threadIdx.x < 64)
+        __builtin_amdgcn_s_setprio(3);
+    else
+        __builtin_amdgcn_s_setprio(2);
     // ---- pass F: ldl_factorization + forward substitution (mlpg.rs:79-105) ----
     {
         const double *const in[4] = {sd.A[0] + row0, sd.A[1] + row0, sd.A[2] + row0, sd.bvec + row0};
@@ -1361,7 +1368,42 @@ __device__ __forceinline__ double serial_add64(double acc, double v)
 
 // Loads of kVtNB blocks of 64 frames are issued together before their serial sums run, so a
 // lone wave pays one memory latency per 256 frames instead of one per 64.
-constexpr int kVtNB = 4;
+#ifndef JB_VT_NB
+#define JB_VT_NB 4
+#endif
+constexpr int kVtNB = JB_VT_NB;
+
+// In-order sum of one value per lane, acc += v[lane 0]; acc += v[lane 1]; ... -- through LDS:
+// the wave parks the values and every lane reads them back in order with broadcast
+// ds_read_b128 (two values per read), so the chain is one dependent v_add_f64 per frame
+// (~2.7 ns) instead of two v_readlane + add with their SGPR hazards (~30 ns).
+__device__ __forceinline__ double serial_add_lds(double acc, const double *buf)
+{
+    // reads run one group of 8 (16 summands) ahead of the adds; the scheduling barriers keep
+    // hipcc from sinking them next to their use (it otherwise keeps ~2 reads in flight and the
+    // chain waits out most of every LDS round trip)
+    const double2 *b2 = reinterpret_cast<const double2 *>(buf);
+    double2 x[2][8];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+        x[0][u] = b2[u];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (g < 3) {
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                x[(g + 1) & 1][u] = b2[8 * (g + 1) + u];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            acc += x[g & 1][u].x;
+            acc += x[g & 1][u].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return acc;
+}
 
 template <bool NONMSD>
 __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, int si)
@@ -1373,10 +1415,12 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
     const uint32_t gvl = sd.gvlen[b];
     if (n == 0 || !(sd.use_gv && st.gv_mean && gvl > 0))
         return;
+    __builtin_amdgcn_s_setprio(3); // latency chain: do not take turns with throughput waves
     const int L = sd.L;
     const uint64_t base = up->frame_off;
     const uint64_t o0 = base * (uint64_t)L + (uint64_t)m, Ls = (uint64_t)L;
 #define IX(k) (o0 + (uint64_t)(k) * Ls)
+    __shared__ __attribute__((aligned(16))) double sbuf[2][kVtNB][64]; // parked summands (one wave per block)
     const uint8_t *sw = sd.vsw + base;
     const double *A0 = sd.A[0], *A1 = sd.A[1], *A2 = sd.A[2], *Bv = sd.bvec;
     double *Gv = sd.g, *Pv = sd.par, *Ov = sd.out;
@@ -1394,10 +1438,15 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
             const uint32_t t = tb + 64u * q + (uint32_t)lane;
             v[q] = (t < n && sw[t]) ? Pv[IX(t)] : 0.0;
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++)
+            sbuf[0][q][lane] = v[q];
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < kVtNB; q++)
             if (tb + 64u * q < n)
-                ssum = serial_add64(ssum, v[q]);
+                ssum = serial_add_lds(ssum, sbuf[0][q]);
     }
     double mean = ssum / glen;
     double vsum = 0.0;
@@ -1410,10 +1459,15 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
             const double p = on ? Pv[IX(t)] : mean;
             v[q] = on ? (p - mean) * (p - mean) : 0.0;
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++)
+            sbuf[0][q][lane] = v[q];
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < kVtNB; q++)
             if (tb + 64u * q < n)
-                vsum = serial_add64(vsum, v[q]);
+                vsum = serial_add_lds(vsum, sbuf[0][q]);
     }
     double vari = vsum / glen;
     {
@@ -1432,10 +1486,15 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
                 }
                 v[q] = pn;
             }
+        __syncthreads();
 #pragma unroll
-            for (int q = 0; q < kVtNB; q++)
-                if (tb + 64u * q < n)
-                    ssum = serial_add64(ssum, v[q]);
+        for (int q = 0; q < kVtNB; q++)
+            sbuf[0][q][lane] = v[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++)
+            if (tb + 64u * q < n)
+                ssum = serial_add_lds(ssum, sbuf[0][q]);
         }
     }
     double step = 0.1, prev = 0.0; // STEPINIT
@@ -1451,33 +1510,64 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
         __syncthreads(); // par written by other lanes in the previous sweep is visible (one wave)
         for (uint32_t tb = 0; tb < n; tb += STEP) {
             double vs[kVtNB], hv[kVtNB];
+            // every load of the iteration is unconditional (clamped index) and issued before the
+            // arithmetic: loads inside the per-lane edge conditions would each be waited for in turn
+            double l_p0[kVtNB], l_pp1[kVtNB], l_pm1[kVtNB], l_pp2[kVtNB], l_pm2[kVtNB], l_a0[kVtNB],
+                l_a1[kVtNB], l_a1m[kVtNB], l_a2[kVtNB], l_a2m[kVtNB], l_b[kVtNB];
+            uint8_t l_sw[kVtNB];
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++) {
+                const uint32_t t = tb + 64u * q + (uint32_t)lane;
+                const uint32_t tc = t < n ? t : n - 1;
+                const uint32_t t1 = tc + 1 < n ? tc + 1 : n - 1, t2 = tc + 2 < n ? tc + 2 : n - 1;
+                const uint32_t m1 = tc >= 1 ? tc - 1 : 0, m2 = tc >= 2 ? tc - 2 : 0;
+                l_p0[q] = Pv[IX(tc)];
+                l_pp1[q] = Pv[IX(t1)];
+                l_pm1[q] = Pv[IX(m1)];
+                l_pp2[q] = Pv[IX(t2)];
+                l_pm2[q] = Pv[IX(m2)];
+                l_a0[q] = A0[IX(tc)];
+                l_a1[q] = A1[IX(tc)];
+                l_a1m[q] = A1[IX(m1)];
+                l_a2[q] = A2[IX(tc)];
+                l_a2m[q] = A2[IX(m2)];
+                l_b[q] = Bv[IX(tc)];
+                l_sw[q] = sw[tc];
+            }
 #pragma unroll
             for (int q = 0; q < kVtNB; q++) {
                 const uint32_t t = tb + 64u * q + (uint32_t)lane;
                 vs[q] = hv[q] = 0.0;
                 if (t < n) {
-                    const double p0 = Pv[IX(t)];
-                    if (sw[t])
+                    const double p0 = l_p0[q];
+                    if (l_sw[q])
                         vs[q] = (p0 - mean) * (p0 - mean);
-                    double g = A0[IX(t)] * p0;
+                    double g = l_a0[q] * p0;
                     if (t + 1 < n)
-                        g += A1[IX(t)] * Pv[IX(t + 1)];
+                        g += l_a1[q] * l_pp1[q];
                     if (t >= 1)
-                        g += A1[IX(t - 1)] * Pv[IX(t - 1)];
+                        g += l_a1m[q] * l_pm1[q];
                     if (t + 2 < n)
-                        g += A2[IX(t)] * Pv[IX(t + 2)];
+                        g += l_a2[q] * l_pp2[q];
                     if (t >= 2)
-                        g += A2[IX(t - 2)] * Pv[IX(t - 2)];
+                        g += l_a2m[q] * l_pm2[q];
                     Gv[IX(t)] = g;
-                    hv[q] = 1.0 * wgt * p0 * (Bv[IX(t)] - 0.5 * g);
+                    hv[q] = 1.0 * wgt * p0 * (l_b[q] - 0.5 * g);
                 }
             }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++) {
+                sbuf[0][q][lane] = vs[q];
+                sbuf[1][q][lane] = hv[q];
+            }
+            __syncthreads();
 #pragma unroll
             for (int q = 0; q < kVtNB; q++)
                 if (tb + 64u * q < n) {
-                    vsum = serial_add64(vsum, vs[q]);
+                    vsum = serial_add_lds(vsum, sbuf[0][q]);
                     // hmmobj has no switch: frames beyond n contribute nothing (exact: + 0.0)
-                    hmmobj = serial_add64(hmmobj, hv[q]);
+                    hmmobj = serial_add_lds(hmmobj, sbuf[1][q]);
                 }
         }
         vari = vsum / glen;
@@ -1495,22 +1585,34 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
         __syncthreads();
         for (uint32_t tb = 0; tb < n; tb += STEP) {
             double sn[kVtNB];
+            double l_p[kVtNB], l_a0[kVtNB], l_g[kVtNB], l_b[kVtNB];
+            uint8_t l_sw[kVtNB];
+#pragma unroll
+            for (int q = 0; q < kVtNB; q++) {
+                const uint32_t t = tb + 64u * q + (uint32_t)lane;
+                const uint32_t tc = t < n ? t : n - 1;
+                l_p[q] = Pv[IX(tc)];
+                l_a0[q] = A0[IX(tc)];
+                l_g[q] = Gv[IX(tc)];
+                l_b[q] = Bv[IX(tc)];
+                l_sw[q] = sw[tc];
+            }
 #pragma unroll
             for (int q = 0; q < kVtNB; q++) {
                 const uint32_t t = tb + 64u * q + (uint32_t)lane;
                 sn[q] = 0.0;
                 if (t < n) {
-                    const double p = Pv[IX(t)];
-                    const double h = -1.0 * wgt * A0[IX(t)] -
+                    const double p = l_p[q];
+                    const double h = -1.0 * wgt * l_a0[q] -
                                      1.0 * 2.0 / ll *
                                          (lm1 * gv_vari * (vari - gv_mean) +
                                           2.0 * gv_vari * (p - mean) * (p - mean));
-                    const bool on = sw[t] != 0;
+                    const bool on = l_sw[q] != 0;
                     double next_g;
                     if (on)
-                        next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]) + 1.0 * dv * (p - mean));
+                        next_g = 1.0 / h * (1.0 * wgt * (-l_g[q] + l_b[q]) + 1.0 * dv * (p - mean));
                     else
-                        next_g = 1.0 / h * (1.0 * wgt * (-Gv[IX(t)] + Bv[IX(t)]));
+                        next_g = 1.0 / h * (1.0 * wgt * (-l_g[q] + l_b[q]));
                     const double pnew = p + step * next_g;
                     if (NONMSD && it == 5)
                         Ov[IX(t)] = pnew; // scatter fused into the last sweep
@@ -1520,10 +1622,15 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
                         sn[q] = pnew;
                 }
             }
+        __syncthreads();
 #pragma unroll
-            for (int q = 0; q < kVtNB; q++)
-                if (tb + 64u * q < n)
-                    ssum = serial_add64(ssum, sn[q]);
+        for (int q = 0; q < kVtNB; q++)
+            sbuf[0][q][lane] = sn[q];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kVtNB; q++)
+            if (tb + 64u * q < n)
+                ssum = serial_add_lds(ssum, sbuf[0][q]);
         }
         prev = obj;
     }

@@ -103,6 +103,7 @@ __global__ void k_pulse(BatchDev bd, VocDev vd)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= vd.nruns[b])
         return;
+    __builtin_amdgcn_s_setprio(3); // serial walk: do not take turns with throughput waves
     const uint32_t t0 = vd.run_list[u.state_off + r];
     if (t0 >= u.T)
         return;
