@@ -58,6 +58,34 @@ def test_config2_full_length_utterance_vs_oracle(ctx):
     assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2])
 
 
+def test_config2_throughput_kernel_at_scale(ctx):
+    """Config 2 at a quarter of its batch (64 x 25,546 frames = 1.6 M frames): enough for the
+    lane-triple throughput kernel at two waves per SIMD, the 2048-frame GV tiles and the
+    LDS-staged band solve to run as they do in bench.py.  Every hand-off is certified without a
+    redo, copies are bit-identical (each ran in a different lane triple / wave / CU), the first
+    and last copy match the oracle, and the fused i16 sink equals clamp(f64)."""
+    eng, tab, vi = ctx
+    u = synth.u128(tab, 0)
+    n = 64
+    with J.Batch(vi, [u] * n) as b:
+        b.run()
+        b.sync()
+        info = b.info()
+        picks = [b.pcm(i) for i in (0, 1, 31, n - 1)]
+    assert info["n_items"] >= 8192 and info["n_redo"] == 0, info
+    for p_ in picks[1:]:
+        assert np.array_equal(picks[0], p_)
+    ref, _ = oracle_pcm(vi, u)
+    e = rel_rms(picks[0], ref)
+    print("config 2 x64: rel RMS vs oracle", e, info)
+    assert e <= 1e-9
+    with J.Batch(vi, [u] * n, pcm_i16=True) as b:
+        b.run()
+        b.sync()
+        q = b.pcm_i16(n - 1)
+    assert np.array_equal(q, np.clip(picks[0], -32768.0, 32767.0).astype(np.int16))
+
+
 def test_config3_mixed_lengths(ctx):
     """Mixed-length batch (config 3 shape, reduced count): every utterance checked
     against the oracle; lengths ragged; launch order must not leak between utterances."""
