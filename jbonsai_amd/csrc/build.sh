@@ -19,5 +19,5 @@ for f in jb_mlpg.hip jb_vocoder.hip jb_batch.cpp jb_voice.cpp jb_engine.cpp; do
   fi
   objs+=("$o")
 done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT "${objs[@]}"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -pthread -o $OUT "${objs[@]}"
 echo "built $(realpath $OUT)"

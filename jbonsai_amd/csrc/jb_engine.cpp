@@ -14,6 +14,8 @@
 #include "jb_voice.h"
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
@@ -309,9 +311,11 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
         // Models::duration (model/mod.rs:80-92)
         std::vector<MV> dp(S);
         std::vector<double> tmp(2 * ns);
+        QuestionMemo memo; // question results of the current label, per model
         for (size_t i = 0; i < nl; i++) {
+            memo.reset();
             blend(e, c.w_duration, 2 * ns, tmp.data(),
-                  [&](const Voice &v) { return v.duration.get_parameter(2, pl.labels[i]); });
+                  [&](const Voice &v) { return v.duration.get_parameter(2, pl.labels[i], &memo); });
             for (size_t s = 0; s < ns; s++)
                 dp[i * ns + s] = {tmp[s], tmp[s + ns]};
         }
@@ -355,10 +359,11 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
             st.var[si].assign(S * WL, 0.0);
             st.msd[si].assign(S, DBL_MAX);
             std::vector<double> buf(plen);
-            for (size_t i = 0; i < nl; i++)
+            for (size_t i = 0; i < nl; i++) {
+                memo.reset();
                 for (size_t s = 0; s < ns; s++) {
                     blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
-                        return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i]);
+                        return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i], &memo);
                     });
                     const size_t row = i * ns + s;
                     std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
@@ -366,6 +371,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                     if (sm.is_msd)
                         st.msd[si][row] = buf[2 * WL];
                 }
+            }
             jb_stream_states &o = st.utt.stream[si];
             o.mean = st.mean[si].data();
             o.var = st.var[si].data();
@@ -664,12 +670,44 @@ int jb_synthesize_batch(const jb_engine *e, const char *const *lines, const size
     }
     std::vector<std::unique_ptr<jb::States>> sts(n_utts);
     std::vector<jb_state_utt> utts(n_utts);
-    for (size_t u = 0; u < n_utts; u++) {
+    for (size_t u = 0; u < n_utts; u++)
         sts[u].reset(new jb::States());
-        int rc = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u]);
-        if (rc)
-            return rc;
-        utts[u] = sts[u]->utt;
+    {
+        // The front half (label parse, tree search, pdf blend, durations: label.rs, model/mod.rs:80-156,
+        // duration.rs) is independent per utterance and read-only on the engine: host threads, one
+        // utterance at a time each (JB_HOST_THREADS, default min(16, cores)).  It is ~90 ms per 128 s
+        // utterance and thread against ~0.5 ms of GPU time, so it is what bounds this entry point.
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt ? std::min(nt, 16u) : 1u;
+        if (const char *ev = getenv("JB_HOST_THREADS"))
+            nt = (unsigned)std::max(1, atoi(ev));
+        nt = (unsigned)std::min<size_t>(nt, n_utts);
+        std::vector<int> rcs(n_utts, JB_OK);
+        std::vector<std::string> errs(n_utts);
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t u; (u = next.fetch_add(1)) < n_utts;) {
+                rcs[u] = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u]);
+                if (rcs[u])
+                    errs[u] = jb::g_err; // the worker's thread-local message
+            }
+        };
+        if (nt <= 1) {
+            work();
+        } else {
+            std::vector<std::thread> pool;
+            for (unsigned k = 0; k < nt; k++)
+                pool.emplace_back(work);
+            for (auto &t : pool)
+                t.join();
+        }
+        for (size_t u = 0; u < n_utts; u++) {
+            if (rcs[u]) {
+                jb::set_error(errs[u]);
+                return rcs[u];
+            }
+            utts[u] = sts[u]->utt;
+        }
     }
     jb_batch_opts opts{};
     opts.device = device;

@@ -43,29 +43,103 @@ bool glob_match(std::string_view pat, std::string_view s)
     return p == pat.size();
 }
 
+void Question::compile()
+{
+    compiled.clear();
+    for (const std::string &p : patterns) {
+        const size_t n = p.size();
+        const bool meta_inside = n > 2 && p.find_first_of("*?", 1) < n - 1;
+        const bool has_q = p.find('?') != std::string::npos;
+        const bool ls = n > 0 && p.front() == '*', ts = n > 0 && p.back() == '*';
+        Kind k = Glob;
+        std::string core;
+        if (has_q || meta_inside || n == 0)
+            k = Glob;
+        else if (n == 1 && ls)
+            k = Any;
+        else if (ls && ts && n >= 2) {
+            k = n == 2 ? Any : Contains; // "**" matches everything
+            core = p.substr(1, n - 2);
+        } else if (ts) {
+            k = Prefix;
+            core = p.substr(0, n - 1);
+        } else if (ls) {
+            k = Suffix;
+            core = p.substr(1);
+        } else {
+            k = Exact;
+            core = p;
+        }
+        compiled.emplace_back(k, k == Glob ? p : core);
+    }
+}
+
 bool Question::test(std::string_view label) const
 {
-    for (const auto &p : patterns)
-        if (glob_match(p, label))
+    if (compiled.size() != patterns.size()) { // not compiled (hand-built question): general matcher
+        for (const auto &p : patterns)
+            if (glob_match(p, label))
+                return true;
+        return false;
+    }
+    for (const auto &[k, t] : compiled) {
+        bool hit;
+        switch (k) {
+        case Any: hit = true; break;
+        case Contains: hit = label.find(t) != std::string_view::npos; break;
+        case Prefix: hit = label.size() >= t.size() && label.compare(0, t.size(), t) == 0; break;
+        case Suffix:
+            hit = label.size() >= t.size() && label.compare(label.size() - t.size(), t.size(), t) == 0;
+            break;
+        case Exact: hit = label == t; break;
+        default: hit = glob_match(t, label); break;
+        }
+        if (hit)
             return true;
+    }
     return false;
 }
 
-int Tree::search(const std::vector<Question> &qs, std::string_view label) const
+std::vector<int8_t> *QuestionMemo::of(const Model *m, size_t nq)
+{
+    for (Slot &s : slots)
+        if (s.m == m)
+            return &s.v;
+    slots.push_back(Slot{m, std::vector<int8_t>(nq, (int8_t)-1)});
+    return &slots.back().v;
+}
+
+void QuestionMemo::reset()
+{
+    for (Slot &s : slots)
+        std::fill(s.v.begin(), s.v.end(), (int8_t)-1);
+}
+
+int Tree::search(const std::vector<Question> &qs, std::string_view label, std::vector<int8_t> *memo) const
 {
     if (nodes.empty())
         return single_leaf;
     int32_t i = 0;
     for (;;) {
         const TreeNode &n = nodes[(size_t)i];
-        int32_t next = qs[(size_t)n.question].test(label) ? n.yes : n.no;
+        bool yes;
+        if (memo) {
+            int8_t &c = (*memo)[(size_t)n.question];
+            if (c < 0)
+                c = qs[(size_t)n.question].test(label) ? 1 : 0;
+            yes = c != 0;
+        } else {
+            yes = qs[(size_t)n.question].test(label);
+        }
+        int32_t next = yes ? n.yes : n.no;
         if (next < 0)
             return -next;
         i = next;
     }
 }
 
-void Model::get_index(int state_index, std::string_view label, int &tree_pos, int &pdf_index) const
+void Model::get_index(int state_index, std::string_view label, int &tree_pos, int &pdf_index,
+                      QuestionMemo *memo) const
 {
     tree_pos = -1;
     for (size_t i = 0; i < trees.size(); i++)
@@ -74,13 +148,13 @@ void Model::get_index(int state_index, std::string_view label, int &tree_pos, in
             break;
         }
     const Tree &t = trees[tree_pos < 0 ? 0 : (size_t)tree_pos];
-    pdf_index = t.search(questions, label);
+    pdf_index = t.search(questions, label, memo ? memo->of(this, questions.size()) : nullptr);
 }
 
-const float *Model::get_parameter(int state_index, std::string_view label) const
+const float *Model::get_parameter(int state_index, std::string_view label, QuestionMemo *memo) const
 {
     int tp, pi;
-    get_index(state_index, label, tp, pi);
+    get_index(state_index, label, tp, pi, memo);
     if (tp < 0 || pi < 1 || pi > npdf[(size_t)tp])
         throw ModelError("index not found"); // reference: todo!() (voice/model.rs:76-79)
     return pdf[(size_t)tp].data() + (size_t)(pi - 1) * (size_t)pdf_len;
@@ -243,6 +317,7 @@ void parse_trees(Model &m, std::string_view text)
                 throw ModelError("bad QS row");
             Question q;
             q.patterns = quoted_list(tk.s.substr(lb + 1, rb - lb - 1));
+            q.compile();
             qidx[name] = (int32_t)m.questions.size();
             m.questions.push_back(std::move(q));
             tk.p = rb + 1;
@@ -379,6 +454,7 @@ std::shared_ptr<Voice> parse_htsvoice(const uint8_t *bytes, size_t n)
     if (auto it = G.find("GV_OFF_CONTEXT"); it != G.end())
         m.gv_off_patterns = quoted_list(it->second);
     v->gv_off.patterns = m.gv_off_patterns;
+    v->gv_off.compile();
     if ((int)m.stream_type.size() != m.num_streams || m.num_states <= 0)
         throw ModelError("inconsistent global header");
 

@@ -18,9 +18,28 @@ struct ModelError : std::runtime_error {
 };
 
 // HTS question: OR of glob patterns ('*', '?') over the full-context label string.
+// Nearly every pattern of a voice is "*X*", "X*" or "*X" with a literal X: those are classified
+// once (compile()) and tested with find / starts_with / ends_with; the rest go through the
+// general matcher.
 struct Question {
+    enum Kind : uint8_t { Glob, Contains, Prefix, Suffix, Exact, Any };
     std::vector<std::string> patterns;
+    std::vector<std::pair<Kind, std::string>> compiled; // same order as patterns
+    void compile();
     bool test(std::string_view label) const;
+};
+
+struct Model;
+// Question results of ONE label, per model: the five state trees of a stream ask largely the
+// same questions, so each is evaluated at most once per (model, label).
+struct QuestionMemo {
+    struct Slot {
+        const Model *m = nullptr;
+        std::vector<int8_t> v; // -1 unknown, 0 / 1
+    };
+    std::vector<Slot> slots;
+    std::vector<int8_t> *of(const Model *m, size_t nq);
+    void reset(); // new label
 };
 
 bool glob_match(std::string_view pat, std::string_view s);
@@ -34,7 +53,8 @@ struct Tree {
     int state = 0;
     std::vector<TreeNode> nodes; // empty => single leaf
     int single_leaf = 0;
-    int search(const std::vector<Question> &qs, std::string_view label) const; // 1-based pdf index
+    // 1-based pdf index; memo (optional) caches question results of this label
+    int search(const std::vector<Question> &qs, std::string_view label, std::vector<int8_t> *memo = nullptr) const;
 };
 
 // Model (src/model/voice/model.rs:12-82)
@@ -46,10 +66,11 @@ struct Model {
     std::vector<std::vector<float>> pdf;  // per tree: npdf*pdf_len (LE f32 as stored)
 
     // get_index: (tree position or -1 when no tree has that state, 1-based pdf index)
-    void get_index(int state_index, std::string_view label, int &tree_pos, int &pdf_index) const;
+    void get_index(int state_index, std::string_view label, int &tree_pos, int &pdf_index,
+                   QuestionMemo *memo = nullptr) const;
     // get_parameter: pointer to pdf_len floats (first half means, second half variances,
     // optional trailing MSD weight: ModelParameter::from_linear, model.rs:99-109)
-    const float *get_parameter(int state_index, std::string_view label) const;
+    const float *get_parameter(int state_index, std::string_view label, QuestionMemo *memo = nullptr) const;
 };
 
 struct StreamModel {

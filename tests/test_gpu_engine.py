@@ -91,6 +91,29 @@ def test_synthesize_batch(engine):
     assert abs(outs[2][70000] - -1898.2890228814217) < EPS
 
 
+def test_synthesize_batch_threaded_front_half(engine):
+    """The host front half runs on worker threads, one utterance each: results must not depend
+    on the thread count, and an error in one utterance (here: a malformed label, LabelError in the
+    reference) must surface with its message."""
+    import os
+    batch = [SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2] * 12 + [[]]
+    ref = engine.synthesize_batch(batch[:2])
+    for nt in ("1", "5"):
+        os.environ["JB_HOST_THREADS"] = nt
+        try:
+            outs = engine.synthesize_batch(batch)
+        finally:
+            del os.environ["JB_HOST_THREADS"]
+        assert len(outs) == 25 and len(outs[24]) == 0
+        for i in range(24):
+            assert np.array_equal(outs[i], ref[i % 2])
+    bad = list(SAMPLE_SENTENCE_1)
+    bad[3] = "not a full-context label"
+    with pytest.raises(J.JbError) as ei:
+        engine.synthesize_batch([SAMPLE_SENTENCE_1] * 7 + [bad] + [SAMPLE_SENTENCE_2] * 3)
+    assert "LABEL" in str(ei.value).upper() or "label" in str(ei.value)
+
+
 def test_volume_db(engine):
     e = J.Engine.load([VOICE])
     base = e.synthesize(SAMPLE_SENTENCE_1)
