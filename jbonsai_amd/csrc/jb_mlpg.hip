@@ -1,20 +1,24 @@
 // jb_mlpg.hip -- parameter generation (MLPG + GV) kernels for gfx950.
 //
 // Restates, per (utterance, vector dimension), /root/reference/src/mlpg_adjust:
-//   k_prep        A1/A2  Mask::create + boundary_distances   (mask.rs:20-82)
-//   k_mlpg_build  A3/A4  per-dim parameter expansion + calc_wuw_and_wum
-//                        (mod.rs:56-84, mlpg.rs:25-70) -- elementwise in time, so
-//                        it is time-parallel: one thread per (frame, dim)
-//   k_mlpg_solve  A5-A9  band LDL^T, substitutions, GV ascent, scatter
-//                        (mlpg.rs:79-292, mask.rs:34-49) -- serial recurrences in
-//                        time: one lane per (utterance, dim), lanes = adjacent dims
-//                        so every load/store of the [frame][dim] workspace is
-//                        coalesced.  All sums run in the reference's order, in
-//                        f64, with FP contraction off: this kernel is bit-exact
-//                        against the oracle except through libm-free paths only
-//                        (sqrt and division are correctly rounded on gfx950).
-// LF0 needs f64 + reference order: pulse positions are chaotic w.r.t. rounding of
-// lf0.  The same code serves MCP and LPF.
+//   k_prep_*          A1/A2  Mask::create + boundary_distances      (mask.rs:20-82)
+//   k_mlpg_ivar       A3     MeanVari::with_ivar per state          (model/mean_vari.rs:21-31)
+//   k_mlpg_build*     A3/A4  parameter expansion + calc_wuw_and_wum (mod.rs:56-84, mlpg.rs:25-70)
+//                            -- elementwise in time: thread per (frame, dim)
+//   k_mlpg_fb_lds     A5/A6  band LDL^T + substitutions             (mlpg.rs:79-115)
+//                            -- serial in time: one solver wave per utterance (lane = dim) fed
+//                            through LDS by mover waves; (k_mlpg_fb_mt: lane-per-row fallback)
+//   k_mlpg_gv_tp      A8     GV ascent, time-parallel (MCP)         (mlpg.rs:145-292)
+//   k_mlpg_gv_vt      A8     GV ascent, lanes over time with the sums in serial order (LF0)
+//   k_mlpg_solve3/solve A5-A9 fused serial-order sweeps / generic band width (bit-exact A/B paths)
+//   k_mlpg_static     A3-A9  one static window, no GV (LPF)
+//   k_mlpg_scatter*, k_mc2b_mt A9 Mask::fill with NODATA (+ mc2b for MCP)  (mask.rs:34-49)
+// Workspace layout: [dim][frame] per utterance for band width 3 (`StreamDev::mt`), [frame][dim]
+// for the generic solver.  All arithmetic is f64 with FP contraction off, in the reference's
+// order of operations, so every path is bit-exact against the oracle except the three GV
+// reductions of k_mlpg_gv_tp (fixed-shape tree sums, ~1e-15 relative; JB_BATCH_SERIAL_GV keeps the
+// serial order).  LF0 needs the reference order: pulse positions are chaotic w.r.t. the rounding
+// of lf0.
 //
 // Compiled with -ffp-contract=off.
 #include "jb_device.h"
