@@ -1032,6 +1032,9 @@ constexpr int kLtChunks = 20;
 #ifndef JB_LT_PF
 #define JB_LT_PF 4
 #endif
+#ifndef JB_LT_MERGED
+#define JB_LT_MERGED 1 // per-tap FMAs as one asm block (0: single-instruction asm statements, A/B)
+#endif
 
 template <int NM, int TPLW>
 __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
@@ -1235,12 +1238,43 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                     if (j + JB_LT_PF <= M)
                         JB_LDS_RD(cq[slotq], j + JB_LT_PF);
                 }
+                // all-pass section of tap j for both stage slots, then the dot-product terms:
+                //   rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem' ; y += c_j * d'
+                // as ONE block of three-address v_fma_f64.  (a) hipcc would select the destructive
+                // v_fmac_f64 and then need a v_mov_b64 per tap to undo the register rotation of the
+                // loop-carried d[] (69 moves per sample, ~19 % of the VALU work); (b) around
+                // single-instruction asm statements its hazard recogniser pads with s_nop (47 per
+                // sample), inside one block the two slots are interleaved by hand instead.
+#if JB_LT_MERGED
+                static_assert(NS == 2, "the block below is written for two stage slots per lane");
+                {
+                    double rn0, rn1;
+                    if (j >= 2) {
+                        // (the interpolation c_j = c0 + i*cinc stays outside: inside the block it
+                        // doubles the padding at the asm boundaries, measured +1 ms)
+                        asm("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                            "v_fma_f64 %[rn1], %[na], %[r1], %[d1]\n\t"
+                            "v_fma_f64 %[d0], %[a], %[rn0], %[r0]\n\t"
+                            "v_fma_f64 %[d1], %[a], %[rn1], %[r1]\n\t"
+                            "v_fma_f64 %[y0], %[c], %[d0], %[y0]\n\t"
+                            "v_fma_f64 %[y1], %[c], %[d1], %[y1]"
+                            : [rn0] "=&v"(rn0), [rn1] "=&v"(rn1), [d0] "+v"(d[0][j]), [d1] "+v"(d[1][j]),
+                              [y0] "+v"(y[0]), [y1] "+v"(y[1])
+                            : [na] "s"(na), [a] "s"(a), [r0] "v"(r[0]), [r1] "v"(r[1]), [c] "v"(cj));
+                    } else {
+                        asm("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                            "v_fma_f64 %[rn1], %[na], %[r1], %[d1]\n\t"
+                            "v_fma_f64 %[d0], %[a], %[rn0], %[r0]\n\t"
+                            "v_fma_f64 %[d1], %[a], %[rn1], %[r1]"
+                            : [rn0] "=&v"(rn0), [rn1] "=&v"(rn1), [d0] "+v"(d[0][j]), [d1] "+v"(d[1][j])
+                            : [na] "s"(na), [a] "s"(a), [r0] "v"(r[0]), [r1] "v"(r[1]));
+                    }
+                    r[0] = rn0;
+                    r[1] = rn1;
+                }
+#else
 #pragma unroll
                 for (int q = 0; q < NS; q++) {
-                    // all-pass section: rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem'
-                    // Written as three-address v_fma_f64: hipcc otherwise selects the destructive
-                    // v_fmac_f64 for both and then needs a v_mov_b64 per tap to undo the register
-                    // rotation of the loop-carried d[] (69 moves per sample, ~19 % of the VALU work).
                     double rn, dn;
                     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rn) : "s"(na), "v"(r[q]), "v"(d[q][j]));
                     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dn) : "s"(a), "v"(rn), "v"(r[q]));
@@ -1249,6 +1283,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                     if (j >= 2)
                         y[q] = fma(cj, dn, y[q]);
                 }
+#endif
             }
 #undef JB_LDS_RD
             // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, gathered on the lead lane ----
