@@ -215,6 +215,12 @@ int jb_engine_set_interpolation_weight(jb_engine *e, int which, size_t stream, c
 int jb_synthesize(const jb_engine *e, const char *const *label_lines, size_t n_lines,
                   double **pcm, size_t *n_samples);
 void jb_pcm_free(double *pcm);
+/* 16-bit mono RIFF/WAVE writer for the i16 sink -- what the reference's examples do with hound
+ * (examples/is-bonsai/main.rs:37-49: 1 channel, 16 bits, SampleFormat::Int).  JB_ERR_MODEL (Io) if the
+ * file cannot be written. */
+int jb_write_wav_i16(const char *path, const int16_t *pcm, size_t n_samples, uint32_t sampling_frequency);
+/* Same from f64 samples, converting like jb's i16 sink: value.min(32767).max(-32768) as i16. */
+int jb_write_wav_f64(const char *path, const double *pcm, size_t n_samples, uint32_t sampling_frequency);
 
 /* Batched synthesize: utterance u has lines [line_off[u], line_off[u+1]).  New
  * entry (the reference is single-utterance); a Rust `Engine::synthesize_batch`

@@ -4,10 +4,10 @@ MLSA-vocoder hot path behind a C ABI (include/jbonsai_amd.h).
 The HIP shared library `libjbonsai_amd.so` is the product; this package is the
 thin host-side mirror of the reference's API used by tests and the benchmark.
 """
-from ._ffi import JbError, LIB_PATH, NODATA, build, lib  # noqa: F401
+from ._ffi import JbError, LIB_PATH, NODATA, build, lib, write_wav  # noqa: F401
 from .batch import Batch, StreamInfo, StreamStates, Utterance, VoiceInfo, paramgen_vocode_batch  # noqa: F401
 
 from .engine import Engine, SpeechGenerator  # noqa: F401,E402
 
-__all__ = ["Engine", "SpeechGenerator", "JbError", "LIB_PATH", "NODATA", "build", "lib", "Batch", "StreamInfo", "StreamStates",
+__all__ = ["Engine", "SpeechGenerator", "JbError", "LIB_PATH", "NODATA", "build", "lib", "write_wav", "Batch", "StreamInfo", "StreamStates",
            "Utterance", "VoiceInfo", "paramgen_vocode_batch"]

@@ -102,7 +102,7 @@ SYMBOLS = [
     "jb_engine_set_alpha", "jb_engine_get_alpha", "jb_engine_set_beta", "jb_engine_get_beta",
     "jb_engine_set_additional_half_tone", "jb_engine_get_additional_half_tone",
     "jb_engine_num_voices", "jb_engine_num_streams", "jb_engine_num_states",
-    "jb_engine_set_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_synthesize_batch",
+    "jb_engine_set_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_write_wav_i16", "jb_write_wav_f64", "jb_synthesize_batch",
     "jb_engine_model_shape", "jb_engine_pdf_table", "jb_engine_tree_index",
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
     "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",
@@ -163,8 +163,23 @@ def lib():
     L.jb_batch_free.restype = None
     L.jb_paramgen_vocode_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz,
                                            C.POINTER(BatchOpts), C.POINTER(dp), C.POINTER(sz)]
+    L.jb_write_wav_i16.argtypes = [C.c_char_p, vp, sz, C.c_uint32]
+    L.jb_write_wav_f64.argtypes = [C.c_char_p, vp, sz, C.c_uint32]
     _lib = L
     return L
+
+
+def write_wav(path, pcm, sampling_frequency: int) -> None:
+    """16-bit mono WAV as the reference's examples write it (examples/is-bonsai/main.rs:37-49).
+    int16 samples are written as they are; float64 samples are clamped and truncated first."""
+    import numpy as np
+
+    a = np.ascontiguousarray(pcm)
+    if a.dtype == np.int16:
+        check(lib().jb_write_wav_i16(str(path).encode(), a.ctypes.data, a.size, sampling_frequency))
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        check(lib().jb_write_wav_f64(str(path).encode(), a.ctypes.data, a.size, sampling_frequency))
 
 
 def check(rc):

@@ -16,8 +16,10 @@
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <cerrno>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -658,6 +660,48 @@ void jb_states_free(jb_states *s) { delete (jb::States *)s; }
 
 // ---- synthesize ----
 void jb_pcm_free(double *p) { free(p); }
+
+// ---- WAV sink (examples/is-bonsai/main.rs:37-49) ----
+static int write_wav(const char *path, const int16_t *pcm, size_t n, uint32_t fs)
+{
+    if (!path || (!pcm && n) || n > (0xffffffffull - 36) / 2) {
+        jb::set_error("bad WAV arguments");
+        return JB_ERR_INVALID;
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        jb::set_error(std::string("cannot open ") + path + ": " + strerror(errno));
+        return JB_ERR_MODEL;
+    }
+    const uint32_t data = (uint32_t)(n * 2), riff = 36 + data, fmt_len = 16, byte_rate = fs * 2;
+    const uint16_t pcm_tag = 1, ch = 1, align = 2, bits = 16;
+    bool ok = fwrite("RIFF", 1, 4, f) == 4 && fwrite(&riff, 4, 1, f) == 1 && fwrite("WAVEfmt ", 1, 8, f) == 8 &&
+              fwrite(&fmt_len, 4, 1, f) == 1 && fwrite(&pcm_tag, 2, 1, f) == 1 && fwrite(&ch, 2, 1, f) == 1 &&
+              fwrite(&fs, 4, 1, f) == 1 && fwrite(&byte_rate, 4, 1, f) == 1 && fwrite(&align, 2, 1, f) == 1 &&
+              fwrite(&bits, 2, 1, f) == 1 && fwrite("data", 1, 4, f) == 4 && fwrite(&data, 4, 1, f) == 1 &&
+              (n == 0 || fwrite(pcm, 2, n, f) == n); // little-endian host (x86-64)
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) {
+        jb::set_error(std::string("short write to ") + path);
+        return JB_ERR_MODEL;
+    }
+    return JB_OK;
+}
+
+int jb_write_wav_i16(const char *path, const int16_t *pcm, size_t n, uint32_t fs) { return write_wav(path, pcm, n, fs); }
+
+int jb_write_wav_f64(const char *path, const double *pcm, size_t n, uint32_t fs)
+{
+    if (!pcm && n)
+        return JB_ERR_INVALID;
+    std::vector<int16_t> q(n);
+    for (size_t i = 0; i < n; i++) {
+        double v = std::fmin(pcm[i], 32767.0);
+        v = std::fmax(v, -32768.0);
+        q[i] = (int16_t)(int)v; // `as i16`: truncation toward zero
+    }
+    return write_wav(path, q.data(), n, fs);
+}
 
 int jb_synthesize_batch(const jb_engine *e, const char *const *lines, const size_t *line_off,
                         size_t n_utts, int32_t device, double **pcm, size_t *n_samples)

@@ -1,3 +1,4 @@
+import pytest
 """The C-ABI library loads and exports every symbol include/jbonsai_amd.h declares
 (no compute calls: runs without a GPU)."""
 import ctypes
@@ -41,3 +42,25 @@ def test_no_torch_or_oracle_in_product():
             s = p.read_text()
             assert "oracle" not in s.replace("the oracle", "").replace("CPU oracle", "") or p.name == "jb_mlpg.hip", p
             assert "import torch" not in s, p
+
+
+def test_wav_sink_roundtrip(tmp_path):
+    """jb_write_wav_{i16,f64}: 16-bit mono RIFF as hound writes it in the reference's examples
+    (examples/is-bonsai/main.rs:37-49); f64 goes through min/max clamp + `as i16` truncation."""
+    import wave
+
+    import numpy as np
+
+    import jbonsai_amd as J
+
+    x = np.array([0.0, 0.9, -0.9, 1.5, -1.5, 32767.4, 32768.0, 1e9, -32768.9, -1e9, 12345.678], dtype=np.float64)
+    want = np.clip(x, -32768.0, 32767.0).astype(np.int16)
+    for name, data in (("f.wav", x), ("i.wav", want)):
+        p_ = tmp_path / name
+        J.write_wav(p_, data, 48000)
+        with wave.open(str(p_), "rb") as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()) == (1, 2, 48000, len(x))
+            got = np.frombuffer(w.readframes(len(x)), dtype="<i2")
+        assert np.array_equal(got, want)
+    with pytest.raises(J.JbError):
+        J.write_wav(tmp_path / "no_such_dir" / "x.wav", want, 48000)
