@@ -82,6 +82,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=0, help="frames per utterance (0 = 25,546 = ~128 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather", action="store_true",
+                    help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
+                         "(torch.distributed gather over xGMI) and report its time as gather_ms; "
+                         "never part of `value` (SURVEY 8e)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
                          "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
@@ -152,6 +156,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    gather_ms = None
+    if args.gather and dist is not None:
+        # optional sink of north_star: PCM of all ranks on GPU 0.  The slab is library-owned device
+        # memory viewed zero-copy; rank 0 needs world x 12.6 GB of HBM for config 2.
+        slab = batch.pcm_tensor()
+        dest = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
+        barrier()
+        tg = time.perf_counter()
+        dist.gather(slab, dest, dst=0)
+        barrier()
+        gather_ms = (time.perf_counter() - tg) * 1e3
+        del dest
+
     if rank == 0:
         total = samples_per_step * world * args.steps
         value = total / dt
@@ -184,6 +201,7 @@ def main():
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
             "realtime_factor": value / vi.sampling_frequency,
+            **({"gather_ms": gather_ms} if gather_ms is not None else {}),
             "roofline": {
                 "bound": "hbm", "kernel": "k_vocoder_lt" if info["chunk_frames"] and info["n_items"] >= 16384 else "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

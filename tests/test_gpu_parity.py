@@ -228,3 +228,41 @@ def test_i16_sink_equals_clamped_cast_of_f64(oracle_voice, have_gpu):
             want = np.clip(f, -32768.0, 32767.0).astype(np.int16)  # astype truncates toward zero
             assert q.dtype == np.int16 and np.array_equal(q, want)
             assert (np.abs(f) > 32768).any() and (want == 32767).any() and (want == -32768).any()
+
+
+def test_device_pcm_slab_as_torch_tensor(have_gpu):
+    """jb_batch_device_pcm + pcm_offset: the contiguous device slab a caller would hand to an RCCL
+    gather, viewed zero-copy as a torch tensor, holds exactly what read_pcm returns.
+    Runs in a child process: torch must be imported before the library so that both share one HIP
+    runtime (as in bench.py); this pytest process has loaded the library long ago."""
+    import subprocess
+    import sys
+    import textwrap
+
+    pytest.importorskip("torch")
+    code = textwrap.dedent("""
+        import torch, numpy as np
+        assert torch.cuda.is_available()
+        import jbonsai_amd as J
+        from oracle import oracle as O
+        from tests.conftest import VOICE
+        from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
+        from tests.helpers import oracle_states, to_utt, voice_info
+        v = O.Voice(VOICE)
+        d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
+        d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+        utts = [to_utt(d2, s2), to_utt(d1, s1), to_utt(d2, s2)]
+        for i16 in (False, True):
+            with J.Batch(voice_info(v), utts, pcm_i16=i16) as b:
+                b.run(); b.sync()
+                t = b.pcm_tensor()
+                assert t.is_cuda and t.numel() == b.total_samples
+                host = t.cpu().numpy()
+                for i in range(3):
+                    o, n = b.pcm_offset(i), b.num_samples(i)
+                    assert np.array_equal(host[o:o + n], b.pcm_i16(i) if i16 else b.pcm(i))
+        print("slab ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    assert r.returncode == 0 and "slab ok" in r.stdout, r.stdout + r.stderr
