@@ -121,7 +121,7 @@ Batch::~Batch()
         hipEventDestroy(ev2);
     if (ev3)
         hipEventDestroy(ev3);
-    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build})
+    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build, ev_mcpbuild})
         if (ev)
             hipEventDestroy(ev);
     for (hipStream_t st : {stream_lf0, stream_lpf})
@@ -290,6 +290,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     hipEventCreateWithFlags(&b->ev_lpf, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_prep, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_build, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_mcpbuild, hipEventDisableTiming);
     hipEventCreate(&b->ev0);
     hipEventCreate(&b->ev1);
     hipEventCreate(&b->ev2);
@@ -638,6 +639,32 @@ int Batch::enqueue_vocoder()
 // main stream, LF0 -> pitch -> pulse schedule and LPF on side streams, forked after
 // whatever the main stream was doing (a previous run may still read the tracks) and
 // joined before the vocoder.
+// Hook of the MCP chain, called between its band solve and its GV sweeps: the pulse-free
+// excitation pass goes onto the main stream there.  Run beside the band solve or the GV sweeps it
+// stretched both by more than its own 7 ms (memory-heavy kernels do not overlap well here);
+// the LF0 / LPF chains it depends on are long done at that point.
+static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
+{
+    Batch *b = (Batch *)ctx;
+    hipError_t e;
+    // LPF chain (width-1 static window: one bandwidth-bound kernel): held back until the MCP
+    // build is done (ev_mcpbuild), so that it runs under the latency-bound band solve instead of
+    // beside the equally bandwidth-bound ivar/build kernels at the head of the step
+    hipStreamWaitEvent(b->stream_lpf, b->ev_mcpbuild, 0);
+    if (b->voice.nstream > 2) {
+        if ((e = launch_prep(b->bd, b->sd[2], 2, b->stream_lpf)) != hipSuccess)
+            return e;
+        if ((e = launch_mlpg(b->bd, b->sd[2], 2, b->stream_lpf, nullptr)) != hipSuccess)
+            return e;
+    }
+    hipEventRecord(b->ev_lpf, b->stream_lpf);
+    hipStreamWaitEvent(stream, b->ev_prep, 0); // voiced flags (LF0 state walk)
+    hipStreamWaitEvent(stream, b->ev_lpf, 0);  // LPF track
+    e = launch_excite_noise(b->bd, b->vd, stream);
+    hipEventRecord(b->ev_build, stream); // "pulse-free excitation done"
+    return e;
+}
+
 int Batch::enqueue_paramgen()
 {
     hipError_t e;
@@ -654,35 +681,21 @@ int Batch::enqueue_paramgen()
         return hip_fail(e, "k_pitch");
     if ((e = launch_pulse(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_pulse");
-    // MCP chain (the critical path): ev_build marks the end of its bandwidth-bound W'U^-1W build,
-    // after which the factor/substitution sweeps leave the machine nearly idle
+    // MCP chain (the critical path); between its band solve and its GV sweeps the hook enqueues
+    // the LPF chain (side stream) and the pulse-free excitation pass (main stream)
     if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess)
         return hip_fail(e, "k_prep(mcp)");
-    if ((e = launch_mlpg(bd, sd[0], 0, stream, ev_build)) != hipSuccess)
-        return hip_fail(e, "k_mlpg(mcp)");
+    if ((e = launch_mlpg(bd, sd[0], 0, stream, ev_mcpbuild, excite_noise_hook, this)) != hipSuccess)
+        return hip_fail(e, "k_mlpg(mcp) / k_excite(noise)");
     if (sd[0].defer_out)
         e = launch_mc2b_mt(bd, sd[0], vd, (flags & JB_BATCH_KEEP_TRACKS) != 0, stream);
     else
         e = launch_mc2b(bd, vd, stream);
     if (e != hipSuccess)
         return hip_fail(e, "k_mc2b");
-    // LPF chain
-    if (voice.nstream > 2) {
-        if ((e = launch_prep(bd, sd[2], 2, stream_lpf)) != hipSuccess)
-            return hip_fail(e, "k_prep(lpf)");
-        if ((e = launch_mlpg(bd, sd[2], 2, stream_lpf, nullptr)) != hipSuccess)
-            return hip_fail(e, "k_mlpg(lpf)");
-    }
-    // the pulse-free part of the excitation needs the LPF taps and the voiced flags only: it is
-    // held back until the MCP build is done and then runs under the latency-bound MCP/LF0
-    // sweeps, instead of after the pulse scheduler where it would compete with the GV sweeps
-    hipStreamWaitEvent(stream_lpf, ev_prep, 0);
-    hipStreamWaitEvent(stream_lpf, ev_build, 0);
-    if ((e = launch_excite_noise(bd, vd, stream_lpf)) != hipSuccess)
-        return hip_fail(e, "k_excite(noise)");
-    hipEventRecord(ev_lpf, stream_lpf);
     // pulses (LF0): the samples after each pulse (split form) or the whole excitation
     hipStreamWaitEvent(stream_lf0, ev_lpf, 0);
+    hipStreamWaitEvent(stream_lf0, ev_build, 0);
     if ((e = launch_excite(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_excite");
     hipEventRecord(ev_lf0, stream_lf0);

@@ -131,9 +131,12 @@ struct BatchDev {
 
 // launchers (all asynchronous on `stream`)
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
-// after_build (optional) is recorded once A/bvec are built, before the serial sweeps start
+// after_build (optional) is recorded once A/bvec are built, before the serial sweeps start;
+// between (optional) is called after the band solve has been enqueued and before the GV sweeps
+// are: the caller may enqueue other work on `stream` there.
+typedef hipError_t (*jb_enqueue_hook)(void *ctx, hipStream_t stream);
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream,
-                       hipEvent_t after_build);
+                       hipEvent_t after_build, jb_enqueue_hook between = nullptr, void *between_ctx = nullptr);
 int mlpg_mt_max_dim();      // largest vector length served by the [dim][frame] fast path
 int mlpg_gv_tile_frames();  // frames per block of the time-parallel GV sweeps
 hipError_t launch_pitch(const BatchDev &bd, const VocDev &vd, hipStream_t stream);

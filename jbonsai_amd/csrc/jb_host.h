@@ -24,7 +24,7 @@ struct Batch {
     jb_voice_desc voice{};
     hipStream_t stream = nullptr;            // main: MCP chain, vocoder
     hipStream_t stream_lf0 = nullptr, stream_lpf = nullptr; // concurrent parameter-generation chains
-    hipEvent_t ev_fork = nullptr, ev_lf0 = nullptr, ev_lpf = nullptr, ev_prep = nullptr, ev_build = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_lf0 = nullptr, ev_lpf = nullptr, ev_prep = nullptr, ev_build = nullptr, ev_mcpbuild = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     std::vector<uint32_t> T;
     std::vector<uint64_t> frame_off;

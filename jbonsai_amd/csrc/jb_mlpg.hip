@@ -2022,7 +2022,7 @@ static void launch_fb(const BatchDev &bd, const StreamDev &sd, int si, hipStream
 
 template <int BW>
 static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
-                                 hipEvent_t after_build)
+                                 hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx)
 {
     const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
     if (work == 0 || bd.B == 0)
@@ -2053,6 +2053,12 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
                 launch_fb(bd, sd, si, stream);
             else
                 hipLaunchKernelGGL((k_mlpg_solve3<true, true, true>), grid, block, 0, stream, bd, sd, si);
+        }
+        if (between) {
+            hipError_t he = between(between_ctx, stream);
+            if (he != hipSuccess)
+                return he;
+            between = nullptr;
         }
         if (tp) {
             // par -> g -> par -> ... : conv_gv + five iterations = six writes, result back in par
@@ -2164,7 +2170,20 @@ hipError_t launch_mc2b_mt(const BatchDev &bd, const StreamDev &sd, const VocDev 
 int mlpg_mt_max_dim() { return kMtMaxDim; }
 int mlpg_gv_tile_frames() { return kGvTT; }
 
-hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream, hipEvent_t after_build)
+static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
+                                    hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx);
+
+hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream, hipEvent_t after_build,
+                       jb_enqueue_hook between, void *between_ctx)
+{
+    hipError_t e = launch_mlpg_inner(bd, sd, si, stream, after_build, between, between_ctx);
+    if (e == hipSuccess && between) // a path without a distinct GV phase: run the hook at the end
+        e = between(between_ctx, stream);
+    return e;
+}
+
+static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
+                                    hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx)
 {
     if (sd.BW == 1 && sd.W == 1 && !sd.use_gv && !sd.generic_solver) {
         const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
@@ -2178,11 +2197,11 @@ hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
     }
     switch (sd.BW) {
     case 1:
-        return launch_mlpg_bw<1>(bd, sd, si, stream, after_build);
+        return launch_mlpg_bw<1>(bd, sd, si, stream, after_build, between, between_ctx);
     case 3:
-        return launch_mlpg_bw<3>(bd, sd, si, stream, after_build);
+        return launch_mlpg_bw<3>(bd, sd, si, stream, after_build, between, between_ctx);
     case 5:
-        return launch_mlpg_bw<5>(bd, sd, si, stream, after_build);
+        return launch_mlpg_bw<5>(bd, sd, si, stream, after_build, between, between_ctx);
     default:
         return hipErrorInvalidValue;
     }
