@@ -74,6 +74,24 @@ def cpu_baseline(utt, vi, n_utts_per_thread=2):
     }
 
 
+def pcm_slab_tensor(batch):
+    """The batch's PCM slab (jb_batch_device_pcm) as a zero-copy torch tensor on its device (f64,
+    or i16 for a pcm_i16 batch), for an RCCL gather by the caller.  The tensor aliases
+    library-owned memory: valid until the batch is closed, contents valid after sync().  Lives
+    here, not in the package: the product does not import torch."""
+    import torch
+
+    p, n = batch.device_pcm()
+    i16 = bool(batch.flags & 64)  # JB_BATCH_PCM_I16
+
+    class _Slab:
+        __cuda_array_interface__ = {"shape": (n,), "typestr": "<i2" if i16 else "<f8",
+                                    "data": (int(p), False), "version": 2}
+
+    dev = batch.device if batch.device >= 0 else torch.cuda.current_device()
+    return torch.as_tensor(_Slab(), device=torch.device("cuda", dev))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +178,7 @@ def main():
     if args.gather and dist is not None:
         # optional sink of north_star: PCM of all ranks on GPU 0.  The slab is library-owned device
         # memory viewed zero-copy; rank 0 needs world x 12.6 GB of HBM for config 2.
-        slab = batch.pcm_tensor()
+        slab = pcm_slab_tensor(batch)
         dest = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
         barrier()
         tg = time.perf_counter()

@@ -124,12 +124,49 @@ typedef struct jb_batch_opts {
  * predecessor's end state within verify_tol, and any chunk that fails is recomputed
  * serially from that end state, so the result is certified against the serial one. */
 
+/* ---- indexed state level --------------------------------------------------
+ * The per-state Gaussians of an utterance are rows of the voice's pdf tables, selected by the
+ * decision trees (src/model/voice/model.rs:51-82) and, with several voices, blended with the
+ * interpolation weights (VoiceSet weighted sum, src/model/voice_set.rs:80-95).  Here the tables
+ * live on the device and an utterance is given by its row indices: the gather and the blend
+ * (first*w0, then += w_i*param_i in voice order, as the reference) run on the GPU, and 12 bytes
+ * per state and voice cross PCIe instead of 2.2 kB per state. */
+#define JB_MAX_VOICES 8
+typedef struct jb_pdf_table {
+    const float *rows;  /* [n_rows][row_len] f32 as stored in the voice: means | variances | (msd weight) */
+    uint32_t n_rows;    /* all trees of the stream concatenated */
+    uint32_t row_len;   /* 2*L*W (+1 for MSD streams) */
+} jb_pdf_table;
+typedef struct jb_pdf_set jb_pdf_set;
+/* tables[v * nstream + s] = stream s of voice v.  The rows are copied to `device` (-1 = current). */
+int jb_pdf_set_create(const jb_pdf_table *tables, uint32_t n_voices, uint32_t nstream, int32_t device,
+                      jb_pdf_set **out);
+void jb_pdf_set_free(jb_pdf_set *set);
+
+typedef struct jb_index_stream {
+    const uint32_t *row[JB_MAX_VOICES]; /* [S] row of the state's pdf in voice v's table */
+    const double *weight;               /* [n_voices] interpolation weights (Condition, engine.rs:211-243) */
+    const double *gv_mean, *gv_var;     /* as jb_stream_states (already blended: one pdf per utterance) */
+    const uint8_t *gv_switch;
+    double gv_weight, msd_threshold;
+} jb_index_stream;
+typedef struct jb_index_utt {
+    uint32_t num_states;
+    const uint32_t *durations;
+    jb_index_stream stream[JB_MAX_STREAM];
+    double lf0_offset; /* additional_half_tone * ln2/12 added to the static LF0 mean and clamped to
+                          [ln 20, ln 20000] (stream_parameter.rs:29-37); 0 = none */
+} jb_index_utt;
+
 typedef struct jb_batch jb_batch;
 
 /* Upload a batch of utterances to HBM and allocate outputs/workspace.
  * Utterances may alias each other's input arrays. */
 int jb_batch_create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
                     const jb_batch_opts *opts, jb_batch **out);
+/* Same from row indices into device-resident pdf tables (gather + blend on the GPU). */
+int jb_batch_create_indexed(const jb_voice_desc *voice, const jb_pdf_set *set, const jb_index_utt *utts,
+                            size_t n_utts, const jb_batch_opts *opts, jb_batch **out);
 /* Enqueue the whole hot path (MLPG+GV x3 -> frame prologue -> pulse schedule ->
  * excitation + MLSA) on the batch's HIP stream.  Inputs are already resident. */
 int jb_batch_run(jb_batch *b);

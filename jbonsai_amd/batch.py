@@ -114,7 +114,7 @@ class Batch:
                       | (F.BATCH_PCM_I16 if pcm_i16 else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "pair": F.BATCH_PAIR_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
-        self._flags, self._device = opts.flags, device
+        self.flags, self.device = opts.flags, device
         h = C.c_void_p()
         F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
         self._h = h
@@ -185,22 +185,6 @@ class Batch:
         n = C.c_size_t()
         p = self._L.jb_batch_device_pcm(self._h, C.byref(n))
         return p, n.value
-
-    def pcm_tensor(self):
-        """The batch's PCM slab as a zero-copy torch tensor on its device (f64, or i16 for a
-        pcm_i16 batch), e.g. for an RCCL gather by the caller.  The tensor aliases
-        library-owned memory: it is valid until the batch is closed, and its contents after sync()."""
-        import torch
-
-        p, n = self.device_pcm()
-        i16 = bool(self._flags & F.BATCH_PCM_I16)
-
-        class _Slab:
-            __cuda_array_interface__ = {"shape": (n,), "typestr": "<i2" if i16 else "<f8",
-                                        "data": (int(p), False), "version": 2}
-
-        dev = self._device if self._device >= 0 else torch.cuda.current_device()
-        return torch.as_tensor(_Slab(), device=torch.device("cuda", dev))
 
     def pcm_offset(self, i):
         return self._L.jb_batch_pcm_offset(self._h, i)

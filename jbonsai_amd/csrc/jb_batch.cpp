@@ -179,6 +179,120 @@ int Batch::upload(const void *host, size_t bytes, const void **dev)
     return JB_OK;
 }
 
+PdfSet::~PdfSet()
+{
+    if (device >= 0)
+        hipSetDevice(device);
+    for (const float *p : tab)
+        if (p)
+            hipFree((void *)p);
+}
+
+// gather + blend of the per-state Gaussians on the device.  Utterances whose index
+// arrays alias (same host pointers, same weights) share one result, like aliased uploads do.
+int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t n,
+                         std::vector<StreamStatesDev> &out)
+{
+    const PdfSet &ps = *idx.set;
+    if (ps.device != device) {
+        set_error("pdf set lives on another device");
+        return JB_ERR_INVALID;
+    }
+    if (ps.ns < voice->nstream || ps.nv == 0 || ps.nv > (uint32_t)kMaxVoices) {
+        set_error("pdf set does not match the voice description");
+        return JB_ERR_INVALID;
+    }
+    const uint32_t ns = voice->nstream;
+    out.assign(n * ns, StreamStatesDev{});
+    std::vector<GatherJob> jobs;
+    std::map<std::string, size_t> seen;
+    uint64_t max_elems = 0;
+    int rc;
+    for (size_t i = 0; i < n; i++) {
+        const jb_index_utt &u = idx.utts[i];
+        for (uint32_t si = 0; si < ns; si++) {
+            const jb_stream_desc &sdsc = voice->stream[si];
+            const jb_index_stream &is = u.stream[si];
+            const uint32_t WL = sdsc.vector_length * sdsc.num_windows;
+            const uint32_t want_len = 2 * WL + (sdsc.is_msd ? 1u : 0u);
+            if (u.num_states == 0)
+                continue;
+            if (!is.weight) {
+                set_error("interpolation weights missing");
+                return JB_ERR_INVALID;
+            }
+            GatherJob j{};
+            j.nv = ps.nv;
+            j.S = u.num_states;
+            j.WL = WL;
+            j.row_len = want_len;
+            j.has_msd = sdsc.is_msd ? 1 : 0;
+            j.lf0_offset = (si == 1) ? u.lf0_offset : 0.0;
+            std::string key((const char *)&u.num_states, sizeof u.num_states);
+            key.append((const char *)&si, sizeof si);
+            key.append((const char *)&j.lf0_offset, sizeof j.lf0_offset);
+            for (uint32_t v = 0; v < ps.nv; v++) {
+                const size_t t = (size_t)v * ps.ns + si;
+                if (!is.row[v] || ps.row_len[t] != want_len) {
+                    set_error("pdf row indices missing or table row length mismatch");
+                    return JB_ERR_INVALID;
+                }
+                for (uint32_t s = 0; s < u.num_states; s++)
+                    if (is.row[v][s] >= ps.n_rows[t]) {
+                        set_error("pdf row index out of range");
+                        return JB_ERR_INVALID;
+                    }
+                j.tab[v] = ps.tab[t];
+                j.w[v] = is.weight[v];
+                key.append((const char *)&is.row[v], sizeof(void *));
+                key.append((const char *)&is.weight[v], sizeof(double));
+            }
+            auto it = seen.find(key);
+            if (it != seen.end()) {
+                const GatherJob &o = jobs[it->second];
+                out[i * ns + si].mean = o.mean;
+                out[i * ns + si].var = o.var;
+                out[i * ns + si].msd = o.msd;
+                continue;
+            }
+            for (uint32_t v = 0; v < ps.nv; v++) {
+                const void *dp;
+                if ((rc = upload(is.row[v], sizeof(uint32_t) * u.num_states, &dp)))
+                    return rc;
+                j.row[v] = (const uint32_t *)dp;
+            }
+            if ((rc = dalloc(&j.mean, (size_t)u.num_states * WL, false)) ||
+                (rc = dalloc(&j.var, (size_t)u.num_states * WL, false)))
+                return rc;
+            if (sdsc.is_msd && (rc = dalloc(&j.msd, u.num_states, false)))
+                return rc;
+            max_elems = std::max<uint64_t>(max_elems, (uint64_t)u.num_states * WL);
+            seen[key] = jobs.size();
+            out[i * ns + si].mean = j.mean;
+            out[i * ns + si].var = j.var;
+            out[i * ns + si].msd = j.msd;
+            jobs.push_back(j);
+        }
+    }
+    if (jobs.empty())
+        return JB_OK;
+    GatherJob *jd;
+    if ((rc = dalloc(&jd, jobs.size(), false)))
+        return rc;
+    hipError_t e = hipMemcpy(jd, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+        return hip_fail(e, "hipMemcpy(gather jobs)");
+    // grid.y is limited to 65535 jobs per launch
+    for (size_t j0 = 0; j0 < jobs.size(); j0 += 65535) {
+        const uint32_t nj = (uint32_t)std::min<size_t>(65535, jobs.size() - j0);
+        if ((e = launch_gather(jd + j0, nj, max_elems, stream)) != hipSuccess)
+            return hip_fail(e, "k_gather_blend");
+    }
+    if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+        return hip_fail(e, "k_gather_blend");
+    return JB_OK;
+}
+
 static int check_voice(const jb_voice_desc *v)
 {
     if (!v)
@@ -241,8 +355,8 @@ static int check_voice(const jb_voice_desc *v)
     return JB_OK;
 }
 
-int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,
-                  const jb_batch_opts *opts, Batch **out)
+int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n, const jb_batch_opts *opts,
+                  Batch **out, const IndexSrc *idx)
 {
     *out = nullptr;
     int rc = check_voice(voice);
@@ -298,6 +412,9 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
 
     const int B = (int)n;
     b->B = B;
+    std::vector<StreamStatesDev> gathered; // indexed source: per-state Gaussians produced on the device
+    if (idx && (rc = b->gather_states(voice, *idx, n, gathered)))
+        return rc;
     b->T.resize(n);
     b->frame_off.resize(n + 1);
     std::vector<UttDev> hu(n);
@@ -332,20 +449,27 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
             const jb_stream_states &hs = u.stream[si];
             const jb_stream_desc &sd = voice->stream[si];
             const size_t WL = (size_t)sd.vector_length * sd.num_windows;
-            if (u.num_states && (!hs.mean || !hs.var)) {
-                set_error("stream mean/var missing");
-                return JB_ERR_INVALID;
-            }
             StreamStatesDev &ds = hu[i].st[si];
-            if ((rc = b->upload(hs.mean, sizeof(double) * WL * u.num_states, &dp)))
-                return rc;
-            ds.mean = (const double *)dp;
-            if ((rc = b->upload(hs.var, sizeof(double) * WL * u.num_states, &dp)))
-                return rc;
-            ds.var = (const double *)dp;
-            if ((rc = b->upload(hs.msd, sizeof(double) * u.num_states, &dp)))
-                return rc;
-            ds.msd = (const double *)dp;
+            if (idx) {
+                const StreamStatesDev &g = gathered[i * voice->nstream + si];
+                ds.mean = g.mean;
+                ds.var = g.var;
+                ds.msd = g.msd;
+            } else {
+                if (u.num_states && (!hs.mean || !hs.var)) {
+                    set_error("stream mean/var missing");
+                    return JB_ERR_INVALID;
+                }
+                if ((rc = b->upload(hs.mean, sizeof(double) * WL * u.num_states, &dp)))
+                    return rc;
+                ds.mean = (const double *)dp;
+                if ((rc = b->upload(hs.var, sizeof(double) * WL * u.num_states, &dp)))
+                    return rc;
+                ds.var = (const double *)dp;
+                if ((rc = b->upload(hs.msd, sizeof(double) * u.num_states, &dp)))
+                    return rc;
+                ds.msd = (const double *)dp;
+            }
             ds.gv_mean = ds.gv_var = nullptr;
             ds.gv_switch = nullptr;
             if (sd.use_gv && hs.gv_mean && hs.gv_var && hs.gv_switch) {
@@ -808,6 +932,8 @@ int Batch::read(const void *dev, void *dst, size_t bytes)
 } // namespace jb
 
 using jb::Batch;
+using jb::IndexSrc;
+using jb::PdfSet;
 
 extern "C" {
 
@@ -840,6 +966,82 @@ int jb_batch_create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t
         return JB_ERR_INVALID;
     Batch *b = nullptr;
     int rc = Batch::create(voice, utts, n_utts, opts, &b);
+    *out = (jb_batch *)b;
+    return rc;
+}
+
+int jb_pdf_set_create(const jb_pdf_table *tables, uint32_t n_voices, uint32_t nstream, int32_t device,
+                      jb_pdf_set **out)
+{
+    if (!out)
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    if (!tables || n_voices == 0 || n_voices > JB_MAX_VOICES || nstream == 0 || nstream > JB_MAX_STREAM) {
+        jb::set_error("bad pdf table set");
+        return JB_ERR_INVALID;
+    }
+    int dev = device;
+    hipError_t e;
+    if (dev < 0 && (e = hipGetDevice(&dev)) != hipSuccess)
+        return jb::hip_fail(e, "hipGetDevice");
+    if ((e = hipSetDevice(dev)) != hipSuccess)
+        return jb::hip_fail(e, "hipSetDevice");
+    std::unique_ptr<PdfSet> ps(new PdfSet());
+    ps->device = dev;
+    ps->nv = n_voices;
+    ps->ns = nstream;
+    const size_t nt = (size_t)n_voices * nstream;
+    ps->tab.assign(nt, nullptr);
+    ps->n_rows.assign(nt, 0);
+    ps->row_len.assign(nt, 0);
+    for (size_t t = 0; t < nt; t++) {
+        const jb_pdf_table &pt = tables[t];
+        if (!pt.rows || pt.n_rows == 0 || pt.row_len == 0) {
+            jb::set_error("empty pdf table");
+            return JB_ERR_INVALID;
+        }
+        const size_t bytes = (size_t)pt.n_rows * pt.row_len * sizeof(float);
+        float *d = nullptr;
+        if ((e = hipMalloc((void **)&d, bytes)) != hipSuccess)
+            return jb::hip_fail(e, "hipMalloc(pdf table)");
+        ps->tab[t] = d;
+        if ((e = hipMemcpy(d, pt.rows, bytes, hipMemcpyHostToDevice)) != hipSuccess)
+            return jb::hip_fail(e, "hipMemcpy(pdf table)");
+        ps->n_rows[t] = pt.n_rows;
+        ps->row_len[t] = pt.row_len;
+    }
+    *out = (jb_pdf_set *)ps.release();
+    return JB_OK;
+}
+
+void jb_pdf_set_free(jb_pdf_set *s) { delete (PdfSet *)s; }
+
+int jb_batch_create_indexed(const jb_voice_desc *voice, const jb_pdf_set *set, const jb_index_utt *utts,
+                            size_t n_utts, const jb_batch_opts *opts, jb_batch **out)
+{
+    if (!out)
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    if (!voice || !set || (n_utts && !utts))
+        return JB_ERR_INVALID;
+    std::vector<jb_state_utt> su(n_utts);
+    for (size_t i = 0; i < n_utts; i++) {
+        su[i] = jb_state_utt{};
+        su[i].num_states = utts[i].num_states;
+        su[i].durations = utts[i].durations;
+        for (uint32_t si = 0; si < voice->nstream && si < JB_MAX_STREAM; si++) {
+            const jb_index_stream &is = utts[i].stream[si];
+            jb_stream_states &o = su[i].stream[si];
+            o.gv_mean = is.gv_mean;
+            o.gv_var = is.gv_var;
+            o.gv_switch = is.gv_switch;
+            o.gv_weight = is.gv_weight;
+            o.msd_threshold = is.msd_threshold;
+        }
+    }
+    IndexSrc idx{(const PdfSet *)set, utts};
+    Batch *b = nullptr;
+    int rc = Batch::create(voice, su.data(), n_utts, opts, &b, &idx);
     *out = (jb_batch *)b;
     return rc;
 }

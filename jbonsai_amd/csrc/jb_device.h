@@ -129,6 +129,21 @@ struct BatchDev {
 };
 
 
+// One gather + blend job: S states of one stream of one utterance.
+// mean[s][k] = sum_v w[v] * tab[v][row[v][s]][k], var likewise from the second half of the row,
+// msd from the trailing element (voice_set.rs:80-95: first*w0, then += w_i*p_i in voice order).
+constexpr int kMaxVoices = 8;
+struct GatherJob {
+    const uint32_t *row[kMaxVoices]; // device, [S]
+    const float *tab[kMaxVoices];    // device, [n_rows][row_len]
+    double w[kMaxVoices];
+    uint32_t nv, S, WL, row_len;
+    int has_msd;
+    double lf0_offset;               // != 0: static LF0 mean += offset, clamped (stream_parameter.rs:29-37)
+    double *mean, *var, *msd;        // device outputs [S][WL], [S][WL], [S] (msd may be null)
+};
+hipError_t launch_gather(const GatherJob *jobs_dev, uint32_t n_jobs, uint64_t max_elems, hipStream_t stream);
+
 // launchers (all asynchronous on `stream`)
 hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream);
 // after_build (optional) is recorded once A/bvec are built, before the serial sweeps start;

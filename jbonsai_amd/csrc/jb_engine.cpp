@@ -15,6 +15,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <thread>
 #include <cerrno>
 #include <cfloat>
@@ -50,7 +52,56 @@ struct Engine {
     jb_voice_desc desc{};
     std::vector<double> win_coef[kMaxStream];
     void refresh_desc();
+    // stream pdf tables with all trees concatenated (row = tree_off[tree] + pdf-1),
+    // built once, and their device copies per GPU
+    struct CatTable {
+        std::vector<float> rows;
+        std::vector<uint32_t> tree_off;
+        uint32_t n_rows = 0, row_len = 0;
+    };
+    mutable std::vector<CatTable> cat; // [voice * nstream + stream]
+    mutable std::map<int, jb_pdf_set *> pdf_sets;
+    mutable std::mutex pdf_mu;
+    int pdf_set_for(int device, const jb_pdf_set **out) const;
+    ~Engine()
+    {
+        for (auto &kv : pdf_sets)
+            jb_pdf_set_free(kv.second);
+    }
 };
+
+int Engine::pdf_set_for(int device, const jb_pdf_set **out) const
+{
+    std::lock_guard<std::mutex> lk(pdf_mu);
+    const size_t ns = std::min(voices[0]->streams.size(), (size_t)kMaxStream);
+    if (cat.empty()) {
+        cat.resize(voices.size() * ns);
+        for (size_t v = 0; v < voices.size(); v++)
+            for (size_t si = 0; si < ns; si++) {
+                const Model &m = voices[v]->streams[si].stream;
+                CatTable &c = cat[v * ns + si];
+                c.row_len = (uint32_t)m.pdf_len;
+                for (size_t t = 0; t < m.pdf.size(); t++) {
+                    c.tree_off.push_back(c.n_rows);
+                    c.rows.insert(c.rows.end(), m.pdf[t].begin(), m.pdf[t].end());
+                    c.n_rows += (uint32_t)m.npdf[t];
+                }
+            }
+    }
+    auto it = pdf_sets.find(device);
+    if (it == pdf_sets.end()) {
+        std::vector<jb_pdf_table> tabs(cat.size());
+        for (size_t i = 0; i < cat.size(); i++)
+            tabs[i] = jb_pdf_table{cat[i].rows.data(), cat[i].n_rows, cat[i].row_len};
+        jb_pdf_set *ps = nullptr;
+        int rc = jb_pdf_set_create(tabs.data(), (uint32_t)voices.size(), (uint32_t)ns, device, &ps);
+        if (rc)
+            return rc;
+        it = pdf_sets.emplace(device, ps).first;
+    }
+    *out = it->second;
+    return JB_OK;
+}
 
 void Engine::refresh_desc()
 {
@@ -279,6 +330,10 @@ static void estimate_with_frame_length(const MV *p, size_t n, double frame_lengt
 // ---- state construction ------------------------------------------------------
 struct States {
     jb_state_utt utt{};
+    // indexed form: pdf rows per stream and voice instead of blended Gaussians
+    jb_index_utt iutt{};
+    std::vector<uint32_t> rows[kMaxStream][JB_MAX_VOICES];
+    std::vector<double> weights[kMaxStream];
     std::vector<uint32_t> dur;
     std::vector<double> mean[kMaxStream], var[kMaxStream], msd[kMaxStream], gvm[kMaxStream],
         gvv[kMaxStream];
@@ -299,7 +354,9 @@ static void blend(const Engine &e, const std::vector<double> &w, size_t len, dou
     }
 }
 
-static int build_states(const Engine &e, const char *const *lines, size_t n, States &st)
+// indexed == true: the stream Gaussians are NOT blended on the host; st.iutt carries the pdf rows
+// (tree search result) of every state and voice for the device-side gather (needs Engine::cat).
+static int build_states(const Engine &e, const char *const *lines, size_t n, States &st, bool indexed = false)
 {
     const Condition &c = e.cond;
     const Voice &v0 = *e.voices[0];
@@ -357,6 +414,28 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
             const StreamModel &sm = v0.streams[si];
             const size_t WL = (size_t)sm.vector_length * (size_t)sm.num_windows;
             const size_t plen = 2 * WL + (sm.is_msd ? 1 : 0);
+            if (indexed) {
+                const size_t nsx = std::min(v0.streams.size(), (size_t)kMaxStream);
+                for (size_t v = 0; v < e.voices.size(); v++)
+                    st.rows[si][v].assign(S, 0);
+                st.weights[si] = c.w_param[si];
+                for (size_t i = 0; i < nl; i++) {
+                    memo.reset();
+                    for (size_t s = 0; s < ns; s++)
+                        for (size_t v = 0; v < e.voices.size(); v++) {
+                            const Model &m = e.voices[v]->streams[si].stream;
+                            int tp, pi;
+                            m.get_index((int)(2 + s), pl.labels[i], tp, pi, &memo);
+                            if (tp < 0 || pi < 1 || pi > m.npdf[(size_t)tp])
+                                throw ModelError("index not found"); // reference: todo!() (voice/model.rs:76-79)
+                            st.rows[si][v][i * ns + s] = e.cat[v * nsx + si].tree_off[(size_t)tp] + (uint32_t)(pi - 1);
+                        }
+                }
+                jb_index_stream &io = st.iutt.stream[si];
+                for (size_t v = 0; v < e.voices.size(); v++)
+                    io.row[v] = st.rows[si][v].data();
+                io.weight = st.weights[si].data();
+            } else {
             st.mean[si].assign(S * WL, 0.0);
             st.var[si].assign(S * WL, 0.0);
             st.msd[si].assign(S, DBL_MAX);
@@ -373,6 +452,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                     if (sm.is_msd)
                         st.msd[si][row] = buf[2 * WL];
                 }
+            }
             }
             jb_stream_states &o = st.utt.stream[si];
             o.mean = st.mean[si].data();
@@ -398,9 +478,22 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                 o.gv_var = st.gvv[si].data();
                 o.gv_switch = st.gsw[si].data();
             }
+            if (indexed) {
+                jb_index_stream &io = st.iutt.stream[si];
+                io.gv_mean = o.gv_mean;
+                io.gv_var = o.gv_var;
+                io.gv_switch = o.gv_switch;
+                io.gv_weight = o.gv_weight;
+                io.msd_threshold = o.msd_threshold;
+            }
+        }
+        if (indexed) {
+            st.iutt.num_states = (uint32_t)S;
+            st.iutt.durations = st.dur.data();
+            st.iutt.lf0_offset = c.additional_half_tone * kHalfTone;
         }
         // apply_additional_half_tone (stream_parameter.rs:29-37, engine.rs:342-345)
-        if (c.additional_half_tone != 0.0 && v0.streams.size() > 1) {
+        if (!indexed && c.additional_half_tone != 0.0 && v0.streams.size() > 1) {
             const size_t WL = (size_t)v0.streams[1].vector_length * (size_t)v0.streams[1].num_windows;
             for (size_t s = 0; s < S; s++) {
                 double x = st.mean[1][s * WL] + c.additional_half_tone * kHalfTone;
@@ -716,6 +809,7 @@ int jb_synthesize_batch(const jb_engine *e, const char *const *lines, const size
     std::vector<jb_state_utt> utts(n_utts);
     for (size_t u = 0; u < n_utts; u++)
         sts[u].reset(new jb::States());
+    const jb_pdf_set *pset_ = nullptr;
     {
         // The front half (label parse, tree search, pdf blend, durations: label.rs, model/mod.rs:80-156,
         // duration.rs) is independent per utterance and read-only on the engine: host threads, one
@@ -726,12 +820,28 @@ int jb_synthesize_batch(const jb_engine *e, const char *const *lines, const size
         if (const char *ev = getenv("JB_HOST_THREADS"))
             nt = (unsigned)std::max(1, atoi(ev));
         nt = (unsigned)std::min<size_t>(nt, n_utts);
+        // device-side gather + blend unless JB_HOST_BLEND=1 (A/B: both produce the same bits)
+        const bool host_blend = getenv("JB_HOST_BLEND") && atoi(getenv("JB_HOST_BLEND")) != 0;
+        const jb_pdf_set *pset = nullptr;
+        if (!host_blend) {
+            int dev = device;
+            if (dev < 0 && hipGetDevice(&dev) != hipSuccess) {
+                jb::set_error("no HIP device");
+                return JB_ERR_DEVICE;
+            }
+            int prc = CENG(e)->pdf_set_for(dev, &pset);
+            if (prc)
+                return prc;
+            device = dev;
+        }
+        const bool indexed = pset != nullptr;
+        pset_ = pset;
         std::vector<int> rcs(n_utts, JB_OK);
         std::vector<std::string> errs(n_utts);
         std::atomic<size_t> next{0};
         auto work = [&]() {
             for (size_t u; (u = next.fetch_add(1)) < n_utts;) {
-                rcs[u] = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u]);
+                rcs[u] = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u], indexed);
                 if (rcs[u])
                     errs[u] = jb::g_err; // the worker's thread-local message
             }
@@ -756,7 +866,15 @@ int jb_synthesize_batch(const jb_engine *e, const char *const *lines, const size
     jb_batch_opts opts{};
     opts.device = device;
     jb::Batch *b = nullptr;
-    int rc = jb::Batch::create(&CENG(e)->desc, utts.data(), n_utts, &opts, &b);
+    int rc;
+    if (pset_) {
+        std::vector<jb_index_utt> iu(n_utts);
+        for (size_t u = 0; u < n_utts; u++)
+            iu[u] = sts[u]->iutt;
+        rc = jb_batch_create_indexed(&CENG(e)->desc, pset_, iu.data(), n_utts, &opts, (jb_batch **)&b);
+    } else {
+        rc = jb::Batch::create(&CENG(e)->desc, utts.data(), n_utts, &opts, &b);
+    }
     if (rc)
         return rc;
     std::unique_ptr<jb::Batch> guard(b);

@@ -17,6 +17,19 @@ void set_error(const std::string &s);
 int hip_fail(hipError_t e, const char *what);
 int noise_table(int device, size_t need, const double **ptr, size_t *len);
 
+// Device-resident pdf tables of a voice set (jb_pdf_set) and an indexed batch source
+struct PdfSet {
+    int device = -1;
+    uint32_t nv = 0, ns = 0;
+    std::vector<const float *> tab;        // [nv * ns] device
+    std::vector<uint32_t> n_rows, row_len; // [nv * ns]
+    ~PdfSet();
+};
+struct IndexSrc {
+    const PdfSet *set;
+    const jb_index_utt *utts;
+};
+
 struct Batch {
     int device = -1;
     uint32_t flags = 0;
@@ -55,7 +68,9 @@ struct Batch {
     template <class T> int dalloc(T **p, size_t n, bool zero);
     int upload(const void *host, size_t bytes, const void **dev);
     static int create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,
-                      const jb_batch_opts *opts, Batch **out);
+                      const jb_batch_opts *opts, Batch **out, const IndexSrc *idx = nullptr);
+    int gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t n,
+                      std::vector<StreamStatesDev> &out); // [n * nstream]: mean/var/msd filled
     int build_work(const jb_batch_opts *opts);
     int build_generator_work();
     int enqueue_paramgen();

@@ -2167,6 +2167,49 @@ hipError_t launch_mc2b_mt(const BatchDev &bd, const StreamDev &sd, const VocDev 
     return hipGetLastError();
 }
 
+// --------------------------------------------------------------------------
+// per-state Gaussians from pdf row indices -- gather from the device-resident
+// tables of each voice and blend with the interpolation weights, in the reference's order
+// (VoiceSet weighted sum, voice_set.rs:80-95: first * w0, then += w_i * param_i).  Thread per
+// (state, element); a state's row is WL contiguous floats, so reads and writes are coalesced.
+constexpr double kHalfToneMinLf0 = 2.995732273553991;  // ln 20     (stream_parameter.rs:8-9)
+constexpr double kHalfToneMaxLf0 = 9.903487552536127;  // ln 20000
+__global__ __launch_bounds__(256) void k_gather_blend(const GatherJob *__restrict__ jobs)
+{
+    const GatherJob &j = jobs[blockIdx.y];
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (uint64_t)j.S * j.WL)
+        return;
+    const uint32_t s = (uint32_t)(e / j.WL), k = (uint32_t)(e % j.WL);
+    const float *p0 = j.tab[0] + (uint64_t)j.row[0][s] * j.row_len;
+    double m = (double)p0[k] * j.w[0], v = (double)p0[j.WL + k] * j.w[0];
+    double q = (j.has_msd && k == 0) ? (double)p0[2 * j.WL] * j.w[0] : 0.0;
+    for (uint32_t vi = 1; vi < j.nv; vi++) {
+        const float *p = j.tab[vi] + (uint64_t)j.row[vi][s] * j.row_len;
+        m += j.w[vi] * (double)p[k];
+        v += j.w[vi] * (double)p[j.WL + k];
+        if (j.has_msd && k == 0)
+            q += j.w[vi] * (double)p[2 * j.WL];
+    }
+    if (j.lf0_offset != 0.0 && k == 0) {
+        const double x = m + j.lf0_offset;
+        m = fmin(fmax(x, kHalfToneMinLf0), kHalfToneMaxLf0);
+    }
+    j.mean[e] = m;
+    j.var[e] = v;
+    if (j.has_msd && k == 0 && j.msd)
+        j.msd[s] = q;
+}
+
+hipError_t launch_gather(const GatherJob *jobs_dev, uint32_t n_jobs, uint64_t max_elems, hipStream_t stream)
+{
+    if (n_jobs == 0 || max_elems == 0)
+        return hipSuccess;
+    dim3 grid((unsigned)((max_elems + 255) / 256), n_jobs), block(256);
+    hipLaunchKernelGGL(k_gather_blend, grid, block, 0, stream, jobs_dev);
+    return hipGetLastError();
+}
+
 int mlpg_mt_max_dim() { return kMtMaxDim; }
 int mlpg_gv_tile_frames() { return kGvTT; }
 

@@ -114,6 +114,41 @@ def test_synthesize_batch_threaded_front_half(engine):
     assert "LABEL" in str(ei.value).upper() or "label" in str(ei.value)
 
 
+def test_device_gather_blend_equals_host_blend():
+    """jb_synthesize_batch hands pdf ROW INDICES to the device, where the gather and
+    the multi-voice blend (voice_set.rs:80-95) run; JB_HOST_BLEND=1 selects the host blend.  Both
+    must produce the same bits -- one voice, and two voices (the nitech voice loaded twice) with
+    unequal interpolation weights, a half-tone shift and a speed change."""
+    import os
+
+    def both(e, batch):
+        outs = []
+        for hb in ("0", "1"):
+            os.environ["JB_HOST_BLEND"] = hb
+            try:
+                outs.append(e.synthesize_batch(batch))
+            finally:
+                del os.environ["JB_HOST_BLEND"]
+        return outs
+
+    batch = [SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2, [], SAMPLE_SENTENCE_1]
+    e1 = J.Engine.load([VOICE])
+    a, b = both(e1, batch)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert abs(a[0][2000] - 19.35141137623778) < EPS  # src/lib.rs:44-46 through the device gather
+    e2 = J.Engine.load([VOICE, VOICE])
+    e2.condition.set_interpolation_parameter(0, [0.3, 0.7])
+    e2.condition.set_interpolation_parameter(1, [0.8, 0.2])
+    e2.condition.set_interpolation_duration([0.5, 0.5])
+    e2.condition.set_additional_half_tone(2.5)
+    e2.condition.set_speed(1.2)
+    a, b = both(e2, batch)
+    for x, y in zip(a, b):
+        assert len(x) == len(y) and np.array_equal(x, y)
+    assert len(a[0]) > 0 and len(a[2]) == 0
+
+
 def test_volume_db(engine):
     e = J.Engine.load([VOICE])
     base = e.synthesize(SAMPLE_SENTENCE_1)

@@ -244,6 +244,7 @@ def test_device_pcm_slab_as_torch_tensor(have_gpu):
         import torch, numpy as np
         assert torch.cuda.is_available()
         import jbonsai_amd as J
+        from bench import pcm_slab_tensor
         from oracle import oracle as O
         from tests.conftest import VOICE
         from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
@@ -255,7 +256,7 @@ def test_device_pcm_slab_as_torch_tensor(have_gpu):
         for i16 in (False, True):
             with J.Batch(voice_info(v), utts, pcm_i16=i16) as b:
                 b.run(); b.sync()
-                t = b.pcm_tensor()
+                t = pcm_slab_tensor(b)
                 assert t.is_cuda and t.numel() == b.total_samples
                 host = t.cpu().numpy()
                 for i in range(3):
