@@ -1189,9 +1189,9 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 for (int ii = 5; ii >= 1; ii--) {
                     e11[ii] = fma(iaa, e12[ii - 1], a * e11[ii]);
                     e12[ii] = e11[ii] * c1;
-                    const double v = e12[ii] * kPPade[ii];
-                    x += (ii & 1) ? v : -v;
-                    out += v;
+                    // x +/- P*d12 and out + P*d12 as FMAs (one rounding less than mul + add each)
+                    x = fma((ii & 1) ? kPPade[ii] : -kPPade[ii], e12[ii], x);
+                    out = fma(kPPade[ii], e12[ii], out);
                 }
                 e12[0] = x;
                 x += out;
