@@ -32,6 +32,7 @@ FLOP_PER_SAMPLE = 1.39e3      # algorithmic f64 flops per output sample (SURVEY.
 # FP64 vector peak = half the guide's 157.3 TFLOPS FP32 vector rate (1024 SIMDs x 16 lanes x 2 flop x
 # 2.4 GHz); tools/microbench/f64_rate.hip sustains 68 TFLOP/s of dependent-free v_fma_f64 on this part
 FP64_VALU_PEAK_TFLOPS = 78.6
+DEFAULT_CU_SPLIT = 0  # CU partition off: measured slower at every split
 VOICE = ROOT / "tests" / "golden" / "voice" / "nitech_jp_atr503_m001.htsvoice"
 
 
@@ -100,6 +101,10 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=0, help="frames per utterance (0 = 25,546 = ~128 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cu-split", type=int, default=-1,
+                    help="CUs per XCD (of 32) given to parameter generation when two batches are in "
+                         "flight; the vocoder gets the rest (jb_batch_opts.mlpg_cus_per_xcd); "
+                         "-1 = default (0 with --pipeline 1)")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
                          "(torch.distributed gather over xGMI) and report its time as gather_ms; "
@@ -136,7 +141,8 @@ def main():
     # uploaded once and aliased; outputs / workspace / filter state are per utterance
     utt = synth.synth_utterance(tab, frames, 0)
     depth = max(1, args.pipeline)
-    batches = [J.Batch(vi, [utt] * args.batch, device=local_rank) for _ in range(depth)]
+    cu_split = args.cu_split if args.cu_split >= 0 else (DEFAULT_CU_SPLIT if depth > 1 else 0)
+    batches = [J.Batch(vi, [utt] * args.batch, device=local_rank, mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
     batch = batches[0]
     samples_per_step = batch.total_samples
 
@@ -214,7 +220,7 @@ def main():
                             "utterance from real nitech pdfs (BASELINE config 2), nitech voice",
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
                 "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
-                "batches_in_flight": depth,
+                "batches_in_flight": depth, "mlpg_cus_per_xcd": cu_split,
                 "vocoder_chunk_frames": info["chunk_frames"], "vocoder_warmup_frames": info["warmup_frames"],
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },

@@ -98,7 +98,8 @@ class Batch:
     def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
                  keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
-                 kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False):
+                 kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False,
+                 mlpg_cus_per_xcd: int = 0):
         L = F.lib()
         self._L = L
         self.voice = voice
@@ -114,6 +115,7 @@ class Batch:
                       | (F.BATCH_PCM_I16 if pcm_i16 else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "pair": F.BATCH_PAIR_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
+        opts.mlpg_cus_per_xcd = mlpg_cus_per_xcd
         self.flags, self.device = opts.flags, device
         h = C.c_void_p()
         F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))

@@ -124,7 +124,10 @@ Batch::~Batch()
     for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build, ev_mcpbuild})
         if (ev)
             hipEventDestroy(ev);
-    for (hipStream_t st : {stream_lf0, stream_lpf})
+    for (hipEvent_t ev : {ev_mlpg_done, ev_voc_done})
+        if (ev)
+            hipEventDestroy(ev);
+    for (hipStream_t st : {stream_lf0, stream_lpf, stream_voc})
         if (st && st != stream)
             hipStreamDestroy(st);
     if (stream)
@@ -389,16 +392,38 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->voice = *voice;
     // (stream priorities were tried for the critical path and made every latency-bound kernel
     // 2-4x slower on this stack; ordering is done with events instead)
-    e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+    b->cu_split = opts ? opts->mlpg_cus_per_xcd : 0;
+    if (b->cu_split > 31) {
+        set_error("mlpg_cus_per_xcd must be 0..31");
+        return JB_ERR_INVALID;
+    }
+    // CU masks (256 CUs = 8 XCDs x 32; bit i = XCD i%8, CU i/8): parameter generation on CU
+    // indices [32-k, 32) of every XCD, the vocoder on [0, 32-k)
+    uint32_t mask_pg[8] = {0}, mask_voc[8] = {0};
+    for (uint32_t i = 0; i < 256; i++)
+        ((i / 8 >= 32 - b->cu_split) ? mask_pg : mask_voc)[i / 32] |= 1u << (i % 32);
+    auto mkstream = [&](hipStream_t *st, const uint32_t *mask) {
+        return b->cu_split ? hipExtStreamCreateWithCUMask(st, 8, mask)
+                           : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    };
+    e = mkstream(&b->stream, mask_pg);
     if (e != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
     // JB_ONE_STREAM=1 (profiling aid): the three parameter-generation chains run back to back
     // on the main stream, so that per-kernel durations are free of overlap effects
     if (getenv("JB_ONE_STREAM") && atoi(getenv("JB_ONE_STREAM")) != 0) {
         b->stream_lf0 = b->stream_lpf = b->stream;
-    } else if ((e = hipStreamCreateWithFlags(&b->stream_lf0, hipStreamNonBlocking)) != hipSuccess ||
-               (e = hipStreamCreateWithFlags(&b->stream_lpf, hipStreamNonBlocking)) != hipSuccess)
+    } else if ((e = mkstream(&b->stream_lf0, mask_pg)) != hipSuccess ||
+               (e = mkstream(&b->stream_lpf, mask_pg)) != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
+    if (b->cu_split) {
+        if ((e = hipExtStreamCreateWithCUMask(&b->stream_voc, 8, mask_voc)) != hipSuccess)
+            return hip_fail(e, "hipExtStreamCreateWithCUMask");
+    } else {
+        b->stream_voc = b->stream;
+    }
+    hipEventCreateWithFlags(&b->ev_mlpg_done, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_voc_done, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_lf0, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_lpf, hipEventDisableTiming);
@@ -652,7 +677,8 @@ int Batch::build_work(const jb_batch_opts *opts)
     if (serial) {
         ch = 0;
     } else if (ch == 0 && lp_mode) {
-        uint64_t target = 2048ull * (uint64_t)vocoder_ls_chunks_per_wave(); // 1024 SIMDs x 2 waves
+        // two waves on every SIMD the vocoder may use: 8 XCDs x (32 - k) CUs x 4 SIMDs x 2
+        uint64_t target = 64ull * (32 - cu_split) * (uint64_t)vocoder_ls_chunks_per_wave();
         if (const char *e = getenv("JB_LP_TARGET"))
             target = strtoull(e, nullptr, 10);
         uint64_t c = (sumT + target - 1) / target;
@@ -751,9 +777,9 @@ int Batch::enqueue_vocoder()
 {
     hipError_t e;
     if (lp_mode)
-        e = launch_vocoder_ls(bd, vd, work_dev, order_dev, n_items, stream);
+        e = launch_vocoder_ls(bd, vd, work_dev, order_dev, n_items, stream_voc);
     else
-        e = launch_vocoder(bd, vd, work_dev, n_items, stream);
+        e = launch_vocoder(bd, vd, work_dev, n_items, stream_voc);
     if (e != hipSuccess)
         return hip_fail(e, "k_vocoder");
     return JB_OK;
@@ -832,26 +858,31 @@ int Batch::run(bool timed)
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess)
         return hip_fail(e, "hipSetDevice");
+    // a previous run's vocoder may still read what this run's parameter generation rewrites
+    hipStreamWaitEvent(stream, ev_voc_done, 0);
     if (timed)
         hipEventRecord(ev0, stream);
     int rc = enqueue_paramgen();
     if (rc)
         return rc;
+    hipEventRecord(ev_mlpg_done, stream);
+    hipStreamWaitEvent(stream_voc, ev_mlpg_done, 0);
     if (timed)
-        hipEventRecord(ev1, stream);
+        hipEventRecord(ev1, stream_voc);
     if ((rc = enqueue_vocoder()))
         return rc;
     if (timed)
-        hipEventRecord(ev2, stream);
+        hipEventRecord(ev2, stream_voc);
     if (chunk_frames != 0 && n_items > 0) {
-        hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream);
+        hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
         if ((e = launch_voc_verify(work_dev, n_items, vd.state_stride, verify_tol, bad_dev, nbad_dev,
-                                   stream)) != hipSuccess)
+                                   stream_voc)) != hipSuccess)
             return hip_fail(e, "k_voc_verify");
         verify_pending = true;
     }
     if (timed)
-        hipEventRecord(ev3, stream);
+        hipEventRecord(ev3, stream_voc);
+    hipEventRecord(ev_voc_done, stream_voc);
     return JB_OK;
 }
 
@@ -901,9 +932,9 @@ int Batch::finish_verify()
         if ((e = hipMemcpy(redo_dev, round.data(), sizeof(VocWork) * round.size(),
                            hipMemcpyHostToDevice)) != hipSuccess)
             return hip_fail(e, "hipMemcpy(redo)");
-        if ((e = launch_vocoder(bd, vd, redo_dev, (uint32_t)round.size(), stream)) != hipSuccess)
+        if ((e = launch_vocoder(bd, vd, redo_dev, (uint32_t)round.size(), stream_voc)) != hipSuccess)
             return hip_fail(e, "k_vocoder(redo)");
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess)
+        if ((e = hipStreamSynchronize(stream_voc)) != hipSuccess)
             return hip_fail(e, "redo sync");
         for (uint32_t k : ids)
             pending[k] = 0;
@@ -913,7 +944,9 @@ int Batch::finish_verify()
 
 int Batch::sync()
 {
-    hipError_t e = hipStreamSynchronize(stream);
+    hipError_t e = hipStreamSynchronize(stream_voc);
+    if (e == hipSuccess && stream_voc != stream)
+        e = hipStreamSynchronize(stream);
     if (e != hipSuccess)
         return hip_fail(e, "stream sync");
     return finish_verify();

@@ -267,3 +267,18 @@ def test_device_pcm_slab_as_torch_tensor(have_gpu):
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
     assert r.returncode == 0 and "slab ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_cu_partition_gives_identical_pcm(oracle_voice, have_gpu):
+    """jb_batch_opts.mlpg_cus_per_xcd: parameter generation and vocoder on disjoint CU sets
+    (masked streams, separate vocoder stream).  Scheduling only: the PCM must not change."""
+    v = oracle_voice
+    d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
+    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+    utts = [to_utt(d2, s2), to_utt(d1, s1)] * 3
+    ref, _ = _run(v, utts, chunk_frames=64, kernel="pair")
+    for k in (8, 31):
+        got, info = _run(v, utts, chunk_frames=64, kernel="pair", mlpg_cus_per_xcd=k)
+        assert info["n_redo"] == 0
+        for a, b in zip(ref, got):
+            assert np.array_equal(a, b)
