@@ -369,30 +369,41 @@ __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd
             for (int i = 0; i < 3; i++)
                 cf[i] = i < ww ? coef[i] : 0.0;
             const uint32_t mo = (uint32_t)(L * w + m);
+            // The six table loads of the window (mean, 1/var of up to three source frames) are
+            // unconditional -- source index clamped into the block's frame window -- and issued
+            // before the arithmetic; loads behind the per-lane edge tests were waited for one at a
+            // time (77 % of the kernel's wave cycles).  A tap that does not exist (past the window
+            // width, zero coefficient, source outside the utterance) enters with wu = 0 and adds
+            // exact zeros where the reference skips it.
+            double mv[3], iv[3];
+            bool ok[3];
 #pragma unroll
             for (int index = 2; index >= 0; index--) {
-                if (index >= ww || cf[index] == 0.0)
-                    continue;
                 const int d = index - lw; // source frame k - d
                 const long idx = (long)k - (long)d;
-                if (idx < 0 || idx >= (long)Tv)
-                    continue;
-                const int fi = kl - d + HW;
+                ok[index] = index < ww && idx >= 0 && idx < (long)Tv;
+                int fi = kl - d + HW;
+                fi = fi < 0 ? 0 : (fi > kBuildTF + 2 * HW - 1 ? kBuildTF + 2 * HW - 1 : fi);
                 const uint64_t pi = (uint64_t)(f_state[fi] * (uint32_t)WL + mo);
-                const double mean = mnt[pi];
+                mv[index] = mnt[pi];
                 double ivar = ivt[pi];
                 // dynamic windows touching an MSD boundary get ivar = 0 (mod.rs:69-80)
                 if (w != 0 && ((int)f_l[fi] < lw || (int)f_r[fi] < rw))
                     ivar = 0.0;
-                const double wu = cf[index] * ivar;
-                wum += wu * mean;
+                iv[index] = ivar;
+            }
+#pragma unroll
+            for (int index = 2; index >= 0; index--) {
+                const double wu = ok[index] ? cf[index] * iv[index] : 0.0;
+                wum += wu * mv[index];
                 bool live = true; // the reference leaves the inner loop at the first tap past the end
 #pragma unroll
                 for (int inner = 2; inner >= 0; inner--) {
-                    if (inner < index || inner >= ww || cf[inner] == 0.0)
+                    if (inner < index)
                         continue;
                     const int j = inner - index;
-                    if ((uint64_t)k + (uint64_t)j >= Tv)
+                    // (a zero coefficient is skipped BEFORE the end test in the reference)
+                    if (cf[inner] != 0.0 && inner < ww && (uint64_t)k + (uint64_t)j >= Tv)
                         live = false;
                     if (live)
                         wuw[j] += wu * cf[inner];

@@ -458,18 +458,22 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             if (lane <= 2 * H) {
                 const int m = p - H + lane;
                 const long g = n0 + m;
+                const bool in = g >= 0 && g < N;
+                // unconditional loads at clamped positions, selected afterwards (loads nested in
+                // the edge / voicing tests would be waited for one after the other)
+                const long gc = in ? g : n0;
+                const int df = !in ? 0 : (m < 0 ? -1 : (m >= fp ? 1 : 0));
+                const uint64_t ff = (uint64_t)((long)f + df);
+                const int i = in ? m - df * fp : 0;
+                const bool vo = vd.voiced[ff] != 0;
+                const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
+                const double pinc = vd.pinc[ff], cur = vd.cur_start[ff], nv = vd.noise[gc];
                 double ev = 0.0;
-                if (g >= 0 && g < N) {
-                    const int df = m < 0 ? -1 : (m >= fp ? 1 : 0);
-                    const uint64_t ff = (uint64_t)((long)f + df);
-                    const int i = m - df * fp;
-                    if (vd.voiced[ff]) {
-                        const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
-                        double pulse = 0.0;
-                        if ((pm >> (i % bs)) & 1ull)
-                            pulse = sqrt(fma((double)i, vd.pinc[ff], vd.cur_start[ff]));
-                        ev = pulse - vd.noise[g];
-                    }
+                if (in && vo) {
+                    double pulse = 0.0;
+                    if ((pm >> (i % bs)) & 1ull)
+                        pulse = sqrt(fma((double)i, pinc, cur));
+                    ev = pulse - nv;
                 }
                 es[lane] = ev;
             }
