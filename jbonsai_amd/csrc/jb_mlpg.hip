@@ -24,6 +24,9 @@
 #include "jb_device.h"
 
 #include <cstdlib>
+#ifndef JB_SIDE_PRIO
+#define JB_SIDE_PRIO 0 // s_setprio in the LF0-chain kernels: stretches the throughput kernels beside them
+#endif
 #include <type_traits>
 
 namespace jb {
@@ -1430,7 +1433,9 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
     const uint32_t gvl = sd.gvlen[b];
     if (n == 0 || !(sd.use_gv && st.gv_mean && gvl > 0))
         return;
+#if JB_SIDE_PRIO
     __builtin_amdgcn_s_setprio(3); // latency chain: do not take turns with throughput waves
+#endif
     const int L = sd.L;
     const uint64_t base = up->frame_off;
     const uint64_t o0 = base * (uint64_t)L + (uint64_t)m, Ls = (uint64_t)L;

@@ -28,6 +28,9 @@
 #include "jb_device.h"
 
 #include <cstdlib>
+#ifndef JB_SIDE_PRIO
+#define JB_SIDE_PRIO 0
+#endif
 #include <cstring>
 
 namespace jb {
@@ -103,7 +106,9 @@ __global__ void k_pulse(BatchDev bd, VocDev vd)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= vd.nruns[b])
         return;
+#if JB_SIDE_PRIO
     __builtin_amdgcn_s_setprio(3); // serial walk: do not take turns with throughput waves
+#endif
     const uint32_t t0 = vd.run_list[u.state_off + r];
     if (t0 >= u.T)
         return;
