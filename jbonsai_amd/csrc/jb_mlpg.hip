@@ -1690,17 +1690,16 @@ struct GvScal {
 
 // MODE 0: statistics of par (shift K = par[0]);  MODE 1: conv_gv rescale;  MODE 2: ascent
 // iteration `it` (1..5).  pass_in/pass_out index gv_part; stats == 0 skips the output sums.
-template <int MODE>
-__global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd, int si, int it,
-                                                       const double *__restrict__ src,
-                                                       double *__restrict__ dst, int stats)
+// IN: interior tile -- every frame of the tile, its two halo frames on either side and their
+// band neighbours exist, so all edge tests are compile-time true (12 of 13 tiles of a 25.5 k-frame
+// row): the kernel is instruction-issue bound (157 VALU + 111 SALU instructions per element-wave
+// with the guards), not traffic bound.
+template <int MODE, bool IN>
+__device__ __forceinline__ void gv_tp_body(const BatchDev &bd, const StreamDev &sd, int si, int it,
+                                           const double *__restrict__ src, double *__restrict__ dst,
+                                           int stats, const UttDev *up, uint32_t n, uint32_t gvl, int t0)
 {
     const int tile = blockIdx.x, m = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const UttDev *up = bd.utt + b;
-    const uint32_t n = sd.Tv[b], gvl = sd.gvlen[b];
-    const int t0 = tile * kGvTT;
-    if (n == 0 || gvl == 0 || (uint32_t)t0 >= n)
-        return;
     const StreamStatesDev st = up->st[si];
     if (!st.gv_mean)
         return;
@@ -1715,7 +1714,10 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
     // ---- every global load of the block is issued before anything waits on one ----
     // window arrays (frame t0 - 4 + i): par_old, A1, A2; own frames (t0 - 2 + i): A0, bvec, switch
     constexpr int KW = (kGvTT + 8 + kGvNT - 1) / kGvNT;
-    double pw[KW], a1w[KW], a2w[KW], a0r[kGvKX], br[kGvKX];
+    // (the off-diagonals A1[t-1], A2[t-2] a frame needs besides its own come straight from global
+    // memory -- the neighbouring lanes load the same lines -- instead of through LDS windows:
+    // half the LDS footprint, twice the blocks per CU)
+    double pw[KW], a0r[kGvKX], a1r[kGvKX], a2r[kGvKX], a1m[kGvKX], a2m[kGvKX], br[kGvKX];
     bool onr[kGvKX];
     double p_own[kGvTT / kGvNT];
     bool on_own[kGvTT / kGvNT];
@@ -1723,7 +1725,7 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
 #pragma unroll
         for (int k = 0; k < kGvTT / kGvNT; k++) {
             const uint32_t t = (uint32_t)t0 + (uint32_t)(tid + kGvNT * k);
-            const bool ok = t < n;
+            const bool ok = IN || t < n;
             p_own[k] = ok ? P[t] : 0.0;
             on_own[k] = ok && sw[t] != 0;
         }
@@ -1732,17 +1734,19 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
         for (int k = 0; k < KW; k++) {
             const int i = tid + kGvNT * k;
             const int t = t0 - 4 + i;
-            const bool ok = i < kGvTT + 8 && t >= 0 && (uint32_t)t < n;
+            const bool ok = i < kGvTT + 8 && (IN || (t >= 0 && (uint32_t)t < n));
             pw[k] = ok ? P[t] : 0.0;
-            a1w[k] = ok ? A1[t] : 0.0;
-            a2w[k] = ok ? A2[t] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < kGvKX; k++) {
             const int i = tid + kGvNT * k;
             const int t = t0 - 2 + i;
-            const bool ok = i < kGvTT + 4 && t >= 0 && (uint32_t)t < n;
+            const bool ok = i < kGvTT + 4 && (IN || (t >= 0 && (uint32_t)t < n));
             a0r[k] = ok ? A0[t] : 0.0;
+            a1r[k] = ok ? A1[t] : 0.0;
+            a2r[k] = ok ? A2[t] : 0.0;
+            a1m[k] = (ok && (IN || t >= 1)) ? A1[t - 1] : 0.0;
+            a2m[k] = (ok && (IN || t >= 2)) ? A2[t - 2] : 0.0;
             br[k] = ok ? Bv[t] : 0.0;
             onr[k] = ok && sw[t] != 0;
         }
@@ -1813,17 +1817,13 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
             }
         }
     } else {
-        // LDS windows: po = par_old[t0-4 .. t0+TT+4), pn = par_new[t0-2 .. t0+TT+2),
-        // a1s/a2s = A1/A2[t0-4 .. t0+TT+4)
-        __shared__ double po[kGvTT + 8], pn[kGvTT + 4], a1s[kGvTT + 8], a2s[kGvTT + 8];
+        // LDS windows: po = par_old[t0-4 .. t0+TT+4), pn = par_new[t0-2 .. t0+TT+2)
+        __shared__ double po[kGvTT + 8], pn[kGvTT + 4];
 #pragma unroll
         for (int k = 0; k < KW; k++) {
             const int i = tid + kGvNT * k;
-            if (i < kGvTT + 8) {
+            if (i < kGvTT + 8)
                 po[i] = pw[k];
-                a1s[i] = a1w[k];
-                a2s[i] = a2w[k];
-            }
         }
         __syncthreads();
         const double length = (double)n;
@@ -1835,7 +1835,7 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
         for (int k = 0; k < kGvKX; k++) {
             const int i = tid + kGvNT * k; // index into pn; frame t = t0 - 2 + i
             const int t = t0 - 2 + i;
-            if (i < kGvTT + 4 && t >= 0 && (uint32_t)t < n) {
+            if (i < kGvTT + 4 && (IN || (t >= 0 && (uint32_t)t < n))) {
                 const double p = po[i + 2];
                 const bool on = onr[k];
                 const double a0 = a0r[k], bb = br[k];
@@ -1845,14 +1845,14 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
                 } else {
                     // calc_hmmobj_derivative (mlpg.rs:205-229), the reference's order of additions
                     double g = a0 * p;
-                    if ((uint32_t)t + 1 < n)
-                        g += a1s[i + 2] * po[i + 3];
-                    if (t >= 1)
-                        g += a1s[i + 1] * po[i + 1];
-                    if ((uint32_t)t + 2 < n)
-                        g += a2s[i + 2] * po[i + 4];
-                    if (t >= 2)
-                        g += a2s[i] * po[i];
+                    if (IN || (uint32_t)t + 1 < n)
+                        g += a1r[k] * po[i + 3];
+                    if (IN || t >= 1)
+                        g += a1m[k] * po[i + 1];
+                    if (IN || (uint32_t)t + 2 < n)
+                        g += a2r[k] * po[i + 4];
+                    if (IN || t >= 2)
+                        g += a2m[k] * po[i];
                     // next_step (mlpg.rs:230-258)
                     const double h = -1.0 * wgt * a0 -
                                      1.0 * 2.0 / ll *
@@ -1874,7 +1874,7 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
         for (int k = 0; k < kGvKX; k++) {
             const int i = tid + kGvNT * k;
             const int t = t0 - 2 + i;
-            if (i >= 2 && i < kGvTT + 2 && (uint32_t)t < n) {
+            if (i >= 2 && i < kGvTT + 2 && (IN || (uint32_t)t < n)) {
                 const double p0 = pn[i];
                 Q[t] = p0;
                 if (stats) {
@@ -1884,14 +1884,14 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
                         s2 += dlt * dlt;
                     }
                     double g = a0r[k] * p0;
-                    if ((uint32_t)t + 1 < n)
-                        g += a1s[i + 2] * pn[i + 1];
-                    if (t >= 1)
-                        g += a1s[i + 1] * pn[i - 1];
-                    if ((uint32_t)t + 2 < n)
-                        g += a2s[i + 2] * pn[i + 2];
-                    if (t >= 2)
-                        g += a2s[i] * pn[i - 2];
+                    if (IN || (uint32_t)t + 1 < n)
+                        g += a1r[k] * pn[i + 1];
+                    if (IN || t >= 1)
+                        g += a1m[k] * pn[i - 1];
+                    if (IN || (uint32_t)t + 2 < n)
+                        g += a2r[k] * pn[i + 2];
+                    if (IN || t >= 2)
+                        g += a2m[k] * pn[i - 2];
                     hh += 1.0 * wgt * p0 * (br[k] - 0.5 * g);
                 }
             }
@@ -1926,6 +1926,23 @@ __global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd,
         po_[1] = r1;
         po_[2] = r2;
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kGvNT) void k_mlpg_gv_tp(BatchDev bd, StreamDev sd, int si, int it,
+                                                       const double *__restrict__ src,
+                                                       double *__restrict__ dst, int stats)
+{
+    const int b = blockIdx.z;
+    const UttDev *up = bd.utt + b;
+    const uint32_t n = sd.Tv[b], gvl = sd.gvlen[b];
+    const int t0 = blockIdx.x * kGvTT;
+    if (n == 0 || gvl == 0 || (uint32_t)t0 >= n)
+        return;
+    if (t0 >= 4 && (uint32_t)t0 + kGvTT + 4 <= n)
+        gv_tp_body<MODE, true>(bd, sd, si, it, src, dst, stats, up, n, gvl, t0);
+    else
+        gv_tp_body<MODE, false>(bd, sd, si, it, src, dst, stats, up, n, gvl, t0);
 }
 
 // A9 for the [dim][frame] workspace: `out` is [frame][dim], so this is a tiled transpose
