@@ -196,3 +196,48 @@ def test_linearity_in_volume_and_idempotence(ctx):
     vi2 = J.VoiceInfo(vi.sampling_frequency, vi.fperiod, vi.alpha, vi.streams, volume=0.25)
     q, _ = run(vi2, [u])
     assert np.array_equal(q[0], p1 * 0.25)
+
+
+@pytest.mark.parametrize("L2", [25, 50])
+def test_other_spectral_orders(ctx, L2):
+    """Voices with another mel-cepstral order (the reference is generic in it): the MCP stream of
+    a synthetic utterance is cut to 25 dims (the lane-triple kernel's second specialisation) or
+    widened to 50 (LDS-staged solve with LMAX=64, 5 taps per lane in the wave kernel, [dim][frame]
+    build at L=50) by dropping / appending small-variance dimensions per window.  HIP vs oracle."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    rng = np.random.default_rng(7)
+    T = 700
+    u = synth.synth_utterance(tab, T, 3)
+    L = vi.streams[0].vector_length
+    W = len(vi.streams[0].windows)
+    m0 = u.streams[0]
+    S = len(u.durations)
+
+    def reshape(a, fill):
+        a = a.reshape(S, W, L)
+        if L2 <= L:
+            return a[:, :, :L2].reshape(S, W * L2).copy()
+        extra = fill((S, W, L2 - L))
+        return np.concatenate([a, extra], axis=2).reshape(S, W * L2)
+
+    mean = reshape(m0.mean, lambda sh: 0.02 * rng.standard_normal(sh))
+    var = reshape(m0.var, lambda sh: 0.01 + 0.01 * rng.random(sh))
+    gvm = m0.gv_mean[:L2] if L2 <= L else np.concatenate([m0.gv_mean, np.full(L2 - L, 4e-4)])
+    gvv = m0.gv_var[:L2] if L2 <= L else np.concatenate([m0.gv_var, np.full(L2 - L, 1e-8)])
+    s0 = dataclasses.replace(m0, mean=mean, var=var, gv_mean=gvm, gv_var=gvv)
+    u2 = J.Utterance(u.durations, [s0, u.streams[1], u.streams[2]])
+    st0 = dataclasses.replace(vi.streams[0], vector_length=L2)
+    vi2 = dataclasses.replace(vi, streams=[st0, vi.streams[1], vi.streams[2]])
+    ref, tr = oracle_pcm(vi2, u2)
+    assert np.isfinite(ref).all()
+    for kw in (dict(keep_tracks=True), dict(chunk_frames=64, kernel="pair")):
+        with J.Batch(vi2, [u2, u2], **kw) as b:
+            b.run()
+            b.sync()
+            got = [b.pcm(0), b.pcm(1)]
+            if kw.get("keep_tracks"):
+                np.testing.assert_allclose(b.track(0, 0), tr[0], rtol=1e-12, atol=1e-13)
+        assert np.array_equal(got[0], got[1])
+        assert rel_rms(got[0], ref) <= 1e-9, (L2, kw)
