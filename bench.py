@@ -124,8 +124,18 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # JB_BENCH_REHEARSE=1: rehearsal of the multi-rank path on a ONE-GPU box -- every rank uses
+    # device 0 and the collectives run over gloo on host tensors (RCCL refuses two ranks on one
+    # device).  Numbers from such a run mean nothing; it only exercises the code path.
+    rehearse = os.environ.get("JB_BENCH_REHEARSE", "0") != "0"
+    if rehearse:
+        local_rank = 0
+    if world > 1:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -176,12 +186,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     gather_ms = None
-    if args.gather and dist is not None:
+    if args.gather and dist is not None and not rehearse:
         # optional sink of north_star: PCM of all ranks on GPU 0.  The slab is library-owned device
         # memory viewed zero-copy; rank 0 needs world x 12.6 GB of HBM for config 2.
         slab = pcm_slab_tensor(batch)
