@@ -1375,6 +1375,11 @@ __global__ __launch_bounds__(64) void k_voc_verify(const VocWork *__restrict__ w
         bad[i] = isbad;
         if (isbad)
             atomicAdd(n_bad, 1u);
+#ifdef JB_VERIFY_DEBUG
+        if (isbad)
+            printf("handoff item %u utt %u t_out %u: max|diff| %.3e max|state| %.3e ratio %.3e\n", i, wk.utt,
+                   wk.t_out, md, mr, md / mr);
+#endif
     }
 }
 
