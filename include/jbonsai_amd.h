@@ -207,6 +207,9 @@ size_t jb_batch_pcm_offset(const jb_batch *b, size_t utt);
  * vocoder work items, and how many chunks failed the hand-off check and were redone. */
 int jb_batch_info(const jb_batch *b, uint32_t *chunk_frames, uint32_t *warmup_frames,
                   uint32_t *n_items, uint32_t *n_redo);
+/* Of the chunks that failed the hand-off check in the last run: how many were settled by
+ * recomputing only up to their checkpoint (48 frames) and how many had to be recomputed to the end. */
+int jb_batch_redo_stats(const jb_batch *b, uint32_t *n_partial, uint32_t *n_full);
 void jb_batch_free(jb_batch *b);
 
 /* One-shot convenience: create + run + read + free.  pcm[i] must hold

@@ -183,6 +183,12 @@ class Batch:
         F.check(self._L.jb_batch_read_excitation(self._h, i, out.ctypes.data, n))
         return out
 
+    def redo_stats(self):
+        """(settled at the checkpoint, recomputed to the end) of the chunks that failed the hand-off check."""
+        a, b = C.c_uint32(), C.c_uint32()
+        F.check(self._L.jb_batch_redo_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def device_pcm(self):
         n = C.c_size_t()
         p = self._L.jb_batch_device_pcm(self._h, C.byref(n))

@@ -726,8 +726,10 @@ int Batch::build_work(const jb_batch_opts *opts)
     if (ch != 0) {
         // zeroed: slots of the state layout that a kernel does not write must compare equal
         if ((rc = dalloc(&end_state, (size_t)n_items * stride, true)) ||
-            (rc = dalloc(&warm_state, (size_t)n_items * stride, true)))
+            (rc = dalloc(&warm_state, (size_t)n_items * stride, true)) ||
+            (rc = dalloc(&ckpt_state, (size_t)n_items * stride, true)))
             return rc;
+        state_stride = stride;
         for (uint32_t k = 0; k < n_items; k++) {
             VocWork &w = work[k];
             const bool first = w.t_out == 0;
@@ -736,6 +738,9 @@ int Batch::build_work(const jb_batch_opts *opts)
                 continue;
             w.save_end = end_state + (size_t)k * stride;
             w.save_warm = first ? nullptr : warm_state + (size_t)k * stride;
+            // checkpoint for the partial redo: only where it saves at least half the chunk
+            w.save_ckpt = (!first && w.t_end - w.t_out >= 2 * kVocCkptFrames) ? ckpt_state + (size_t)k * stride
+                                                                              : nullptr;
         }
     }
     if (n_items)
@@ -906,36 +911,99 @@ int Batch::finish_verify()
     if ((e = hipMemcpy(bad.data(), bad_dev, n_items, hipMemcpyDeviceToHost)) != hipSuccess)
         return hip_fail(e, "hipMemcpy(bad)");
     // rounds: every failing chunk whose predecessor is final (not itself pending) is
-    // recomputed in the same launch; runs of consecutive failures take one round each
-    if (!redo_dev) {
-        int rc = dalloc(&redo_dev, n_items, false);
-        if (rc)
-            return rc;
-    }
+    // recomputed in the same launch; runs of consecutive failures take one round each.
+    // A chunk with a checkpoint is first recomputed only up to it (kVocCkptFrames frames): if the
+    // recomputed state meets the checkpoint the original chunk left there, the rest of that chunk
+    // was computed from a trajectory that had already converged and stands; otherwise the
+    // recomputation continues from there to the end of the chunk.
+    n_redo_partial = n_redo_full = 0;
+    const size_t stride = state_stride;
+    int rc;
+    if (!redo_dev && (rc = dalloc(&redo_dev, n_items, false)))
+        return rc;
+    if (!tmp_state && ((rc = dalloc(&tmp_state, (size_t)n_items * stride, true)) ||
+                       (rc = dalloc(&pairs_dev, 2 * (size_t)n_items, false))))
+        return rc;
+    auto run_round = [&](const std::vector<VocWork> &round) -> int {
+        if (round.empty())
+            return JB_OK;
+        hipError_t he;
+        if ((he = hipMemcpy(redo_dev, round.data(), sizeof(VocWork) * round.size(), hipMemcpyHostToDevice)) !=
+            hipSuccess)
+            return hip_fail(he, "hipMemcpy(redo)");
+        if ((he = launch_vocoder(bd, vd, redo_dev, (uint32_t)round.size(), stream_voc)) != hipSuccess)
+            return hip_fail(he, "k_vocoder(redo)");
+        if ((he = hipStreamSynchronize(stream_voc)) != hipSuccess)
+            return hip_fail(he, "redo sync");
+        return JB_OK;
+    };
     std::vector<uint8_t> pending(bad);
     pending[0] = 0;
     for (;;) {
-        std::vector<VocWork> round;
         std::vector<uint32_t> ids;
-        for (uint32_t k = 1; k < n_items; k++) {
-            if (!pending[k] || pending[k - 1])
-                continue;
+        for (uint32_t k = 1; k < n_items; k++)
+            if (pending[k] && !pending[k - 1])
+                ids.push_back(k);
+        if (ids.empty())
+            break;
+        // stage A: up to the checkpoint (or the whole chunk where there is none)
+        std::vector<VocWork> round;
+        std::vector<uint32_t> part; // positions in ids with a checkpoint
+        for (size_t j = 0; j < ids.size(); j++) {
+            const uint32_t k = ids[j];
             VocWork w = work[k];
             w.t_start = w.t_out;
             w.load_state = work[k - 1].save_end;
             w.save_warm = nullptr;
+            if (w.save_ckpt) {
+                w.t_end = w.t_out + kVocCkptFrames;
+                w.save_end = tmp_state + (size_t)k * stride;
+                part.push_back((uint32_t)j);
+            } else {
+                n_redo_full++;
+            }
+            w.save_ckpt = nullptr;
             round.push_back(w);
-            ids.push_back(k);
         }
-        if (round.empty())
-            break;
-        if ((e = hipMemcpy(redo_dev, round.data(), sizeof(VocWork) * round.size(),
-                           hipMemcpyHostToDevice)) != hipSuccess)
-            return hip_fail(e, "hipMemcpy(redo)");
-        if ((e = launch_vocoder(bd, vd, redo_dev, (uint32_t)round.size(), stream_voc)) != hipSuccess)
-            return hip_fail(e, "k_vocoder(redo)");
-        if ((e = hipStreamSynchronize(stream_voc)) != hipSuccess)
-            return hip_fail(e, "redo sync");
+        if ((rc = run_round(round)))
+            return rc;
+        // does the recomputed state meet the checkpoint?
+        if (!part.empty()) {
+            std::vector<const double *> pairs(2 * part.size());
+            for (size_t q = 0; q < part.size(); q++) {
+                const uint32_t k = ids[part[q]];
+                pairs[2 * q] = tmp_state + (size_t)k * stride;
+                pairs[2 * q + 1] = work[k].save_ckpt;
+            }
+            hipMemcpy(pairs_dev, pairs.data(), sizeof(double *) * pairs.size(), hipMemcpyHostToDevice);
+            hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
+            if ((e = launch_voc_verify_pairs(pairs_dev, (uint32_t)part.size(), vd.state_stride, vd.nmcp - 1, verify_tol, bad_dev,
+                                             nbad_dev, stream_voc)) != hipSuccess)
+                return hip_fail(e, "k_voc_verify_pairs");
+            std::vector<uint8_t> bad2(part.size());
+            if ((e = hipMemcpyAsync(bad2.data(), bad_dev, part.size(), hipMemcpyDeviceToHost, stream_voc)) !=
+                    hipSuccess ||
+                (e = hipStreamSynchronize(stream_voc)) != hipSuccess)
+                return hip_fail(e, "hipMemcpy(bad2)");
+            // stage B: the rest of the chunks that had not converged at their checkpoint
+            std::vector<VocWork> rest;
+            for (size_t q = 0; q < part.size(); q++) {
+                const uint32_t k = ids[part[q]];
+                if (!bad2[q]) {
+                    n_redo_partial++;
+                    continue;
+                }
+                n_redo_full++;
+                VocWork w = work[k];
+                w.t_start = w.t_out = work[k].t_out + kVocCkptFrames;
+                w.load_state = tmp_state + (size_t)k * stride;
+                w.save_warm = nullptr;
+                w.save_ckpt = nullptr;
+                rest.push_back(w);
+            }
+            if ((rc = run_round(rest)))
+                return rc;
+        }
         for (uint32_t k : ids)
             pending[k] = 0;
     }
@@ -1230,6 +1298,18 @@ int jb_batch_info(const jb_batch *hb, uint32_t *chunk_frames, uint32_t *warmup_f
         *n_items = b->n_items;
     if (n_redo)
         *n_redo = b->n_redo;
+    return JB_OK;
+}
+
+int jb_batch_redo_stats(const jb_batch *hb, uint32_t *n_partial, uint32_t *n_full)
+{
+    const Batch *b = (const Batch *)hb;
+    if (!b)
+        return JB_ERR_INVALID;
+    if (n_partial)
+        *n_partial = b->n_redo_partial;
+    if (n_full)
+        *n_full = b->n_redo_full;
     return JB_OK;
 }
 

@@ -118,7 +118,11 @@ struct VocWork {
     const double *load_state; // exact continuation (streaming / re-do), or nullptr
     double *save_warm;        // state on entering t_out (after warm-up), or nullptr
     double *save_end;         // state after t_end, or nullptr
+    double *save_ckpt;        // state on entering frame t_out + kVocCkptFrames, or nullptr (partial redo)
 };
+// A failing chunk is first recomputed only up to this many frames past its start; if the recomputed
+// state meets the checkpoint the original chunk left there, the rest of the chunk stands.
+constexpr uint32_t kVocCkptFrames = 48;
 
 struct BatchDev {
     int B;
@@ -180,5 +184,8 @@ hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork
 hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, double tol,
                              uint8_t *bad, uint32_t *n_bad, hipStream_t stream);
 int vocoder_state_doubles(int nmcp);
+// bad[j] = 1 (and ++*n_bad) when states pairs[2j] and pairs[2j+1] differ by more than tol * max|state|
+hipError_t launch_voc_verify_pairs(const double *const *pairs_dev, uint32_t n_pairs, int state_doubles, int ntaps,
+                                   double tol, uint8_t *bad, uint32_t *n_bad, hipStream_t stream);
 
 } // namespace jb

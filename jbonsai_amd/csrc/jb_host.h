@@ -57,6 +57,10 @@ struct Batch {
     uint32_t n_items = 0, chunk_frames = 0, warmup_frames = 0, n_redo = 0;
     double verify_tol = 1e-9;
     double *end_state = nullptr, *warm_state = nullptr;
+    double *ckpt_state = nullptr, *tmp_state = nullptr; // partial redo: checkpoints / recomputed states
+    const double **pairs_dev = nullptr;
+    uint32_t n_redo_partial = 0, n_redo_full = 0;   // of the last run: settled at the checkpoint / redone to the end
+    size_t state_stride = 0;
     uint8_t *bad_dev = nullptr;
     uint32_t *nbad_dev = nullptr;
     bool verify_pending = false;

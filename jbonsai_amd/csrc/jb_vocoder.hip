@@ -663,6 +663,8 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
         const bool emit = t >= t_out; // warm-up frames are computed but not stored
         if (t == t_out && t_out > t_begin && wk.save_warm)
             save_state(wk.save_warm);
+        if (t == t_out + kVocCkptFrames && wk.save_ckpt)
+            save_state(wk.save_ckpt);
         // ---- frame setup (vocoder/mod.rs:116-125) ----
         // c at frame start = previous frame's cc exactly (mod.rs:140); first frame: c = cc.
         const double *bcur = vd.bcoef + f * (uint64_t)nmcp;
@@ -890,6 +892,11 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
             double *sw_ = work[item].save_warm;
             if (sw_)
                 save_state(sw_);
+        }
+        if (act && t == wk.t_out + kVocCkptFrames) {
+            double *sc_ = work[item].save_ckpt;
+            if (sc_)
+                save_state(sc_);
         }
         // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
         // the two lanes of a pair fill alternate taps
@@ -1160,6 +1167,11 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             if (sw_)
                 save_state(sw_);
         }
+        if (act && t == wk.t_out + kVocCkptFrames) {
+            double *sc_ = work[item].save_ckpt;
+            if (sc_)
+                save_state(sc_);
+        }
         // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
         // the three lanes of a triple fill every third tap
         __syncthreads();
@@ -1383,6 +1395,53 @@ __global__ __launch_bounds__(64) void k_voc_verify(const VocWork *__restrict__ w
     }
 }
 
+// same comparison for explicit pairs of states (partial redo: recomputed state vs checkpoint)
+__global__ __launch_bounds__(64) void k_voc_verify_pairs(const double *const *__restrict__ pairs, uint32_t n_pairs,
+                                                          int nfilt, int ntaps, double tol, uint8_t *bad,
+                                                          uint32_t *n_bad)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= n_pairs)
+        return;
+    const int lane = threadIdx.x;
+    const double *a = pairs[2 * i], *r = pairs[2 * i + 1];
+    double md = 0.0, mr = 0.0;
+    // The two dumps may come from different kernels (checkpoint: throughput kernel, recomputed
+    // state: wave kernel).  They agree on everything that is carried state; the wave kernel also
+    // leaves values in slots that are not: the u row holds per-lane temporaries except at the head
+    // lane of each 12-lane stage segment, and the tap slots past the last tap (12 groups x TPL
+    // slots for ntaps taps) and of lanes 60..63 carry the remainder through.  Those are skipped.
+    const int urow = nfilt - 76; // 64*TPL: start of the u row (layout: d[TPL][64] | u[64] | e11[6] | e12[6])
+    const int tpl = urow / 64;
+    for (int k = lane; k < nfilt; k += 64) {
+        if (k < urow) {
+            const int ln = k & 63, kk = k >> 6;
+            if (ln >= kGroups * kPade || (ln % kGroups) * tpl + kk >= ntaps)
+                continue;
+        } else if (k < urow + 64 && ((k - urow) % kGroups != 0 || (k - urow) >= kGroups * kPade)) {
+            continue;
+        }
+        const double x = a[k], y = r[k];
+        md = fmax(md, fabs(x - y));
+        mr = fmax(mr, fabs(y));
+        if (!(x == x) || !(y == y))
+            md = 1e300;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        md = fmax(md, __shfl_xor(md, o));
+        mr = fmax(mr, __shfl_xor(mr, o));
+    }
+    if (lane == 0) {
+        const bool isbad = md > tol * mr && md > 1e-300;
+        bad[i] = isbad;
+        if (isbad)
+            atomicAdd(n_bad, 1u);
+#ifdef JB_VERIFY_DEBUG
+        printf("checkpoint pair %u: max|diff| %.3e max|state| %.3e %s\n", i, md, mr, isbad ? "FAIL" : "ok");
+#endif
+    }
+}
+
 static int tpl_for(int nmcp)
 {
     int M = nmcp - 1;
@@ -1475,6 +1534,16 @@ hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int stat
         return hipSuccess;
     hipLaunchKernelGGL(k_voc_verify, dim3(n_items), dim3(64), 0, stream, work_dev, n_items,
                        state_doubles - 4, tol, bad, n_bad);
+    return hipGetLastError();
+}
+
+hipError_t launch_voc_verify_pairs(const double *const *pairs_dev, uint32_t n_pairs, int state_doubles, int ntaps,
+                                   double tol, uint8_t *bad, uint32_t *n_bad, hipStream_t stream)
+{
+    if (n_pairs == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(k_voc_verify_pairs, dim3(n_pairs), dim3(64), 0, stream, pairs_dev, n_pairs,
+                       state_doubles - 4, ntaps, tol, bad, n_bad);
     return hipGetLastError();
 }
 

@@ -137,6 +137,23 @@ def test_time_parallel_gv_is_deterministic_and_tiled(oracle_voice, have_gpu):
         np.testing.assert_allclose(res[0][i], ref, rtol=1e-12, atol=1e-13)
 
 
+@pytest.fixture(scope="module")
+def ctx_long():
+    """A 6000-frame synthetic utterance (seed 52: it has slowly decaying stretches, tools/warmup_sweep.py)."""
+    from jbonsai_amd import synth
+    from tests.conftest import VOICE
+
+    eng = J.Engine.load([VOICE])
+    return eng.voice_info(), synth.synth_utterance(synth.VoiceTables(eng), 6000, 52)
+
+
+def _run_vi(vi, utts, **kw):
+    with J.Batch(vi, utts, **kw) as b:
+        b.run()
+        b.sync()
+        return [b.pcm(i) for i in range(len(utts))], b.info()
+
+
 def _run(v, utts, **kw):
     with J.Batch(voice_info(v), utts, **kw) as b:
         b.run()
@@ -178,6 +195,33 @@ def test_chunk_handoff_check_triggers_redo(oracle_voice, have_gpu):
     # and with the check effectively disabled the truncated warm-up is visible
     bad, info2 = _run(v, utts, chunk_frames=64, warmup_frames=1, verify_tol=1e30)
     assert info2["n_redo"] == 0 and rel_rms(bad[0], ser[0]) > 1e-6
+
+
+def test_partial_redo_at_checkpoint(ctx_long, have_gpu):
+    """Chunks of >= 96 frames leave a checkpoint state 48 frames in.  A failing chunk is first
+    recomputed only up to it; where the recomputed state meets the checkpoint the rest of the
+    chunk stands (certified to the same tolerance as an ordinary hand-off), elsewhere the
+    recomputation runs on to the end.  With a 6-frame warm-up most hand-offs fail; both outcomes
+    must occur and the PCM must match the serial recursion to the hand-off tolerance."""
+    vi, u = ctx_long
+    ser, _ = _run_vi(vi, [u], serial=True)
+    for kern in ("wave", "pair"):
+        with J.Batch(vi, [u, u], chunk_frames=160, warmup_frames=6, verify_tol=1e-9, kernel=kern) as b:
+            b.run()
+            b.sync()
+            info, (n_part, n_full) = b.info(), b.redo_stats()
+            out = [b.pcm(0), b.pcm(1)]
+        assert info["n_redo"] >= 10 and n_part >= 2 and n_part + n_full == info["n_redo"], (info, n_part, n_full)
+        assert np.array_equal(out[0], out[1])
+        e = rel_rms(out[0], ser[0])
+        print(kern, "hand-offs failing", info["n_redo"], "settled at checkpoint", n_part, "to the end", n_full,
+              "rel RMS vs serial", e)
+        assert e <= 1e-9
+    # 32-frame warm-up, the default-like case: whatever fails, the result stays certified
+    with J.Batch(vi, [u], chunk_frames=136, warmup_frames=32, kernel="pair") as b:
+        b.run()
+        b.sync()
+        assert rel_rms(b.pcm(0), ser[0]) <= 1e-9
 
 
 def test_pair_kernel_equals_wave_kernel_and_oracle(oracle_voice, have_gpu):
