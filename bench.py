@@ -105,6 +105,9 @@ def main():
                     help="CUs per XCD (of 32) given to parameter generation when two batches are in "
                          "flight; the vocoder gets the rest (jb_batch_opts.mlpg_cus_per_xcd); "
                          "-1 = default (0 with --pipeline 1)")
+    ap.add_argument("--distinct", type=int, default=1,
+                    help="number of DISTINCT synthetic utterances tiled over the batch (default 1 = BASELINE "
+                         "config 2's copies of one utterance); >1 shows the cost of real hand-off failures")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
                          "(torch.distributed gather over xGMI) and report its time as gather_ms; "
@@ -150,9 +153,12 @@ def main():
     # every utterance of the batch is the same sequence (BASELINE config 2: "256 copies"),
     # uploaded once and aliased; outputs / workspace / filter state are per utterance
     utt = synth.synth_utterance(tab, frames, 0)
+    nd = max(1, min(args.distinct, args.batch))
+    utts = [utt] + [synth.synth_utterance(tab, frames, 1000 + i) for i in range(1, nd)]
     depth = max(1, args.pipeline)
     cu_split = args.cu_split if args.cu_split >= 0 else (DEFAULT_CU_SPLIT if depth > 1 else 0)
-    batches = [J.Batch(vi, [utt] * args.batch, device=local_rank, mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
+    batches = [J.Batch(vi, [utts[i % nd] for i in range(args.batch)], device=local_rank,
+                       mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
     batch = batches[0]
     samples_per_step = batch.total_samples
 
@@ -230,7 +236,8 @@ def main():
                             "utterance from real nitech pdfs (BASELINE config 2), nitech voice",
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
                 "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
-                "batches_in_flight": depth, "mlpg_cus_per_xcd": cu_split,
+                "batches_in_flight": depth, "mlpg_cus_per_xcd": cu_split, "distinct_utterances": nd,
+                "chunks_settled_at_checkpoint_last_step": batch.redo_stats()[0],
                 "vocoder_chunk_frames": info["chunk_frames"], "vocoder_warmup_frames": info["warmup_frames"],
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
