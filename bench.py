@@ -108,6 +108,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=1,
                     help="number of DISTINCT synthetic utterances tiled over the batch (default 1 = BASELINE "
                          "config 2's copies of one utterance); >1 shows the cost of real hand-off failures")
+    ap.add_argument("--mixed", action="store_true",
+                    help="BASELINE config 3's per-GPU share instead of config 2: --batch distinct utterances "
+                         "of seed-fixed lengths U[400, 25546] frames (synth.mixed_lengths); not the headline line")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
                          "(torch.distributed gather over xGMI) and report its time as gather_ms; "
@@ -157,8 +160,12 @@ def main():
     utts = [utt] + [synth.synth_utterance(tab, frames, 1000 + i) for i in range(1, nd)]
     depth = max(1, args.pipeline)
     cu_split = args.cu_split if args.cu_split >= 0 else (DEFAULT_CU_SPLIT if depth > 1 else 0)
-    batches = [J.Batch(vi, [utts[i % nd] for i in range(args.batch)], device=local_rank,
-                       mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
+    if args.mixed:
+        lens = synth.mixed_lengths(args.batch, seed=3 + rank)
+        batch_utts = [synth.synth_utterance(tab, T, 2000 + i) for i, T in enumerate(lens)]
+    else:
+        batch_utts = [utts[i % nd] for i in range(args.batch)]
+    batches = [J.Batch(vi, batch_utts, device=local_rank, mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
     batch = batches[0]
     samples_per_step = batch.total_samples
 
@@ -231,9 +238,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": f"batch={args.batch}/GPU copies of a {frames}-frame "
-                            f"({frames * vi.fperiod / vi.sampling_frequency:.1f} s) synthetic state-level "
-                            "utterance from real nitech pdfs (BASELINE config 2), nitech voice",
+                "workload": (f"batch={args.batch}/GPU distinct synthetic state-level utterances of mixed length "
+                             "U[400, 25546] frames from real nitech pdfs (BASELINE config 3 share), nitech voice"
+                             if args.mixed else
+                             f"batch={args.batch}/GPU copies of a {frames}-frame "
+                             f"({frames * vi.fperiod / vi.sampling_frequency:.1f} s) synthetic state-level "
+                             "utterance from real nitech pdfs (BASELINE config 2), nitech voice"),
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
                 "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
                 "batches_in_flight": depth, "mlpg_cus_per_xcd": cu_split, "distinct_utterances": nd,
