@@ -40,9 +40,9 @@ namespace jb {
 // ballot/readlane, ~15 instructions per state instead of three dependent global loads.
 __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, int si)
 {
-    const int b = blockIdx.x;
-    if (b >= bd.B)
+    if ((int)blockIdx.x >= bd.B)
         return;
+    const int b = (int)bd.order[blockIdx.x]; // longest utterance first
     const int lane = threadIdx.x;
     const UttDev *up = bd.utt + b;
     const StreamStatesDev st = up->st[si];
@@ -1288,7 +1288,8 @@ template <int LMAX>
 __global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd, int si)
 {
     extern __shared__ double lds[];
-    const int b = blockIdx.x;
+    const int b = (int)bd.order[blockIdx.x]; // longest utterance first: the serial sweeps of a ragged
+                                             // batch end together instead of with a late long one
     const UttDev *up = bd.utt + b;
     const uint32_t n = sd.Tv[b];
     if (n == 0)
@@ -1426,7 +1427,7 @@ __device__ __forceinline__ double serial_add_lds(double acc, const double *buf)
 template <bool NONMSD>
 __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, int si)
 {
-    const int m = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int m = blockIdx.x, b = (int)bd.order[blockIdx.y], lane = threadIdx.x; // longest first
     const UttDev *up = bd.utt + b;
     const StreamStatesDev st = up->st[si];
     const uint32_t n = sd.Tv[b];

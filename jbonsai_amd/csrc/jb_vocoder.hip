@@ -101,7 +101,7 @@ __global__ void k_pulse(BatchDev bd, VocDev vd)
 {
     // one lane per voiced run (compact run list from k_prep_states of the LF0 stream); a
     // thread per frame would leave ~2 of 64 lanes working
-    const int b = blockIdx.y;
+    const int b = (int)bd.order[blockIdx.y]; // longest utterance first
     const UttDev u = bd.utt[b];
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= vd.nruns[b])
