@@ -669,7 +669,9 @@ int Batch::build_work(const jb_batch_opts *opts)
     uint32_t ch = opts ? opts->chunk_frames : 0;
     // lane-pair throughput kernel: worth it once the batch holds enough frames to give
     // every SIMD 32 chunks that are long against the warm-up
-    uint64_t lp_min = 1500000;
+    // (measured crossover against the wave kernel: between 4 and 8 utterances of 25.5 k frames,
+    // tools/ab_lpmin.sh)
+    uint64_t lp_min = 150000;
     if (const char *e = getenv("JB_LP_MIN_FRAMES"))
         lp_min = strtoull(e, nullptr, 10);
     lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vocoder_ls_supported(vd.nmcp) &&
@@ -682,7 +684,14 @@ int Batch::build_work(const jb_batch_opts *opts)
         if (const char *e = getenv("JB_LP_TARGET"))
             target = strtoull(e, nullptr, 10);
         uint64_t c = (sumT + target - 1) / target;
-        ch = (uint32_t)std::max<uint64_t>(c, 2ull * warmup_frames);
+        // while the batch cannot fill the chip the time of the launch is that of ONE chunk
+        // (chunk + warm-up frames), but shorter chunks also mean more hand-off positions and more
+        // of them failing the check: below 2x the warm-up the redo rounds cost what the shorter
+        // chunks save (tools/ab_chmin.sh)
+        uint64_t cmin = 2ull * warmup_frames;
+        if (const char *e = getenv("JB_CHUNK_MIN"))
+            cmin = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
+        ch = (uint32_t)std::max<uint64_t>(c, cmin);
         ch = (ch + 3) / 4 * 4;
     } else if (ch == 0) {
         // auto: enough items to fill 1024 SIMDs several waves deep, chunks >= 4x the warm-up
