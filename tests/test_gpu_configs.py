@@ -241,3 +241,28 @@ def test_other_spectral_orders(ctx, L2):
                 np.testing.assert_allclose(b.track(0, 0), tr[0], rtol=1e-12, atol=1e-13)
         assert np.array_equal(got[0], got[1])
         assert rel_rms(got[0], ref) <= 1e-9, (L2, kw)
+
+
+def test_five_point_delta_windows(ctx):
+    """Voices with 5-point delta / acceleration windows (max_width 2 => band width 5): the generic
+    band solver and build (`k_mlpg_solve<5>`, [frame][dim] workspace) on all three streams' shapes
+    (MCP with GV, MSD LF0 with GV) against the oracle, tracks and PCM."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    u = synth.synth_utterance(tab, 900, 11)
+    w5 = [[1.0], [-0.2, -0.1, 0.0, 0.1, 0.2], [0.285714, -0.142857, -0.285714, -0.142857, 0.285714]]
+    streams = [dataclasses.replace(vi.streams[0], windows=w5), dataclasses.replace(vi.streams[1], windows=w5),
+               vi.streams[2]]
+    vi5 = dataclasses.replace(vi, streams=streams)
+    ref, tr = oracle_pcm(vi5, u)
+    assert np.isfinite(ref).all()
+    with J.Batch(vi5, [u, u], keep_tracks=True) as b:
+        b.run()
+        b.sync()
+        for si in range(3):
+            got = b.track(0, si)
+            assert np.array_equal(got == O.NODATA, tr[si] == O.NODATA)
+            np.testing.assert_allclose(got, tr[si], rtol=1e-12, atol=1e-13)
+        g0, g1 = b.pcm(0), b.pcm(1)
+    assert np.array_equal(g0, g1) and rel_rms(g0, ref) <= 1e-9
