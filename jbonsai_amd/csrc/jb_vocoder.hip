@@ -165,6 +165,7 @@ __global__ void k_pulse(BatchDev bd, VocDev vd)
 // staged in LDS, and so are the LPF taps of the (at most 4) frames the block touches.
 constexpr int kExcBlock = 256;
 constexpr int kExcHalo = 64; // >= nlpf-1
+constexpr int kExcMaxFrames = (kExcBlock + kExcHalo) / 30 + 3;
 
 __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
 {
@@ -179,7 +180,9 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     const int tid = threadIdx.x;
     const int anti = (nlpf - 1) / 2;
     __shared__ double e[kExcBlock + kExcHalo];
-    __shared__ double taps[4][64];
+    // taps of every frame the block and its history touch: (256 + 64) / fperiod + 2 frames; the
+    // smallest supported frame period is nlpf-1 >= 30 (block divisor rule), hence 13 rows
+    __shared__ double taps[kExcMaxFrames][64];
     __shared__ int anyv;
     // frames touched by samples [n0 - halo, n0 + 255]
     const long mfirst = (long)n0 - (long)kExcHalo;
@@ -187,9 +190,13 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     if (tid == 0)
         anyv = 0;
     {
-        const int fi = tid >> 6, k = tid & 63;
-        const uint32_t fr = f_lo + (uint32_t)fi;
-        taps[fi][k] = (fr < u->T && k < nlpf) ? vd.lpf[(base + fr) * (uint64_t)nlpf + k] : 0.0;
+        const uint32_t f_hi = (uint32_t)((n0 + kExcBlock - 1) / (uint64_t)fp);
+        const int nfr = (int)(f_hi - f_lo) + 1; // <= kExcMaxFrames for fperiod >= 30
+        const int k = tid & 63;
+        for (int fi = tid >> 6; fi < nfr && fi < kExcMaxFrames; fi += kExcBlock / 64) {
+            const uint32_t fr = f_lo + (uint32_t)fi;
+            taps[fi][k] = (fr < u->T && k < nlpf) ? vd.lpf[(base + fr) * (uint64_t)nlpf + k] : 0.0;
+        }
     }
     __syncthreads();
     for (int j = tid; j < kExcBlock + kExcHalo; j += kExcBlock) {
@@ -332,8 +339,9 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const int i0 = lane * kExw;
-    if (i0 >= fp)
-        return;
+    // lanes past the end of the frame own no samples but stay: pass 2 turns the first NLPF-1
+    // samples to one per lane and needs lanes 0..NLPF-2 whatever the frame period
+    const bool own = i0 < fp;
     double x[kExw];
 #pragma unroll
     for (int r = 0; r < kExw; r++) {
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
         x[r] = ((long)n0 + i0 + r - anti >= 0) ? nz[o & (kExw - 1)][o >> 2] : 0.0;
     }
     const double *tc = vd.lpf + f * (uint64_t)nlpf;
-    if (vcur) {
+    if (vcur && own) {
         double ck[NLPF];
 #pragma unroll
         for (int k = 0; k < NLPF; k++)
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
         // with zeros where this frame starts: x + 0*c == x, the order of the remaining terms is the
         // tap order.
         const double *tp = tc - nlpf;
-        if (i0 < kExwHalo) {
+        if (own && i0 < kExwHalo) {
 #pragma unroll
             for (int r = 0; r < kExw; r++)
                 xs[i0 + r] = x[r];
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < NLPF - 1) {
+        if (lane < NLPF - 1 && lane < fp) {
             double xv = xs[lane];
 #pragma unroll
             for (int k = 1; k < NLPF; k++)
@@ -385,12 +393,14 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (i0 < kExwHalo) {
+        if (own && i0 < kExwHalo) {
 #pragma unroll
             for (int r = 0; r < kExw; r++)
                 x[r] = xs[i0 + r];
         }
     }
+    if (!own)
+        return;
     const uint64_t o = base * (uint64_t)fp + n0 + (uint64_t)i0;
     *reinterpret_cast<double2 *>(vd.xin + o) = make_double2(x[0], x[1]);
     *reinterpret_cast<double2 *>(vd.xin + o + 2) = make_double2(x[2], x[3]);

@@ -266,3 +266,85 @@ def test_five_point_delta_windows(ctx):
             np.testing.assert_allclose(got, tr[si], rtol=1e-12, atol=1e-13)
         g0, g1 = b.pcm(0), b.pcm(1)
     assert np.array_equal(g0, g1) and rel_rms(g0, ref) <= 1e-9
+
+
+@pytest.mark.parametrize("fs,fp,alpha,nlpf", [(16000, 80, 0.42, 31), (48000, 90, 0.55, 31), (48000, 240, 0.55, 15),
+                                              (22050, 100, 0.45, 31)])
+def test_other_frame_periods_and_lpf_orders(ctx, fs, fp, alpha, nlpf):
+    """Frame periods other than 240 (divisible by 4 or not: the 32-byte PCM stores and the wave-per-frame
+    excitation kernel need fperiod % 4 == 0, the generic paths take over at 90), another warping
+    alpha, and a 15-tap LPF stream (second specialisation of the split excitation).  HIP vs oracle,
+    default kernels and the throughput kernel."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    u = synth.synth_utterance(tab, 500, 21)
+    streams = list(vi.streams)
+    ustreams = list(u.streams)
+    if nlpf != vi.streams[2].vector_length:
+        L = vi.streams[2].vector_length
+        lo = (L - nlpf) // 2  # centre taps of the (symmetric) low-pass filters
+        s2 = u.streams[2]
+        ustreams[2] = dataclasses.replace(s2, mean=s2.mean[:, lo:lo + nlpf].copy(), var=s2.var[:, lo:lo + nlpf].copy())
+        streams[2] = dataclasses.replace(vi.streams[2], vector_length=nlpf)
+    vi2 = dataclasses.replace(vi, sampling_frequency=fs, fperiod=fp, alpha=alpha, streams=streams)
+    u2 = J.Utterance(u.durations, ustreams)
+    ref, _ = oracle_pcm(vi2, u2)
+    assert len(ref) == 500 * fp and np.isfinite(ref).all()
+    for kw in (dict(), dict(chunk_frames=64, kernel="pair"), dict(chunk_frames=64, kernel="wave")):
+        got, info = run(vi2, [u2, u2], **kw)
+        assert np.array_equal(got[0], got[1])
+        assert rel_rms(got[0], ref) <= 1e-9, (fs, fp, alpha, nlpf, kw)
+
+
+def test_unsupported_frame_period_fails_loudly(ctx):
+    """The vocoder works in blocks of a divisor of fperiod that is <= 64 and >= nlpf-1; a frame
+    period without one (75: divisors 25, 15, ...) is refused with JB_ERR_UNSUPPORTED, not mis-synthesised."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    u = synth.synth_utterance(tab, 50, 1)
+    with pytest.raises(J.JbError) as ei:
+        J.Batch(dataclasses.replace(vi, fperiod=75), [u])
+    assert "UNSUPPORTED" in str(ei.value)
+
+
+@pytest.mark.parametrize("case", ["static_mcp_with_gv", "no_gv_anywhere", "delta_only"])
+def test_other_window_sets_and_gv_flags(ctx, case):
+    """Stream shapes off the nitech voice's: a static-only spectral stream that still has GV (band
+    width 1 through the generic solver), GV switched off on every stream (the fused sweeps end
+    after the substitutions), static + delta only (two windows).  HIP vs oracle, tracks and PCM."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    u = synth.synth_utterance(tab, 600, 31)
+    streams, ustreams = list(vi.streams), list(u.streams)
+
+    def cut_windows(si, nw):
+        L = vi.streams[si].vector_length
+        st = u.streams[si]
+        ustreams[si] = dataclasses.replace(st, mean=st.mean[:, :nw * L].copy(), var=st.var[:, :nw * L].copy())
+        streams[si] = dataclasses.replace(streams[si], windows=vi.streams[si].windows[:nw])
+
+    if case == "static_mcp_with_gv":
+        cut_windows(0, 1)
+    elif case == "delta_only":
+        cut_windows(0, 2)
+        cut_windows(1, 2)
+    else:
+        for si in (0, 1):
+            streams[si] = dataclasses.replace(streams[si], use_gv=False)
+            ustreams[si] = dataclasses.replace(ustreams[si], gv_mean=None, gv_var=None, gv_switch=None)
+    vi2 = dataclasses.replace(vi, streams=streams)
+    u2 = J.Utterance(u.durations, ustreams)
+    ref, tr = oracle_pcm(vi2, u2)
+    assert np.isfinite(ref).all()
+    with J.Batch(vi2, [u2, u2], keep_tracks=True) as b:
+        b.run()
+        b.sync()
+        for si in range(3):
+            got = b.track(0, si)
+            assert np.array_equal(got == O.NODATA, tr[si] == O.NODATA)
+            np.testing.assert_allclose(got, tr[si], rtol=1e-12, atol=1e-13)
+        g0, g1 = b.pcm(0), b.pcm(1)
+    assert np.array_equal(g0, g1) and rel_rms(g0, ref) <= 1e-9
