@@ -348,3 +348,23 @@ def test_other_window_sets_and_gv_flags(ctx, case):
             np.testing.assert_allclose(got, tr[si], rtol=1e-12, atol=1e-13)
         g0, g1 = b.pcm(0), b.pcm(1)
     assert np.array_equal(g0, g1) and rel_rms(g0, ref) <= 1e-9
+
+
+def test_many_tiny_utterances(ctx):
+    """A batch of 4,000 utterances of 30-70 frames (220 k frames: the throughput kernel with most
+    utterances shorter than two chunks; one block / grid row per utterance in the serial kernels):
+    a sample of them against the oracle, duplicates bit-identical."""
+    eng, tab, vi = ctx
+    base = [synth.synth_utterance(tab, 30 + (7 * i) % 41, 300 + i) for i in range(25)]
+    utts = [base[i % 25] for i in range(4000)]
+    with J.Batch(vi, utts) as b:
+        b.run()
+        b.sync()
+        info = b.info()
+        picks = {i: b.pcm(i) for i in (0, 1, 24, 25, 26, 1999, 3975, 3999)}
+    assert info["n_items"] >= 4000
+    for i, g in picks.items():
+        assert len(g) == int(base[i % 25].durations.sum()) * 240
+        assert np.array_equal(g, picks[i % 25]) if i % 25 in picks else True
+        ref, _ = oracle_pcm(vi, base[i % 25])
+        assert rel_rms(g, ref) <= 1e-9, i
