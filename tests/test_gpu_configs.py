@@ -368,3 +368,16 @@ def test_many_tiny_utterances(ctx):
         assert np.array_equal(g, picks[i % 25]) if i % 25 in picks else True
         ref, _ = oracle_pcm(vi, base[i % 25])
         assert rel_rms(g, ref) <= 1e-9, i
+
+
+def test_one_very_long_utterance(ctx):
+    """A single 160,000-frame (13 min) utterance: 79 GV tiles per row, 10,000 states in the state
+    walk, the throughput kernel fed by one utterance only.  HIP vs oracle."""
+    eng, tab, vi = ctx
+    u = synth.synth_utterance(tab, 160000, 77)
+    got, info = run(vi, [u])
+    assert len(got[0]) == 160000 * 240 and info["n_items"] > 1000
+    ref, _ = oracle_pcm(vi, u)
+    e = rel_rms(got[0], ref)
+    print("160 k frames: rel RMS vs oracle", e, info)
+    assert e <= 1e-9
