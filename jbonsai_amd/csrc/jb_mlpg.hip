@@ -2028,12 +2028,10 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
 template <int LMAX>
 static void launch_fb_lds(const BatchDev &bd, const StreamDev &sd, int si, size_t lds, hipStream_t stream)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_mlpg_fb_lds<LMAX>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        attr_set = true;
-    }
+    // once per instantiation; a function-local static's initialisation is thread-safe
+    static const hipError_t attr = hipFuncSetAttribute((const void *)k_mlpg_fb_lds<LMAX>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr;
     hipLaunchKernelGGL(k_mlpg_fb_lds<LMAX>, dim3(bd.B), dim3(kFlNT), lds, stream, bd, sd, si);
 }
 

@@ -149,6 +149,34 @@ def test_device_gather_blend_equals_host_blend():
     assert len(a[0]) > 0 and len(a[2]) == 0
 
 
+def test_concurrent_synthesize_on_one_engine(engine):
+    """Engine::synthesize takes &self and the reference Engine is Sync: several host threads may
+    synthesise through one engine at once (each call owns its batch and streams; the noise table
+    and the device pdf tables are shared behind locks)."""
+    import threading
+
+    ref = {0: engine.synthesize(SAMPLE_SENTENCE_1), 1: engine.synthesize(SAMPLE_SENTENCE_2)}
+    out, errs = {}, []
+
+    def work(i):
+        try:
+            for k in range(3):
+                out[(i, k)] = (engine.synthesize_batch([SAMPLE_SENTENCE_2, SAMPLE_SENTENCE_1])
+                               if (i + k) % 2 else [engine.synthesize(SAMPLE_SENTENCE_2), engine.synthesize(SAMPLE_SENTENCE_1)])
+        except Exception as ex:  # noqa: BLE001
+            errs.append(ex)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert len(out) == 12
+    for v in out.values():
+        assert np.array_equal(v[0], ref[1]) and np.array_equal(v[1], ref[0])
+
+
 def test_volume_db(engine):
     e = J.Engine.load([VOICE])
     base = e.synthesize(SAMPLE_SENTENCE_1)
