@@ -615,6 +615,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.voiced = b->sd[1].voiced;
     vd.run_list = b->sd[1].run_list;
     vd.nruns = b->sd[1].nruns;
+    if ((rc = b->dalloc(&vd.run_base, n + 1, true)) || (rc = b->dalloc(&vd.run_counter, 1, true)))
+        return rc;
     vd.mcp = b->sd[0].out;
     vd.lf0 = b->sd[1].out;
     vd.lpf = b->sd[2].out;

@@ -100,6 +100,8 @@ struct VocDev {
     const uint8_t *voiced;     // [sumT] MSD voiced flag of the LF0 stream (k_prep_frames)
     const uint32_t *run_list;  // voiced runs of the LF0 stream (k_prep_states)
     const uint32_t *nruns;
+    uint32_t *run_base;        // [B+1] exclusive prefix of nruns (k_run_scan) for the pulse work queue
+    uint32_t *run_counter;     // [1] next run to hand out
     const double *noise;  // [noise_len] shared Gaussian stream
     uint64_t noise_len;
     double *xin;          // [sumT*fperiod] excitation after the LPF mix and gain (k_excite)

@@ -97,18 +97,10 @@ __global__ __launch_bounds__(kMc2bFrames) void k_mc2b(BatchDev bd, VocDev vd)
 // state carried across frames: at every
 // frame start pitch_of_curr_point is reset to the previous frame's pitch by
 // Excitation::end, excitation.rs:102-104).
-__global__ void k_pulse(BatchDev bd, VocDev vd)
+// One voiced run (entry r of utterance b's compact run list from k_prep_states).
+__device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, int b, uint32_t r)
 {
-    // one lane per voiced run (compact run list from k_prep_states of the LF0 stream); a
-    // thread per frame would leave ~2 of 64 lanes working
-    const int b = (int)bd.order[blockIdx.y]; // longest utterance first
     const UttDev u = bd.utt[b];
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= vd.nruns[b])
-        return;
-#if JB_SIDE_PRIO
-    __builtin_amdgcn_s_setprio(3); // serial walk: do not take turns with throughput waves
-#endif
     const uint32_t t0 = vd.run_list[u.state_off + r];
     if (t0 >= u.T)
         return;
@@ -151,6 +143,76 @@ __global__ void k_pulse(BatchDev bd, VocDev vd)
             vd.pmask[(base + t) * nblk + q] = mask;
         }
         prevp = p; // Excitation::end
+    }
+}
+
+// Static form: one lane per voiced run, 64 consecutive runs of an utterance per wave.  Every wave
+// then lasts as long as its longest run, and ~2,800 of them issue instructions for the whole
+// 6 ms beside the throughput kernels.
+__global__ void k_pulse(BatchDev bd, VocDev vd)
+{
+    const int b = (int)bd.order[blockIdx.y]; // longest utterance first
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= vd.nruns[b])
+        return;
+    pulse_run(bd, vd, b, r);
+}
+
+// Exclusive prefix of the per-utterance run counts (one block), and the counter reset.
+__global__ __launch_bounds__(256) void k_run_scan(BatchDev bd, VocDev vd)
+{
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x;
+    const int per = (bd.B + 255) / 256;
+    uint32_t s = 0;
+    for (int i = 0; i < per; i++) {
+        const int b = tid * per + i;
+        if (b < bd.B)
+            s += vd.nruns[bd.order[b]];
+    }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < 256; i++) {
+            const uint32_t v = part[i];
+            part[i] = acc;
+            acc += v;
+        }
+        vd.run_base[bd.B] = acc;
+        *vd.run_counter = 0;
+    }
+    __syncthreads();
+    uint32_t acc = part[tid];
+    for (int i = 0; i < per; i++) {
+        const int b = tid * per + i;
+        if (b < bd.B) {
+            vd.run_base[b] = acc; // position b of the longest-first order
+            acc += vd.nruns[bd.order[b]];
+        }
+    }
+}
+
+// Work-queue form: a fixed number of lanes, each taking the next run (utterances longest first)
+// from an atomic counter until none is left, so that lanes stay busy and the walk occupies a few
+// hundred waves instead of thousands.  Every lane reaches the exit condition (counter >= total).
+__global__ __launch_bounds__(64) void k_pulse_queue(BatchDev bd, VocDev vd)
+{
+    const uint32_t total = vd.run_base[bd.B];
+    for (;;) {
+        const uint32_t idx = atomicAdd(vd.run_counter, 1u);
+        if (idx >= total)
+            return;
+        // utterance position: last p with run_base[p] <= idx
+        int lo = 0, hi = bd.B - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (vd.run_base[mid] <= idx)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        pulse_run(bd, vd, (int)bd.order[lo], idx - vd.run_base[lo]);
     }
 }
 
@@ -1532,6 +1594,12 @@ hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
+    static const int qwaves = getenv("JB_PULSE_QUEUE") ? atoi(getenv("JB_PULSE_QUEUE")) : 512;
+    if (qwaves > 0 && vd.run_base) {
+        hipLaunchKernelGGL(k_run_scan, dim3(1), dim3(256), 0, stream, bd, vd);
+        hipLaunchKernelGGL(k_pulse_queue, dim3((unsigned)qwaves), dim3(64), 0, stream, bd, vd);
+        return hipGetLastError();
+    }
     dim3 grid((bd.maxS + 63) / 64, bd.B), block(64);
     hipLaunchKernelGGL(k_pulse, grid, block, 0, stream, bd, vd);
     return hipGetLastError();
