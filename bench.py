@@ -115,6 +115,8 @@ def main():
                     help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
                          "(torch.distributed gather over xGMI) and report its time as gather_ms; "
                          "never part of `value` (SURVEY 8e)")
+    ap.add_argument("--beta", type=float, default=0.0,
+                    help="post-filter coefficient (off-config: BASELINE's metric is quoted at beta = 0)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
                          "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
@@ -152,6 +154,7 @@ def main():
     eng = J.Engine.load([VOICE])
     tab = synth.VoiceTables(eng)
     vi = eng.voice_info()
+    vi.beta = args.beta
     frames = args.frames or synth.T_128S
     # every utterance of the batch is the same sequence (BASELINE config 2: "256 copies"),
     # uploaded once and aliased; outputs / workspace / filter state are per utterance
@@ -247,6 +250,7 @@ def main():
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
                 "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
                 "batches_in_flight": depth, "mlpg_cus_per_xcd": cu_split, "distinct_utterances": nd,
+                "beta": args.beta,
                 "chunks_settled_at_checkpoint_last_step": batch.redo_stats()[0],
                 "vocoder_chunk_frames": info["chunk_frames"], "vocoder_warmup_frames": info["warmup_frames"],
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],

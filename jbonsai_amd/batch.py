@@ -177,6 +177,13 @@ class Batch:
         F.check(self._L.jb_batch_read_track(self._h, i, stream, out.ctypes.data, out.size))
         return out
 
+    def coefficients(self, i) -> np.ndarray:
+        """MLSA filter coefficients per frame, mc2b(postfilter_mcp(spectrum)) (vocoder/mod.rs:116-118)."""
+        T, Lv = self.num_frames(i), self.voice.streams[0].vector_length
+        out = np.empty((T, Lv), dtype=np.float64)
+        F.check(self._L.jb_batch_read_coefficients(self._h, i, out.ctypes.data, out.size))
+        return out
+
     def excitation(self, i) -> np.ndarray:
         n = self.num_samples(i)
         out = np.empty(n, dtype=np.float64)

@@ -304,9 +304,9 @@ static int check_voice(const jb_voice_desc *v)
         set_error("Stage::NonZero (GAMMA != 0, LSP/MGLSA) is not supported");
         return JB_ERR_UNSUPPORTED;
     }
-    if (v->beta != 0.0) {
-        set_error("beta > 0 (postfilter_mcp) is not supported");
-        return JB_ERR_UNSUPPORTED;
+    if (!(v->beta >= 0.0)) {
+        set_error("beta must be >= 0");
+        return JB_ERR_INVALID;
     }
     if (v->nstream != 3) {
         // Engine::generator indexes stream_metadata(2) unconditionally (src/engine.rs:305)
@@ -612,6 +612,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.nblk = vd.fperiod / bs;
     vd.alpha = voice->alpha;
     vd.volume = voice->volume;
+    // postfilter_mcp acts only for beta > 0 and more than two coefficients (cepstrum.rs:24)
+    vd.beta = (voice->beta > 0.0 && vd.nmcp > 2) ? voice->beta : 0.0;
     vd.voiced = b->sd[1].voiced;
     vd.run_list = b->sd[1].run_list;
     vd.nruns = b->sd[1].nruns;
@@ -628,6 +630,11 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         (rc = b->dalloc(&vd.pmask, nf * (size_t)vd.nblk, false)) ||
         (rc = b->dalloc(&vd.xin, b->total_samples, false)))
         return rc;
+    if (vd.beta > 0.0) {
+        if ((rc = b->dalloc(&vd.bfirst, (size_t)std::max<size_t>(n, 1) * (size_t)vd.nmcp, true)) ||
+            (rc = b->dalloc(&vd.pf_table, (size_t)vd.nmcp * 576, false)) || (rc = b->dalloc(&vd.pf_rcp, 576, false)))
+            return rc;
+    }
     if (b->flags & JB_BATCH_PCM_I16)
         rc = b->dalloc(&vd.pcm16, b->total_samples, false);
     else
@@ -650,6 +657,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         return rc;
     vd.noise = np;
     vd.noise_len = nl;
+    if (vd.beta > 0.0 && (e = launch_pf_table(vd, b->stream)) != hipSuccess)
+        return hip_fail(e, "k_pf_table");
     if ((rc = b->build_work(opts)))
         return rc;
     e = hipDeviceSynchronize();
@@ -859,6 +868,8 @@ int Batch::enqueue_paramgen()
         e = launch_mc2b(bd, vd, stream);
     if (e != hipSuccess)
         return hip_fail(e, "k_mc2b");
+    if (vd.beta > 0.0 && (e = launch_postfilter(bd, vd, (uint64_t)sumT, stream)) != hipSuccess)
+        return hip_fail(e, "k_postfilter");
     // pulses (LF0): the samples after each pulse (split form) or the whole excitation
     hipStreamWaitEvent(stream_lf0, ev_lpf, 0);
     hipStreamWaitEvent(stream_lf0, ev_build, 0);
@@ -1276,6 +1287,19 @@ int jb_batch_read_track(jb_batch *hb, size_t i, uint32_t si, double *dst, size_t
     if (ne == 0)
         return JB_OK;
     return b->read(b->sd[si].out + (size_t)b->frame_off[i] * L, dst, ne * sizeof(double));
+}
+
+int jb_batch_read_coefficients(jb_batch *hb, size_t i, double *dst, size_t cap)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || i >= (size_t)b->B)
+        return JB_ERR_INVALID;
+    size_t L = (size_t)b->vd.nmcp, ne = (size_t)b->T[i] * L;
+    if (cap < ne)
+        return JB_ERR_BUFFER;
+    if (ne == 0)
+        return JB_OK;
+    return b->read(b->vd.bcoef + (size_t)b->frame_off[i] * L, dst, ne * sizeof(double));
 }
 
 int jb_batch_read_excitation(jb_batch *hb, size_t i, double *dst, size_t cap)

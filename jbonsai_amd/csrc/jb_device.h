@@ -92,6 +92,10 @@ struct VocDev {
     const double *lf0;    // [sumT]
     const double *lpf;    // [sumT][nlpf]
     double *bcoef;        // [sumT][nmcp]  mc2b(mcp)  (src/vocoder/cepstrum.rs:139-149)
+    double beta;          // post-filter coefficient (cepstrum.rs:23-37); 0 = off
+    double *bfirst;       // [B][nmcp] un-filtered bcoef of each utterance's first frame, or nullptr (beta == 0)
+    double *pf_table;     // [nmcp][576] freqt(575, -alpha) as a linear operator (k_pf_table), or nullptr
+    double *pf_rcp;       // [576] 1/n
     double *pitch;        // [sumT]  period in samples, 0 = unvoiced
     double *cur_start;    // [sumT]  pitch_of_curr_point at frame start
     double *pinc;         // [sumT]  pitch_inc_per_point
@@ -174,6 +178,9 @@ hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream
 bool excite_is_split(const VocDev &vd);
 hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
 hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+// X1 post-filter (cepstrum.rs:23-37): constant tables once, then bcoef in place for every frame
+hipError_t launch_pf_table(const VocDev &vd, hipStream_t stream);
+hipError_t launch_postfilter(const BatchDev &bd, const VocDev &vd, uint64_t nframes, hipStream_t stream);
 hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                           hipStream_t stream);
 // lane-serial throughput kernel (one chunk per lane); order_dev = launch permutation of items

@@ -740,7 +740,8 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
         // ---- frame setup (vocoder/mod.rs:116-125) ----
         // c at frame start = previous frame's cc exactly (mod.rs:140); first frame: c = cc.
         const double *bcur = vd.bcoef + f * (uint64_t)nmcp;
-        const double *bprev = (t > 0) ? bcur - nmcp : bcur;
+        // beta > 0: the first frame starts from the un-filtered mc2b(spectrum) (mod.rs:80-89)
+        const double *bprev = (t > 0) ? bcur - nmcp : (vd.bfirst ? vd.bfirst + (uint64_t)b * (uint64_t)nmcp : bcur);
 #pragma unroll
         for (int k = 0; k < TPL; k++) {
             double c0v = dotv[k] ? bprev[tapj[k]] : 0.0;
@@ -975,7 +976,7 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
         __syncthreads();
         if (has) {
             const double *bcur = vd.bcoef + f * (uint64_t)NM;
-            const double *bprev = (t > 0) ? bcur - NM : bcur;
+            const double *bprev = (t > 0) ? bcur - NM : (vd.bfirst ? vd.bfirst + (uint64_t)wk.utt * NM : bcur);
             for (int k = 1 + (lane & 1); k < NM; k += 2) {
                 const double c0v = bprev[k], c1v = bcur[k];
                 cc[k - 1][pair] = make_double2(c0v, (c1v - c0v) / (double)fp);
@@ -1249,7 +1250,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         __syncthreads();
         if (has) {
             const double *bcur = vd.bcoef + f * (uint64_t)NM;
-            const double *bprev = (t > 0) ? bcur - NM : bcur;
+            const double *bprev = (t > 0) ? bcur - NM : (vd.bfirst ? vd.bfirst + (uint64_t)wk.utt * NM : bcur);
             for (int k = 1 + pos; k < NM; k += 3) {
                 const double c0v = bprev[k], c1v = bcur[k];
                 cc[k - 1][ci] = make_double2(c0v, (c1v - c0v) / (double)fp);

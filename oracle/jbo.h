@@ -32,7 +32,7 @@ typedef struct jbo_voice jbo_voice;
 typedef struct {
     double speed;                 /* 1.0 */
     double volume;                /* linear, 1.0 */
-    double beta;                  /* 0.0 (postfilter unsupported: must be 0) */
+    double beta;                  /* post-filter coefficient, 0 = off (engine.rs:75,215-218) */
     double additional_half_tone;  /* 0.0 */
     double msd_threshold[JBO_MAX_STREAM]; /* 0.5 */
     double gv_weight[JBO_MAX_STREAM];     /* 1.0 */
@@ -120,6 +120,17 @@ int jbo_mlpg(const jbo_stream *st, uint32_t S, const uint32_t *dur, double *par 
 int jbo_vocoder(int fs, int fperiod, double alpha, double volume, int nmcp, int nlpf,
                 size_t T, const double *lf0, const double *mcp, const double *lpf,
                 double *pcm, double *exc, double *pulse);
+/* Same with the mel-cepstral post-filter (beta > 0): postfilter_mcp per frame
+ * (src/vocoder/cepstrum.rs:23-37).  No reference test exercises beta > 0: parity unpinned. */
+int jbo_vocoder_beta(int fs, int fperiod, double alpha, double beta, double volume, int nmcp,
+                     int nlpf, size_t T, const double *lf0, const double *mcp, const double *lpf,
+                     double *pcm, double *exc, double *pulse);
+/* X1 pieces: freqt (cepstrum.rs:153-173), c2ir (:175-186), b2en (coefficients.rs:75-78),
+ * postfilter_mcp in place (cepstrum.rs:23-37). */
+void jbo_freqt(const double *c1, size_t n1, double *out /*[m2+1]*/, size_t m2, double alpha);
+void jbo_c2ir(const double *c, size_t nc, double *ir, size_t len);
+double jbo_b2en(const double *b, size_t n, double alpha);
+void jbo_postfilter_mcp(double *mc, size_t n, double alpha, double beta);
 /* Random::nrandom stream (src/vocoder/excitation.rs:177-237), seed next=1. */
 void jbo_noise(double *out, size_t n);
 
@@ -134,6 +145,9 @@ int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *
 int jbo_paramgen_vocode(int fs, int fperiod, double alpha, double volume,
                         const jbo_stream st[3], int nstream, uint32_t S, const uint32_t *dur,
                         double **pcm, size_t *n_samples);
+int jbo_paramgen_vocode_beta(int fs, int fperiod, double alpha, double beta, double volume,
+                             const jbo_stream st[3], int nstream, uint32_t S, const uint32_t *dur,
+                             double **pcm, size_t *n_samples);
 void jbo_free(void *p);
 
 #ifdef __cplusplus

@@ -253,6 +253,14 @@ int jbo_paramgen_vocode(int fs, int fperiod, double alpha, double volume, const 
                         int nstream, uint32_t S, const uint32_t *dur, double **pcm_out,
                         size_t *n_samples)
 {
+    return jbo_paramgen_vocode_beta(fs, fperiod, alpha, 0.0, volume, st, nstream, S, dur, pcm_out,
+                                    n_samples);
+}
+
+int jbo_paramgen_vocode_beta(int fs, int fperiod, double alpha, double beta, double volume,
+                             const jbo_stream st[3], int nstream, uint32_t S, const uint32_t *dur,
+                             double **pcm_out, size_t *n_samples)
+{
     size_t T = 0;
     for (uint32_t s = 0; s < S; s++)
         T += dur[s];
@@ -269,8 +277,8 @@ int jbo_paramgen_vocode(int fs, int fperiod, double alpha, double volume, const 
     if (Ll)
         jbo_mlpg(&st[2], S, dur, lpf);
     double *pcm = (double *)malloc(sizeof(double) * T * (size_t)fperiod);
-    int r = jbo_vocoder(fs, fperiod, alpha, volume, (int)Lm, (int)Ll, T, lf0, mcp, lpf, pcm, NULL,
-                        NULL);
+    int r = jbo_vocoder_beta(fs, fperiod, alpha, beta, volume, (int)Lm, (int)Ll, T, lf0, mcp, lpf, pcm,
+                             NULL, NULL);
     free(mcp);
     free(lf0);
     free(lpf);
@@ -301,8 +309,8 @@ int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *
         *lpf_out = NULL;
     if (T_out)
         *T_out = 0;
-    if (v->stage != 0 || c->beta != 0.0)
-        return -2; /* Stage::NonZero / postfilter not restated */
+    if (v->stage != 0)
+        return -2; /* Stage::NonZero not restated */
     const char **labels = (const char **)malloc(sizeof(char *) * (size_t)(n ? n : 1));
     double *times = (double *)malloc(sizeof(double) * 2 * (size_t)(n ? n : 1));
     int m = jbo_parse_label_lines(v->fs, v->fperiod, lines, n, labels, times);
@@ -378,8 +386,8 @@ int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *
         if (Ll)
             jbo_mlpg(&st[2], S, dur, lpf);
         double *pcm = (double *)malloc(sizeof(double) * (T ? T : 1) * (size_t)v->fperiod);
-        rc = jbo_vocoder(v->fs, v->fperiod, v->alpha, c->volume, (int)Lm, (int)Ll, T, lf0, mcp,
-                         Ll ? lpf : NULL, pcm, NULL, NULL);
+        rc = jbo_vocoder_beta(v->fs, v->fperiod, v->alpha, c->beta, c->volume, (int)Lm, (int)Ll, T, lf0,
+                              mcp, Ll ? lpf : NULL, pcm, NULL, NULL);
         *pcm_out = pcm;
         *n_samples = T * (size_t)v->fperiod;
         if (T_out)

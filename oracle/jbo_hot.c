@@ -586,11 +586,103 @@ static void mc2b(const double *mc, double *b, size_t n, double alpha)
     }
 }
 
+/* b2mc (src/vocoder/coefficients.rs:65-73) */
+static void b2mc(const double *b, double *mc, size_t n, double alpha)
+{
+    size_t last = n - 1;
+    mc[last] = b[last];
+    for (size_t i = last; i-- > 0;)
+        mc[i] = b[i] + alpha * b[i + 1];
+}
+
+/* X1: freqt (src/vocoder/cepstrum.rs:153-173).  The reference feeds the input coefficients in
+ * ASCENDING index order (self[i], i = 0..len), where hts_engine's HTS_freqt walks c1[m1]..c1[0];
+ * this restatement follows the reference as written.  out[m2+1], scratch f[m2+1]. */
+void jbo_freqt(const double *c1, size_t n1, double *out, size_t m2, double alpha)
+{
+    const double aa = 1.0 - alpha * alpha;
+    const size_t n2 = m2 + 1;
+    double *f = (double *)calloc(n2, sizeof(double));
+    for (size_t j = 0; j < n2; j++)
+        out[j] = 0.0;
+    for (size_t i = 0; i < n1; i++) {
+        f[0] = out[0];
+        out[0] = c1[i] + alpha * out[0];
+        if (1 <= m2) {
+            f[1] = out[1];
+            out[1] = aa * f[0] + alpha * out[1];
+        }
+        for (size_t j = 2; j < n2; j++) {
+            f[j] = out[j];
+            out[j] = f[j - 1] + alpha * (out[j] - out[j - 1]);
+        }
+    }
+    free(f);
+}
+
+/* X1: c2ir (src/vocoder/cepstrum.rs:175-186): impulse response of exp(C(z)), len samples. */
+void jbo_c2ir(const double *c, size_t nc, double *ir, size_t len)
+{
+    ir[0] = exp(c[0]);
+    for (size_t n = 1; n < len; n++) {
+        double d = 0.0;
+        size_t kend = nc < n + 1 ? nc : n + 1;
+        for (size_t k = 1; k < kend; k++)
+            d += (double)k * c[k] * ir[n - k];
+        ir[n] = d / (double)n;
+    }
+}
+
+#define JBO_IRLENG 576 /* coefficients.rs:76 */
+
+/* X1: b2en (src/vocoder/coefficients.rs:75-78) */
+double jbo_b2en(const double *b, size_t n, double alpha)
+{
+    double *mc = (double *)malloc(sizeof(double) * n);
+    double g[JBO_IRLENG], ir[JBO_IRLENG];
+    b2mc(b, mc, n, alpha);
+    jbo_freqt(mc, n, g, JBO_IRLENG - 1, -alpha);
+    jbo_c2ir(g, JBO_IRLENG, ir, JBO_IRLENG);
+    double e = 0.0;
+    for (size_t i = 0; i < JBO_IRLENG; i++)
+        e += ir[i] * ir[i];
+    free(mc);
+    return e;
+}
+
+/* X1: MelCepstrum::postfilter_mcp (src/vocoder/cepstrum.rs:23-37), in place on mc[n]. */
+void jbo_postfilter_mcp(double *mc, size_t n, double alpha, double beta)
+{
+    if (!(beta > 0.0 && n > 2))
+        return;
+    double *b = (double *)malloc(sizeof(double) * n);
+    mc2b(mc, b, n, alpha);
+    const double e1 = jbo_b2en(b, n, alpha);
+    b[1] -= beta * alpha * b[2];
+    for (size_t k = 2; k < n; k++)
+        b[k] *= 1.0 + beta;
+    const double e2 = jbo_b2en(b, n, alpha);
+    b[0] += log(e1 / e2) / 2.0;
+    b2mc(b, mc, n, alpha);
+    free(b);
+}
+
 /* V2,V5,V8,V9: Vocoder::synthesize Stage::Zero (src/vocoder/mod.rs:72-141) looped
  * as SpeechGenerator::generate_all does (src/speech.rs:87-96). */
 int jbo_vocoder(int fs, int fperiod_i, double alpha, double volume, int nmcp_i, int nlpf_i,
                 size_t T, const double *lf0, const double *mcp, const double *lpf, double *pcm,
                 double *excd, double *pulsed)
+{
+    return jbo_vocoder_beta(fs, fperiod_i, alpha, 0.0, volume, nmcp_i, nlpf_i, T, lf0, mcp, lpf, pcm,
+                            excd, pulsed);
+}
+
+/* Same with the post-filter coefficient beta (Vocoder::new's beta, src/vocoder/mod.rs:45-70).
+ * The first frame starts from the UN-filtered mc2b(spectrum) (mod.rs:80-89) and interpolates to
+ * the filtered one (mod.rs:116-118). */
+int jbo_vocoder_beta(int fs, int fperiod_i, double alpha, double beta, double volume, int nmcp_i,
+                     int nlpf_i, size_t T, const double *lf0, const double *mcp, const double *lpf,
+                     double *pcm, double *excd, double *pulsed)
 {
     const double MAX_LF0 = 9.903487552536127, MIN_LF0 = 2.995732273553991; /* constants.rs:4-6 */
     size_t fperiod = (size_t)fperiod_i, nmcp = (size_t)nmcp_i, nlpf = (size_t)nlpf_i;
@@ -609,6 +701,7 @@ int jbo_vocoder(int fs, int fperiod_i, double alpha, double volume, int nmcp_i, 
     double *c = (double *)calloc(nmcp, sizeof(double));
     double *cc = (double *)calloc(nmcp, sizeof(double));
     double *cinc = (double *)calloc(nmcp, sizeof(double));
+    double *pf = (double *)calloc(nmcp, sizeof(double));
     int is_first = 1;
     for (size_t t = 0; t < T; t++) {
         double l = lf0[t];
@@ -624,7 +717,13 @@ int jbo_vocoder(int fs, int fperiod_i, double alpha, double volume, int nmcp_i, 
             is_first = 0;
             mc2b(spec, c, nmcp, alpha);
         }
-        mc2b(spec, cc, nmcp, alpha); /* beta == 0: postfilter_mcp is a no-op */
+        if (beta > 0.0 && nmcp > 2) {
+            memcpy(pf, spec, sizeof(double) * nmcp);
+            jbo_postfilter_mcp(pf, nmcp, alpha, beta);
+            mc2b(pf, cc, nmcp, alpha);
+        } else {
+            mc2b(spec, cc, nmcp, alpha);
+        }
         for (size_t k = 0; k < nmcp; k++)
             cinc[k] = (cc[k] - c[k]) / (double)fperiod;
         exc_start(&e, p, fperiod);
@@ -654,5 +753,6 @@ int jbo_vocoder(int fs, int fperiod_i, double alpha, double volume, int nmcp_i, 
     free(c);
     free(cc);
     free(cinc);
+    free(pf);
     return 0;
 }

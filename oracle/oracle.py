@@ -117,6 +117,15 @@ def lib():
         L.jbo_vocoder.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int,
                                   C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]
+        L.jbo_vocoder_beta.restype = C.c_int
+        L.jbo_vocoder_beta.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                       C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+        L.jbo_freqt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double]
+        L.jbo_c2ir.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.jbo_b2en.restype = C.c_double
+        L.jbo_b2en.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
+        L.jbo_postfilter_mcp.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double]
         L.jbo_noise.argtypes = [C.c_void_p, C.c_size_t]
         L.jbo_synthesize_ex.restype = C.c_int
         L.jbo_synthesize_ex.argtypes = [C.c_void_p, C.POINTER(Cond), C.POINTER(C.c_char_p), C.c_int,
@@ -269,10 +278,11 @@ class Voice:
                             gm, gv, gs, gv_weight, msd_threshold)
 
     def synthesize(self, lines, speed=1.0, volume=1.0, half_tone=0.0, alignment=False,
-                   gv_weight=None, msd_threshold=None, want_tracks=False):
+                   gv_weight=None, msd_threshold=None, want_tracks=False, beta=0.0):
         c = Cond()
         self.L.jbo_cond_default(C.byref(c))
         c.speed, c.volume, c.additional_half_tone = speed, volume, half_tone
+        c.beta = beta
         c.phoneme_alignment = int(alignment)
         if gv_weight is not None:
             for i, x in enumerate(gv_weight):
@@ -343,7 +353,34 @@ def mlpg(st: StreamStates, dur):
     return par[:T]
 
 
-def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False):
+def freqt(c1, m2, alpha):
+    """freqt (cepstrum.rs:153-173) in the reference's (ascending) input order."""
+    c1 = np.ascontiguousarray(c1, dtype=np.float64)
+    out = np.zeros(m2 + 1)
+    lib().jbo_freqt(c1.ctypes.data, len(c1), out.ctypes.data, m2, alpha)
+    return out
+
+
+def c2ir(c, n):
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    ir = np.zeros(n)
+    lib().jbo_c2ir(c.ctypes.data, len(c), ir.ctypes.data, n)
+    return ir
+
+
+def b2en(b, alpha):
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return lib().jbo_b2en(b.ctypes.data, len(b), alpha)
+
+
+def postfilter_mcp(mc, alpha, beta):
+    """MelCepstrum::postfilter_mcp (cepstrum.rs:23-37); returns the filtered copy."""
+    out = np.array(mc, dtype=np.float64, copy=True)
+    lib().jbo_postfilter_mcp(out.ctypes.data, len(out), alpha, beta)
+    return out
+
+
+def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False, beta=0.0):
     lf0 = np.ascontiguousarray(lf0, dtype=np.float64).reshape(-1)
     T = len(lf0)
     mcp = np.ascontiguousarray(mcp, dtype=np.float64).reshape(T, -1)
@@ -355,7 +392,7 @@ def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False):
     pcm = np.zeros(T * fperiod)
     exc = np.zeros(T * fperiod) if dumps else None
     pul = np.zeros(T * fperiod) if dumps else None
-    r = lib().jbo_vocoder(fs, fperiod, alpha, volume, nmcp, nlpf, T, lf0.ctypes.data, mcp.ctypes.data,
+    r = lib().jbo_vocoder_beta(fs, fperiod, alpha, beta, volume, nmcp, nlpf, T, lf0.ctypes.data, mcp.ctypes.data,
                           lpf.ctypes.data if nlpf else None, pcm.ctypes.data,
                           exc.ctypes.data if dumps else None, pul.ctypes.data if dumps else None)
     if r:

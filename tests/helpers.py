@@ -8,10 +8,10 @@ import jbonsai_amd as J
 from oracle import oracle as O
 
 
-def voice_info(v: "O.Voice", volume: float = 1.0) -> J.VoiceInfo:
+def voice_info(v: "O.Voice", volume: float = 1.0, beta: float = 0.0) -> J.VoiceInfo:
     streams = [J.StreamInfo(v.vector_length[i], bool(v.is_msd[i]), bool(v.use_gv[i]), v.windows[i])
                for i in range(v.nstream)]
-    return J.VoiceInfo(v.fs, v.fperiod, v.alpha, streams, volume=volume)
+    return J.VoiceInfo(v.fs, v.fperiod, v.alpha, streams, volume=volume, beta=beta)
 
 
 def oracle_states(v: "O.Voice", labels, speed=1.0, gv_weight=(1.0, 1.0, 1.0),
@@ -29,10 +29,11 @@ def to_utt(dur, sts) -> J.Utterance:
     return J.Utterance(dur, out)
 
 
-def oracle_run(v: "O.Voice", dur, sts, volume=1.0, dumps=False):
+def oracle_run(v: "O.Voice", dur, sts, volume=1.0, dumps=False, beta=0.0):
     """MLPG x3 + vocoder with the oracle on flat state arrays."""
     tracks = [O.mlpg(s, dur) for s in sts]
-    r = O.vocoder(v.fs, v.fperiod, v.alpha, volume, tracks[1][:, 0], tracks[0], tracks[2], dumps=dumps)
+    r = O.vocoder(v.fs, v.fperiod, v.alpha, volume, tracks[1][:, 0], tracks[0], tracks[2], dumps=dumps,
+                  beta=beta)
     return tracks, r
 
 

@@ -185,9 +185,13 @@ def test_volume_db(engine):
     np.testing.assert_allclose(quiet, base * np.exp(-6.0 * 0.11512925464970228), rtol=1e-12, atol=1e-12)
 
 
-def test_unsupported_paths_fail_loudly():
+def test_engine_beta_postfilter(oracle_voice):
+    """Engine::synthesize with Condition::set_beta (engine.rs:215-218 -> cepstrum.rs:23-37).
+    The reference has no golden for beta > 0: the oracle for this case is unpinned."""
     e = J.Engine.load([VOICE])
     e.condition.set_beta(0.3)
-    with pytest.raises(J.JbError) as ei:
-        e.synthesize(SAMPLE_SENTENCE_1)
-    assert ei.value.code == -2
+    got = e.synthesize(SAMPLE_SENTENCE_1)
+    want = oracle_voice.synthesize(SAMPLE_SENTENCE_1, beta=0.3)
+    assert len(got) == len(want) == 66480
+    den = np.sqrt(np.mean(want * want))
+    assert np.sqrt(np.mean((got - want) ** 2)) / den <= 1e-9

@@ -181,3 +181,67 @@ def test_stagewise_equals_end_to_end(oracle_voice):
     assert np.array_equal(tracks[2], ref["lpf"])
     pcm = O.vocoder(v.fs, v.fperiod, v.alpha, 1.0, tracks[1][:, 0], tracks[0], tracks[2])
     assert np.array_equal(pcm, ref["pcm"])
+
+
+def test_postfilter_pieces():
+    """X1 (beta > 0) has no golden in the reference's tests: PARITY UNPINNED.  These identities
+    pin what can be pinned without one.
+      * c2ir (cepstrum.rs:175-186): exp of a two-term series has the closed form e^c0 c1^n / n!
+      * freqt (cepstrum.rs:153-173) with alpha = 0 is a shift register fed in ascending order, so
+        the reference's input order REVERSES the coefficients (hts_engine feeds c1[m1]..c1[0]);
+        with alpha != 0 it equals the textbook recursion applied to the reversed input
+      * postfilter_mcp (cepstrum.rs:23-37): no-op for beta = 0 and for <= 2 coefficients; b[k>=2]
+        scale by 1 + beta, b[1] -= beta*alpha*b[2]
+    """
+    import math
+
+    ir = O.c2ir([0.3, 0.7], 12)
+    want = [math.exp(0.3) * 0.7 ** n / math.factorial(n) for n in range(12)]
+    np.testing.assert_allclose(ir, want, rtol=1e-14)
+    assert np.array_equal(O.freqt([1.0, 2.0, 3.0], 5, 0.0), [3.0, 2.0, 1.0, 0.0, 0.0, 0.0])
+
+    def textbook_freqt(c1, m2, a):
+        g, d, aa = np.zeros(m2 + 1), np.zeros(m2 + 1), 1 - a * a
+        for i in range(len(c1) - 1, -1, -1):
+            d[0] = g[0]
+            g[0] = c1[i] + a * d[0]
+            d[1] = g[1]
+            g[1] = aa * d[0] + a * g[1]
+            for j in range(2, m2 + 1):
+                d[j] = g[j]
+                g[j] = d[j - 1] + a * (g[j] - g[j - 1])
+        return g
+
+    c = np.random.default_rng(7).normal(size=9)
+    assert np.array_equal(O.freqt(c, 40, -0.55), textbook_freqt(c[::-1], 40, -0.55))
+
+    a, beta = 0.55, 0.3
+    mc = np.random.default_rng(8).normal(size=35) * 0.3
+    assert np.array_equal(O.postfilter_mcp(mc, a, 0.0), mc)
+    assert np.array_equal(O.postfilter_mcp(mc[:2], a, beta), mc[:2])
+
+    def mc2b(cc):
+        b = cc.copy()
+        for i in range(len(cc) - 2, -1, -1):
+            b[i] = cc[i] - a * b[i + 1]
+        return b
+
+    b0, b1 = mc2b(mc), mc2b(O.postfilter_mcp(mc, a, beta))
+    np.testing.assert_allclose(b1[2:], b0[2:] * (1 + beta), rtol=1e-13)
+    np.testing.assert_allclose(b1[1], b0[1] - beta * a * b0[2], rtol=1e-13)
+    # the gain term: b[0] moves by ln(e1/e2)/2 with e from b2en (coefficients.rs:75-78)
+    bm = b0.copy()
+    bm[1] -= beta * a * bm[2]
+    bm[2:] *= 1 + beta
+    np.testing.assert_allclose(b1[0] - b0[0], math.log(O.b2en(b0, a) / O.b2en(bm, a)) / 2, rtol=1e-12)
+
+
+def test_postfilter_changes_first_frame_only_gradually(oracle_voice):
+    """vocoder/mod.rs:80-89: the first frame starts from the un-filtered coefficients, so with
+    beta > 0 the very first samples are still those of the plain path's start."""
+    v = oracle_voice
+    r = v.synthesize(SAMPLE_SENTENCE_1, want_tracks=True)
+    p1 = v.synthesize(SAMPLE_SENTENCE_1, beta=0.5)
+    assert len(p1) == len(r["pcm"]) == 66480
+    assert np.isfinite(p1).all()
+    assert not np.allclose(p1, r["pcm"])
