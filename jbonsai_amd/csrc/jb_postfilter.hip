@@ -101,12 +101,27 @@ __global__ void k_pf_first(BatchDev bd, VocDev vd)
     vd.bfirst[i] = vd.bcoef[bd.utt[b].frame_off * (uint64_t)vd.nmcp + (uint64_t)k];
 }
 
+// LDS per wave and chain: 64 zeros, then k*g[k] for k = 0..575.  The zeros are what lanes whose sum is
+// already final multiply by in the triangular sweep (index 64 + lane - j <= 64, and kg[0] == 0).
+constexpr int kPfPad = 64;
+constexpr int kPfChain = kPfPad + kIrLen;
+
+__device__ __forceinline__ double pf_wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m);
+    return v;
+}
+
 __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_t nframes)
 {
-    extern __shared__ double pf_lds[]; // per wave: kg0[576] | kg1[576]
+    extern __shared__ double pf_lds[]; // per wave: pad|kg0[576] | pad|kg1[576]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double *kg0 = pf_lds + (size_t)w * (2 * kIrLen);
-    double *kg1 = kg0 + kIrLen;
+    double *kg0 = pf_lds + (size_t)w * (2 * kPfChain) + kPfPad;
+    double *kg1 = kg0 + kPfChain;
+    kg0[lane - kPfPad] = 0.0;
+    kg1[lane - kPfPad] = 0.0;
     const int nm = vd.nmcp;
     const double alpha = vd.alpha, beta = vd.beta;
     const double *__restrict__ table = vd.pf_table;
@@ -141,8 +156,9 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
                 A1[r] = __builtin_fma(fv, m1, A1[r]);
             }
         }
-        const double g00 = pf_readlane(A0[0], 0), g10 = pf_readlane(A1[0], 0);
-        // k*g[k] (c2ir's first product, cepstrum.rs:181); kg[0] = 0 doubles as the "no term" slot
+        // ir[0] = exp(g[0]) (cepstrum.rs:177)
+        const double x00 = exp(pf_readlane(A0[0], 0)), x10 = exp(pf_readlane(A1[0], 0));
+        // k*g[k] (c2ir's first product, cepstrum.rs:181)
 #pragma unroll
         for (int r = 0; r < kIrBlk; r++) {
             const double kf = (double)(64 * r + lane);
@@ -153,35 +169,36 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- c2ir (cepstrum.rs:175-186), both chains; energy in the reference's order ----
-        double e0 = 0.0, e1 = 0.0;
+        // ---- c2ir (cepstrum.rs:175-186), both chains ----
+        double es0 = 0.0, es1 = 0.0; // per-lane partial sums of ir^2
 #pragma unroll
         for (int B = 0; B < kIrBlk; B++) {
-            double fin0 = 0.0, fin1 = 0.0; // final ir[64B + lane]
-            const double rcpv = rcp[64 * B + lane];
+            // d / n, correctly rounded, for every lane's current sum: q = d*(1/n); q += (d - q*n)*(1/n).
+            // Only lane j's value is final (and used) at step j; finished lanes keep adding x*0.
+            const double rcpv = rcp[64 * B + lane], dn = (double)(64 * B + lane);
+            auto quot = [&](double d) {
+                const double q = d * rcpv;
+                return __builtin_fma(__builtin_fma(-q, dn, d), rcpv, q);
+            };
+            const double *t0 = kg0 + lane, *t1 = kg1 + lane;
+#pragma unroll 8
             for (int j = 0; j < 64; j++) {
-                const int n = 64 * B + j;
-                double x0, x1;
+                double x0 = pf_readlane(quot(A0[B]), j), x1 = pf_readlane(quot(A1[B]), j);
                 if (B == 0 && j == 0) {
-                    x0 = exp(g00);
-                    x1 = exp(g10);
-                } else {
-                    // d / n, correctly rounded: q = d*(1/n); q += (d - q*n)*(1/n)
-                    const double d0 = pf_readlane(A0[B], j), d1 = pf_readlane(A1[B], j);
-                    const double rn = pf_readlane(rcpv, j), dn = (double)n;
-                    const double q0 = d0 * rn, q1 = d1 * rn;
-                    x0 = __builtin_fma(__builtin_fma(-q0, dn, d0), rn, q0);
-                    x1 = __builtin_fma(__builtin_fma(-q1, dn, d1), rn, q1);
+                    x0 = x00;
+                    x1 = x10;
                 }
-                e0 += x0 * x0;
-                e1 += x1 * x1;
-                fin0 = lane == j ? x0 : fin0;
-                fin1 = lane == j ? x1 : fin1;
-                // lanes past j take k = lane - j; the others read kg[0] == 0 (their sums are final)
-                const int k = lane > j ? lane - j : 0;
-                A0[B] = __builtin_fma(x0, kg0[k], A0[B]);
-                A1[B] = __builtin_fma(x1, kg1[k], A1[B]);
+                A0[B] = __builtin_fma(x0, t0[-j], A0[B]);
+                A1[B] = __builtin_fma(x1, t1[-j], A1[B]);
             }
+            // final ir[64B + lane]: the same quotient the sweep broadcast for this lane
+            double fin0 = quot(A0[B]), fin1 = quot(A1[B]);
+            if (B == 0 && lane == 0) {
+                fin0 = x00;
+                fin1 = x10;
+            }
+            es0 += fin0 * fin0;
+            es1 += fin1 * fin1;
             // Toeplitz push of block B into blocks r > B: k = 64(r-B) + lane - l in 1..575
             if (B + 1 < kIrBlk) {
                 for (int l = 0; l < 64; l++) {
@@ -196,6 +213,7 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
             }
         }
         // ---- gain correction (cepstrum.rs:33-34), b2mc, and the vocoder's own mc2b (mod.rs:118) ----
+        const double e0 = pf_wave_sum(es0), e1 = pf_wave_sum(es1);
         const double shift = log(e0 / e1) / 2.0;
         if (lane == 0)
             b1 += shift;
@@ -235,7 +253,7 @@ hipError_t launch_postfilter(const BatchDev &bd, const VocDev &vd, uint64_t nfra
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    const size_t lds = (size_t)kPfWaves * 2 * kIrLen * sizeof(double); // 36 KB: four blocks per CU
+    const size_t lds = (size_t)kPfWaves * 2 * kPfChain * sizeof(double); // 40 KB: four blocks per CU
     uint64_t blocks = (nframes + kPfWaves - 1) / kPfWaves;
     if (blocks > 256 * 4)
         blocks = 256 * 4;
