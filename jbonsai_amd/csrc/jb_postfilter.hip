@@ -23,8 +23,7 @@
 // k_postfilter: one wave per frame, both energies (e1, e2) computed side by side as two
 // independent chains.  The convolution recurrence is blocked by 64: lane = n mod 64, nine
 // accumulators per chain in registers.  Block B is finished by a 64-step triangular sweep (one ir
-// value becomes final per step: exact division by n through a reciprocal and one residual
-// correction, then broadcast), and then pushed into every later block as a Toeplitz product:
+// value becomes final per step: times the correctly rounded 1/n, then broadcast), and then pushed into every later block as a Toeplitz product:
 // ir[64B+l] comes from a register by readlane, k*g[k] from LDS with consecutive lanes on
 // consecutive words.  The bound is LDS bandwidth: every multiply-add takes one 8-byte LDS operand
 // per lane (512 B per wave instruction, 128 B/clk per CU).
@@ -106,6 +105,10 @@ __global__ void k_pf_first(BatchDev bd, VocDev vd)
 constexpr int kPfPad = 64;
 constexpr int kPfChain = kPfPad + kIrLen;
 
+// LDS pointer whose loads stay single ds_read_b64: 2 LDS cycles per wave instruction (256 B/clk per CU);
+// merged into ds_read2_b64 a pair costs 8 (128 B/clk).  volatile is what keeps them apart.
+typedef const volatile __attribute__((address_space(3))) double *pf_lds_ptr;
+
 __device__ __forceinline__ double pf_wave_sum(double v)
 {
 #pragma unroll
@@ -173,17 +176,14 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
         double es0 = 0.0, es1 = 0.0; // per-lane partial sums of ir^2
 #pragma unroll
         for (int B = 0; B < kIrBlk; B++) {
-            // d / n, correctly rounded, for every lane's current sum: q = d*(1/n); q += (d - q*n)*(1/n).
-            // Only lane j's value is final (and used) at step j; finished lanes keep adding x*0.
-            const double rcpv = rcp[64 * B + lane], dn = (double)(64 * B + lane);
-            auto quot = [&](double d) {
-                const double q = d * rcpv;
-                return __builtin_fma(__builtin_fma(-q, dn, d), rcpv, q);
-            };
-            const double *t0 = kg0 + lane, *t1 = kg1 + lane;
+            // d / n as d * (1/n) with the correctly rounded reciprocal (within one ulp of the reference's
+            // division), taken for every lane's current sum; only lane j's is final, and used, at step j.
+            // Finished lanes keep adding x * 0.
+            const double rcpv = rcp[64 * B + lane];
+            const pf_lds_ptr t0 = (pf_lds_ptr)(kg0 + lane), t1 = (pf_lds_ptr)(kg1 + lane);
 #pragma unroll 8
             for (int j = 0; j < 64; j++) {
-                double x0 = pf_readlane(quot(A0[B]), j), x1 = pf_readlane(quot(A1[B]), j);
+                double x0 = pf_readlane(A0[B] * rcpv, j), x1 = pf_readlane(A1[B] * rcpv, j);
                 if (B == 0 && j == 0) {
                     x0 = x00;
                     x1 = x10;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
                 A1[B] = __builtin_fma(x1, t1[-j], A1[B]);
             }
             // final ir[64B + lane]: the same quotient the sweep broadcast for this lane
-            double fin0 = quot(A0[B]), fin1 = quot(A1[B]);
+            double fin0 = A0[B] * rcpv, fin1 = A1[B] * rcpv;
             if (B == 0 && lane == 0) {
                 fin0 = x00;
                 fin1 = x10;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
             if (B + 1 < kIrBlk) {
                 for (int l = 0; l < 64; l++) {
                     const double u0 = pf_readlane(fin0, l), u1 = pf_readlane(fin1, l);
-                    const double *p0 = kg0 + lane - l, *p1 = kg1 + lane - l;
+                    const pf_lds_ptr p0 = (pf_lds_ptr)(kg0 + lane - l), p1 = (pf_lds_ptr)(kg1 + lane - l);
 #pragma unroll
                     for (int r = B + 1; r < kIrBlk; r++) {
                         A0[r] = __builtin_fma(u0, p0[64 * (r - B)], A0[r]);
@@ -253,10 +253,23 @@ hipError_t launch_postfilter(const BatchDev &bd, const VocDev &vd, uint64_t nfra
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    const size_t lds = (size_t)kPfWaves * 2 * kPfChain * sizeof(double); // 40 KB: four blocks per CU
+    const size_t lds = (size_t)kPfWaves * 2 * kPfChain * sizeof(double); // 40 KB per workgroup
+    // persistent grid: exactly the workgroups that are resident at once (a second, thinner round of
+    // workgroups would run at a fraction of the occupancy the latency-bound sweep needs)
+    static int per_cu = 0, ncu = 0;
+    if (!per_cu) {
+        int occ = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_postfilter, 64 * kPfWaves, lds) != hipSuccess || occ < 1)
+            occ = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return hipGetLastError();
+        ncu = prop.multiProcessorCount;
+        per_cu = occ;
+    }
     uint64_t blocks = (nframes + kPfWaves - 1) / kPfWaves;
-    if (blocks > 256 * 4)
-        blocks = 256 * 4;
+    if (blocks > (uint64_t)ncu * (uint64_t)per_cu)
+        blocks = (uint64_t)ncu * (uint64_t)per_cu;
     hipLaunchKernelGGL(k_postfilter, dim3((unsigned)blocks), dim3(64 * kPfWaves), lds, stream, vd, nframes);
     return hipGetLastError();
 }
