@@ -37,7 +37,13 @@ namespace jb {
 
 constexpr int kIrLen = 576; // IRLENG (coefficients.rs:76)
 constexpr int kIrBlk = kIrLen / 64;
-constexpr int kPfWaves = 4; // waves (= frames in flight) per workgroup
+#ifndef JB_PF_WAVES
+#define JB_PF_WAVES 2
+#endif
+#ifndef JB_PF_BCAST
+#define JB_PF_BCAST 1 // 1: finished block reaches the lanes through same-address LDS reads; 0: readlane
+#endif
+constexpr int kPfWaves = JB_PF_WAVES; // waves (= frames in flight) per workgroup
 
 __device__ __forceinline__ double pf_readlane(double v, int lane)
 {
@@ -104,6 +110,7 @@ __global__ void k_pf_first(BatchDev bd, VocDev vd)
 // already final multiply by in the triangular sweep (index 64 + lane - j <= 64, and kg[0] == 0).
 constexpr int kPfPad = 64;
 constexpr int kPfChain = kPfPad + kIrLen;
+constexpr int kPfWaveLds = 2 * kPfChain + 2 * 64; // + the finished block of each chain, for broadcast reads
 
 // LDS pointer whose loads stay single ds_read_b64: 2 LDS cycles per wave instruction (256 B/clk per CU);
 // merged into ds_read2_b64 a pair costs 8 (128 B/clk).  volatile is what keeps them apart.
@@ -119,10 +126,11 @@ __device__ __forceinline__ double pf_wave_sum(double v)
 
 __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_t nframes)
 {
-    extern __shared__ double pf_lds[]; // per wave: pad|kg0[576] | pad|kg1[576]
+    extern __shared__ double pf_lds[]; // per wave: pad|kg0[576] | pad|kg1[576] | fin0[64] | fin1[64]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    double *kg0 = pf_lds + (size_t)w * (2 * kPfChain) + kPfPad;
+    double *kg0 = pf_lds + (size_t)w * kPfWaveLds + kPfPad;
     double *kg1 = kg0 + kPfChain;
+    double *fl0 = kg1 + kIrLen, *fl1 = fl0 + 64;
     kg0[lane - kPfPad] = 0.0;
     kg1[lane - kPfPad] = 0.0;
     const int nm = vd.nmcp;
@@ -201,8 +209,20 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
             es1 += fin1 * fin1;
             // Toeplitz push of block B into blocks r > B: k = 64(r-B) + lane - l in 1..575
             if (B + 1 < kIrBlk) {
+                // ir[64B + l] reaches all lanes as a same-address LDS read (the VALU, not the LDS, is
+                // the busier unit here; two readlanes per value would go to the VALU)
+                fl0[lane] = fin0;
+                fl1[lane] = fin1;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const pf_lds_ptr q0 = (pf_lds_ptr)fl0, q1 = (pf_lds_ptr)fl1;
                 for (int l = 0; l < 64; l++) {
+#if JB_PF_BCAST
+                    const double u0 = q0[l], u1 = q1[l];
+#else
                     const double u0 = pf_readlane(fin0, l), u1 = pf_readlane(fin1, l);
+#endif
                     const pf_lds_ptr p0 = (pf_lds_ptr)(kg0 + lane - l), p1 = (pf_lds_ptr)(kg1 + lane - l);
 #pragma unroll
                     for (int r = B + 1; r < kIrBlk; r++) {
@@ -253,7 +273,7 @@ hipError_t launch_postfilter(const BatchDev &bd, const VocDev &vd, uint64_t nfra
     hipError_t e = hipGetLastError();
     if (e != hipSuccess)
         return e;
-    const size_t lds = (size_t)kPfWaves * 2 * kPfChain * sizeof(double); // 40 KB per workgroup
+    const size_t lds = (size_t)kPfWaves * kPfWaveLds * sizeof(double); // 11 KB per wave
     // persistent grid: exactly the workgroups that are resident at once (a second, thinner round of
     // workgroups would run at a fraction of the occupancy the latency-bound sweep needs)
     static int per_cu = 0, ncu = 0;

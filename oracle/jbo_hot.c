@@ -6,6 +6,10 @@
  *   A1-A9  src/mlpg_adjust/{mod.rs,mask.rs,mlpg.rs}, src/model/mean_vari.rs:21-37,
  *          src/model/voice/window.rs:19-76
  *   V1-V9  src/vocoder/{mod.rs,mlsa.rs,excitation.rs,cepstrum.rs:139-149}, src/speech.rs
+ *   X1     post-filter, beta > 0: src/vocoder/cepstrum.rs:23-37,153-186,
+ *          src/vocoder/coefficients.rs:65-78 -- PARITY UNPINNED for this part: the reference's
+ *          tests never set beta > 0, so nothing but analytic identities holds it
+ *          (tests/test_oracle_golden.py::test_postfilter_pieces)
  * Compile with -ffp-contract=off so that no FMA is formed.
  */
 #include "jbo_internal.h"
