@@ -279,6 +279,13 @@ int jb_write_wav_f64(const char *path, const double *pcm, size_t n_samples, uint
 int jb_synthesize_batch(const jb_engine *e, const char *const *label_lines,
                         const size_t *line_off, size_t n_utts, int32_t device, double **pcm,
                         size_t *n_samples);
+/* Same with the 16-bit sink fused into the vocoder (what the reference's callers do with the
+ * result: clamp to i16 and write WAV, examples/is-bonsai/main.rs:37-49): a quarter of the PCIe
+ * traffic.  pcm[u] library-owned (jb_pcm_i16_free each). */
+int jb_synthesize_batch_i16(const jb_engine *e, const char *const *label_lines,
+                            const size_t *line_off, size_t n_utts, int32_t device,
+                            int16_t **pcm, size_t *n_samples);
+void jb_pcm_i16_free(int16_t *pcm);
 
 /* Host front half only (tree search + durations): fills a state-level utterance
  * owned by the returned handle; used by tests and by jb_synthesize itself. */

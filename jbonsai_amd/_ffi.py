@@ -102,7 +102,7 @@ SYMBOLS = [
     "jb_engine_set_alpha", "jb_engine_get_alpha", "jb_engine_set_beta", "jb_engine_get_beta",
     "jb_engine_set_additional_half_tone", "jb_engine_get_additional_half_tone",
     "jb_engine_num_voices", "jb_engine_num_streams", "jb_engine_num_states",
-    "jb_engine_set_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_write_wav_i16", "jb_write_wav_f64", "jb_synthesize_batch",
+    "jb_engine_set_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_write_wav_i16", "jb_write_wav_f64", "jb_synthesize_batch", "jb_synthesize_batch_i16", "jb_pcm_i16_free",
     "jb_engine_model_shape", "jb_engine_pdf_table", "jb_engine_tree_index",
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
     "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",

@@ -86,6 +86,9 @@ struct Batch {
     int run(bool timed);
     int sync();
     int read(const void *dev, void *dst, size_t bytes);
+    // whole PCM slab -> one host buffer per utterance (dst[u] may be null for empty utterances);
+    // elem = 8 (f64) or 2 (JB_BATCH_PCM_I16)
+    int read_pcm_split(void *const *dst, size_t elem);
 };
 
 } // namespace jb

@@ -10,6 +10,7 @@ tests read like the reference's own (src/lib.rs:38-160).
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import List, Sequence
 
 import numpy as np
@@ -53,6 +54,10 @@ def _bind(L):
     L.jb_pcm_free.argtypes = [dp]
     L.jb_pcm_free.restype = None
     L.jb_synthesize_batch.argtypes = [vp, cpp, C.POINTER(sz), sz, C.c_int32, C.POINTER(dp), C.POINTER(sz)]
+    L.jb_synthesize_batch_i16.argtypes = [vp, cpp, C.POINTER(sz), sz, C.c_int32,
+                                          C.POINTER(C.POINTER(C.c_int16)), C.POINTER(sz)]
+    L.jb_pcm_i16_free.argtypes = [C.POINTER(C.c_int16)]
+    L.jb_pcm_i16_free.restype = None
     L.jb_engine_states.argtypes = [vp, cpp, sz, C.POINTER(vp)]
     L.jb_states_utt.argtypes = [vp]
     L.jb_states_utt.restype = C.POINTER(F.StateUtt)
@@ -236,21 +241,30 @@ class Engine:
             if pcm:
                 self._L.jb_pcm_free(pcm)
 
-    def synthesize_batch(self, utterances: Sequence[Sequence[str]], device: int = -1) -> List[np.ndarray]:
+    def synthesize_batch(self, utterances: Sequence[Sequence[str]], device: int = -1,
+                         i16: bool = False) -> List[np.ndarray]:
+        """jb_synthesize_batch / jb_synthesize_batch_i16.  The arrays view the library-owned buffers
+        (no copy); each is released with jb_pcm_free / jb_pcm_i16_free when its array dies."""
         flat = [l for u in utterances for l in u]
         off = np.cumsum([0] + [len(u) for u in utterances]).astype(np.uint64)
         B = len(utterances)
         offs = (C.c_size_t * (B + 1))(*[int(x) for x in off])
-        pcm = (C.POINTER(C.c_double) * max(1, B))()
+        ety = C.c_int16 if i16 else C.c_double
+        pcm = (C.POINTER(ety) * max(1, B))()
         ns = (C.c_size_t * max(1, B))()
-        try:
-            F.check(self._L.jb_synthesize_batch(self._h, _lines(flat), offs, B, device, pcm, ns))
-            return [np.ctypeslib.as_array(pcm[i], shape=(ns[i],)).copy() if ns[i] else np.zeros(0)
-                    for i in range(B)]
-        finally:
-            for i in range(B):
-                if pcm[i]:
-                    self._L.jb_pcm_free(pcm[i])
+        fn = self._L.jb_synthesize_batch_i16 if i16 else self._L.jb_synthesize_batch
+        free = self._L.jb_pcm_i16_free if i16 else self._L.jb_pcm_free
+        F.check(fn(self._h, _lines(flat), offs, B, device, pcm, ns))
+        out = []
+        for i in range(B):
+            if not ns[i]:
+                out.append(np.zeros(0, dtype=np.int16 if i16 else np.float64))
+                continue
+            buf = (ety * ns[i]).from_address(C.addressof(pcm[i].contents))
+            arr = np.frombuffer(buf, dtype=np.int16 if i16 else np.float64)
+            weakref.finalize(buf, free, C.cast(C.addressof(pcm[i].contents), C.POINTER(ety)))
+            out.append(arr)
+        return out
 
     def generator(self, labels: Sequence[str]) -> "SpeechGenerator":
         h = C.c_void_p()

@@ -195,3 +195,22 @@ def test_engine_beta_postfilter(oracle_voice):
     assert len(got) == len(want) == 66480
     den = np.sqrt(np.mean(want * want))
     assert np.sqrt(np.mean((got - want) ** 2)) / den <= 1e-9
+
+
+def test_synthesize_batch_i16_and_staged_readback(engine):
+    """jb_synthesize_batch_i16 = the f64 result through the reference callers' sink
+    (value.min(i16::MAX).max(i16::MIN) as i16, examples/is-bonsai/main.rs:44-48), and both entries
+    bring the slab back through the pinned staging ring: utterances of different lengths, more
+    than one 16 MB slot in total, buffers owned by the library until the arrays die."""
+    long = list(SAMPLE_SENTENCE_2) * 24  # ~50 s -> 19 MB of f64 per utterance
+    utts = [SAMPLE_SENTENCE_1, long, [], SAMPLE_SENTENCE_2, long, SAMPLE_SENTENCE_1]
+    f64 = engine.synthesize_batch(utts)
+    i16 = engine.synthesize_batch(utts, i16=True)
+    assert sum(x.nbytes for x in f64) > 2 * (16 << 20)
+    assert [len(x) for x in f64] == [len(x) for x in i16] and len(f64[2]) == 0
+    for a, b in zip(f64, i16):
+        assert b.dtype == np.int16
+        assert np.array_equal(np.clip(a, -32768.0, 32767.0).astype(np.int16), b)
+    # same utterance twice in the batch, and against the single-utterance entry
+    assert np.array_equal(f64[0], f64[5]) and np.array_equal(f64[1], f64[4])
+    assert np.array_equal(f64[3], engine.synthesize(SAMPLE_SENTENCE_2))
