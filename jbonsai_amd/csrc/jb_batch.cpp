@@ -109,12 +109,111 @@ int noise_table(int device, size_t need, const double **ptr, size_t *len)
 }
 
 // ---- batch -----------------------------------------------------------------
+// --------------------------------------------------------------------------
+// Device memory of finished batches is kept per device and handed to the next batch instead of
+// going back to the driver: a batch of config 2 takes ~60 allocations and tens of GB, and
+// hipMalloc/hipFree of that cost 25-250 ms per jb_synthesize_batch call (more than the 48 ms of
+// GPU work for 64 x 157 s).  Blocks are rounded to 2 MB (4 KB below that) and reused when the
+// cached block is at most a quarter larger than the request.  JB_DEVICE_POOL_MB caps what is kept
+// (default 65536, 0 = off); jb_release_cached_memory() empties the pool; an out-of-memory
+// hipMalloc empties it and retries once.  Reused memory is NOT zero: dalloc(zero) clears.
+namespace {
+struct DevPool {
+    std::multimap<size_t, void *> free_;
+    size_t cached = 0;
+};
+std::mutex g_pool_mu;
+std::map<int, DevPool> g_pool;
+
+size_t pool_cap()
+{
+    static const size_t cap = [] {
+        const char *ev = getenv("JB_DEVICE_POOL_MB");
+        return (size_t)(ev ? std::max(0L, atol(ev)) : 65536L) << 20;
+    }();
+    return cap;
+}
+
+size_t pool_round(size_t bytes)
+{
+    const size_t g = bytes >= (2u << 20) ? (2u << 20) : 4096u;
+    return (bytes + g - 1) / g * g;
+}
+
+void pool_trim_locked(DevPool &dp, size_t keep)
+{
+    // largest blocks first: they are the ones a differently shaped batch is least likely to fit
+    while (dp.cached > keep && !dp.free_.empty()) {
+        auto it = std::prev(dp.free_.end());
+        hipFree(it->second);
+        dp.cached -= it->first;
+        dp.free_.erase(it);
+    }
+}
+
+hipError_t pool_alloc(int device, size_t bytes, void **out, size_t *got)
+{
+    const size_t need = pool_round(bytes);
+    *got = need;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        DevPool &dp = g_pool[device];
+        auto it = dp.free_.lower_bound(need);
+        if (it != dp.free_.end() && it->first <= need + need / 4) {
+            *out = it->second;
+            *got = it->first;
+            dp.cached -= it->first;
+            dp.free_.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, need);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_trim_locked(g_pool[device], 0);
+        e = hipMalloc(out, need);
+    }
+    return e;
+}
+
+void pool_free(int device, void *p, size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (pool_cap() == 0) {
+        hipFree(p);
+        return;
+    }
+    DevPool &dp = g_pool[device];
+    dp.free_.emplace(bytes, p);
+    dp.cached += bytes;
+    if (dp.cached > pool_cap())
+        pool_trim_locked(dp, pool_cap());
+}
+} // namespace
+
+void release_cached_memory()
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : g_pool) {
+        hipSetDevice(kv.first);
+        pool_trim_locked(kv.second, 0);
+    }
+    if (cur >= 0)
+        hipSetDevice(cur);
+}
+
 Batch::~Batch()
 {
     if (device >= 0)
         hipSetDevice(device);
-    for (void *p : allocs)
-        hipFree(p);
+    // everything this batch enqueued has to be finished before another batch may get the memory
+    if (!allocs.empty())
+        hipDeviceSynchronize();
+    for (auto &a : allocs)
+        pool_free(device, a.first, a.second);
     if (ev0)
         hipEventDestroy(ev0);
     if (ev1)
@@ -142,13 +241,14 @@ template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
     if (n == 0)
         n = 1;
     void *v = nullptr;
-    hipError_t e = hipMalloc(&v, n * sizeof(T));
+    size_t got = 0;
+    hipError_t e = pool_alloc(device, n * sizeof(T), &v, &got);
     if (e != hipSuccess) {
         char msg[128];
         snprintf(msg, sizeof msg, "hipMalloc(%zu bytes)", n * sizeof(T));
         return hip_fail(e, msg);
     }
-    allocs.push_back(v);
+    allocs.emplace_back(v, got);
     bytes_alloc += n * sizeof(T);
     if (zero) {
         e = hipMemset(v, 0, n * sizeof(T));
@@ -1410,6 +1510,12 @@ int jb_batch_read_track(jb_batch *hb, size_t i, uint32_t si, double *dst, size_t
     if (ne == 0)
         return JB_OK;
     return b->read(b->sd[si].out + (size_t)b->frame_off[i] * L, dst, ne * sizeof(double));
+}
+
+int jb_release_cached_memory(void)
+{
+    jb::release_cached_memory();
+    return JB_OK;
 }
 
 int jb_batch_read_coefficients(jb_batch *hb, size_t i, double *dst, size_t cap)

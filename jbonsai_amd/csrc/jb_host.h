@@ -16,6 +16,7 @@ extern thread_local std::string g_err;
 void set_error(const std::string &s);
 int hip_fail(hipError_t e, const char *what);
 int noise_table(int device, size_t need, const double **ptr, size_t *len);
+void release_cached_memory(); // empties the per-device pools of finished batches' memory
 
 // Device-resident pdf tables of a voice set (jb_pdf_set) and an indexed batch source
 struct PdfSet {
@@ -68,7 +69,7 @@ struct Batch {
     uint32_t *order_dev = nullptr;   // its launch permutation
     VocWork *redo_dev = nullptr;
     VocWork *gen_work_dev = nullptr; // one item per frame of utterance 0 (streaming generator)
-    std::vector<void *> allocs;
+    std::vector<std::pair<void *, size_t>> allocs; // device blocks (pointer, pooled size)
     std::map<std::pair<const void *, size_t>, const void *> uploaded;
 
     ~Batch();
