@@ -10,7 +10,7 @@ from jbonsai_amd import synth
 from oracle import oracle as O
 from tests.conftest import VOICE
 from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
-from tests.helpers import rel_rms
+from tests.helpers import oracle_states, rel_rms, to_utt, voice_info
 
 pytestmark = pytest.mark.gpu
 DMAX = 1.7976931348623157e308
@@ -381,3 +381,24 @@ def test_one_very_long_utterance(ctx):
     e = rel_rms(got[0], ref)
     print("160 k frames: rel RMS vs oracle", e, info)
     assert e <= 1e-9
+
+
+def test_device_pool_reuse_release_and_dirty_blocks(oracle_voice):
+    """Device blocks of finished batches go to the next batch (dirty, not zeroed) or back to the
+    driver with jb_release_cached_memory: same bits either way, for equal and for different shapes."""
+    v = oracle_voice
+    d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
+    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
+    vi = voice_info(v)
+    L = J.lib()
+    assert L.jb_release_cached_memory() == 0
+    fresh1 = J.paramgen_vocode_batch(vi, [to_utt(d1, s1)])[0]
+    fresh2 = J.paramgen_vocode_batch(vi, [to_utt(d2, s2), to_utt(d1, s1)])
+    # now every block comes out of the pool, written by the batches before
+    for _ in range(3):
+        again2 = J.paramgen_vocode_batch(vi, [to_utt(d2, s2), to_utt(d1, s1)])
+        again1 = J.paramgen_vocode_batch(vi, [to_utt(d1, s1)])[0]
+        assert np.array_equal(again1, fresh1)
+        assert np.array_equal(again2[0], fresh2[0]) and np.array_equal(again2[1], fresh2[1])
+    assert L.jb_release_cached_memory() == 0
+    assert np.array_equal(J.paramgen_vocode_batch(vi, [to_utt(d1, s1)])[0], fresh1)
