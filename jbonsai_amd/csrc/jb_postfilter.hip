@@ -191,6 +191,7 @@ __global__ __launch_bounds__(64 * kPfWaves) void k_postfilter(VocDev vd, uint64_
             const pf_lds_ptr t0 = (pf_lds_ptr)(kg0 + lane), t1 = (pf_lds_ptr)(kg1 + lane);
 #pragma unroll 8
             for (int j = 0; j < 64; j++) {
+                // (v_readlane, not ds_bpermute: the crossbar's latency sits on the serial chain, 349 vs 252 ms)
                 double x0 = pf_readlane(A0[B] * rcpv, j), x1 = pf_readlane(A1[B] * rcpv, j);
                 if (B == 0 && j == 0) {
                     x0 = x00;
