@@ -214,3 +214,21 @@ def test_synthesize_batch_i16_and_staged_readback(engine):
     # same utterance twice in the batch, and against the single-utterance entry
     assert np.array_equal(f64[0], f64[5]) and np.array_equal(f64[1], f64[4])
     assert np.array_equal(f64[3], engine.synthesize(SAMPLE_SENTENCE_2))
+
+
+def test_generator_with_postfilter_equals_synthesize():
+    """Streaming generate_step with Condition::set_beta: the first step starts from the un-filtered
+    coefficients like generate_all does (vocoder/mod.rs:80-89,116-118)."""
+    e = J.Engine.load([VOICE])
+    e.condition.set_beta(0.4)
+    whole = e.synthesize(SAMPLE_SENTENCE_2)
+    g = e.generator(SAMPLE_SENTENCE_2)
+    fp = g.fperiod()
+    buf = np.zeros(fp)
+    out = []
+    for _ in range(3):
+        assert g.generate_step(buf) == fp
+        out.append(buf.copy())
+    got = np.concatenate(out + [g.generate_all()])
+    assert len(got) == len(whole) == 100800
+    assert rel_rms(got, whole) < 1e-12
