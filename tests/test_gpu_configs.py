@@ -402,3 +402,64 @@ def test_device_pool_reuse_release_and_dirty_blocks(oracle_voice):
         assert np.array_equal(again2[0], fresh2[0]) and np.array_equal(again2[1], fresh2[1])
     assert L.jb_release_cached_memory() == 0
     assert np.array_equal(J.paramgen_vocode_batch(vi, [to_utt(d1, s1)])[0], fresh1)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_shape_combinations(ctx, seed):
+    """Seeded random COMBINATIONS of what the tests above vary one at a time: mel-cepstral order,
+    frame period, LPF order, warping alpha, volume, post-filter beta, a ragged batch with an empty
+    utterance -- every utterance against the oracle."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    rng = np.random.default_rng(1000 + seed)
+    L = vi.streams[0].vector_length
+    W = len(vi.streams[0].windows)
+    L2 = int(rng.choice([8, 13, 20, 25, 30, 35]))
+    fs, fp = [(16000, 80), (48000, 240), (44100, 220), (48000, 96), (22050, 100), (48000, 120)][seed - 1]
+    nlpf = int(rng.choice([7, 15, 23, 31]))
+    alpha = float(rng.choice([0.42, 0.5, 0.55]))
+    beta = float(rng.choice([0.0, 0.0, 0.2, 0.5]))
+    volume = float(rng.choice([1.0, 0.5, 1.7]))
+    lens = [int(x) for x in rng.integers(1, 900, size=4)] + [0]
+    utts = []
+    for k, T in enumerate(lens):
+        if T == 0:
+            u = synth.synth_utterance(tab, 5, 50 + k)
+            S = 0
+            streams = [dataclasses.replace(s, mean=s.mean[:0], var=s.var[:0],
+                                           msd=None if s.msd is None else s.msd[:0],
+                                           gv_switch=None if s.gv_switch is None else s.gv_switch[:0])
+                       for s in u.streams]
+            u = J.Utterance(u.durations[:0], streams)
+        else:
+            u = synth.synth_utterance(tab, T, 50 * seed + k)
+        S = len(u.durations)
+        m0, s2 = u.streams[0], u.streams[2]
+        lo = (vi.streams[2].vector_length - nlpf) // 2
+        st0 = dataclasses.replace(m0, mean=m0.mean.reshape(S, W, L)[:, :, :L2].reshape(S, W * L2).copy(),
+                                  var=m0.var.reshape(S, W, L)[:, :, :L2].reshape(S, W * L2).copy(),
+                                  gv_mean=m0.gv_mean[:L2].copy(), gv_var=m0.gv_var[:L2].copy())
+        st2 = dataclasses.replace(s2, mean=s2.mean[:, lo:lo + nlpf].copy(), var=s2.var[:, lo:lo + nlpf].copy())
+        utts.append(J.Utterance(u.durations, [st0, u.streams[1], st2]))
+    streams = [dataclasses.replace(vi.streams[0], vector_length=L2), vi.streams[1],
+               dataclasses.replace(vi.streams[2], vector_length=nlpf)]
+    vi2 = dataclasses.replace(vi, sampling_frequency=fs, fperiod=fp, alpha=alpha, beta=beta, volume=volume,
+                              streams=streams)
+    got, info = run(vi2, utts)
+    for u, g, T in zip(utts, got, lens):
+        assert len(g) == T * fp
+        if T == 0:
+            continue
+        sts = []
+        for i, s in enumerate(u.streams):
+            si = vi2.streams[i]
+            msd = s.msd if s.msd is not None else np.full(len(u.durations), DMAX)
+            sts.append(O.StreamStates(si.vector_length, len(si.windows), si.is_msd, si.use_gv,
+                                      [len(w) for w in si.windows], [c for w in si.windows for c in w],
+                                      s.mean, s.var, msd, s.gv_mean, s.gv_var, s.gv_switch,
+                                      s.gv_weight, s.msd_threshold))
+        tr = [O.mlpg(s, u.durations) for s in sts]
+        ref = O.vocoder(fs, fp, alpha, volume, tr[1][:, 0], tr[0], tr[2], beta=beta)
+        assert np.isfinite(ref).all()
+        assert rel_rms(g, ref) <= 1e-9, (seed, L2, fs, fp, nlpf, alpha, beta, volume, T)
