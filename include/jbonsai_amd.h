@@ -196,9 +196,10 @@ int jb_batch_read_pcm(jb_batch *b, size_t utt, double *dst, size_t cap);
 int jb_batch_read_pcm_i16(jb_batch *b, size_t utt, int16_t *dst, size_t cap);
 /* Parameter track of stream s ([T][L], NODATA in unvoiced frames); needs KEEP_TRACKS. */
 int jb_batch_read_track(jb_batch *b, size_t utt, uint32_t stream, double *dst, size_t cap);
-/* Device memory of freed batches is kept per device for the next batch (hipMalloc/hipFree of a
- * config-2 batch cost more than its GPU work); this hands it back to the driver.  The cap is
- * JB_DEVICE_POOL_MB (environment, default 65536; 0 disables the pool). */
+/* Device memory and HIP streams of freed batches are kept per device for the next batch
+ * (hipMalloc/hipFree of a config-2 batch cost more than its GPU work, stream creation more than a
+ * one-sentence synthesis); this hands them back to the driver.  The memory cap is
+ * JB_DEVICE_POOL_MB (environment, default 65536; 0 disables the memory pool). */
 int jb_release_cached_memory(void);
 /* Parity tap: the MLSA filter coefficients the vocoder interpolates between, [T][nmcp] =
  * mc2b(postfilter_mcp(spectrum)) per frame (src/vocoder/mod.rs:116-118). */

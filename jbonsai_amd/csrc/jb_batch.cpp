@@ -192,11 +192,51 @@ void pool_free(int device, void *p, size_t bytes)
 }
 } // namespace
 
+// Streams are kept the same way: hipStreamCreateWithFlags / hipStreamDestroy take 2.4 / 1.9 ms each on
+// this stack, three of each per batch = 13 of the 24 ms of a one-sentence jb_synthesize call.
+namespace {
+std::map<int, std::vector<hipStream_t>> g_streams; // guarded by g_pool_mu
+constexpr size_t kStreamPoolMax = 48;
+
+hipError_t stream_acquire(int device, hipStream_t *st)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto &v = g_streams[device];
+        if (!v.empty()) {
+            *st = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+}
+
+void stream_release(int device, hipStream_t st)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto &v = g_streams[device];
+        if (v.size() < kStreamPoolMax) {
+            v.push_back(st);
+            return;
+        }
+    }
+    hipStreamDestroy(st);
+}
+} // namespace
+
 void release_cached_memory()
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
     int cur = -1;
     (void)hipGetDevice(&cur);
+    for (auto &kv : g_streams) {
+        hipSetDevice(kv.first);
+        for (hipStream_t st : kv.second)
+            hipStreamDestroy(st);
+        kv.second.clear();
+    }
     for (auto &kv : g_pool) {
         hipSetDevice(kv.first);
         pool_trim_locked(kv.second, 0);
@@ -210,7 +250,8 @@ Batch::~Batch()
     if (device >= 0)
         hipSetDevice(device);
     // everything this batch enqueued has to be finished before another batch may get the memory
-    if (!allocs.empty())
+    // or the streams
+    if (!allocs.empty() || stream)
         hipDeviceSynchronize();
     for (auto &a : allocs)
         pool_free(device, a.first, a.second);
@@ -228,11 +269,17 @@ Batch::~Batch()
     for (hipEvent_t ev : {ev_mlpg_done, ev_voc_done})
         if (ev)
             hipEventDestroy(ev);
+    auto drop = [&](hipStream_t st) {
+        if (cu_split)
+            hipStreamDestroy(st); // CU-masked streams are not pooled
+        else
+            stream_release(device, st);
+    };
     for (hipStream_t st : {stream_lf0, stream_lpf, stream_voc})
         if (st && st != stream)
-            hipStreamDestroy(st);
+            drop(st);
     if (stream)
-        hipStreamDestroy(stream);
+        drop(stream);
 }
 
 template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
@@ -505,8 +552,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     for (uint32_t i = 0; i < 256; i++)
         ((i / 8 >= 32 - b->cu_split) ? mask_pg : mask_voc)[i / 32] |= 1u << (i % 32);
     auto mkstream = [&](hipStream_t *st, const uint32_t *mask) {
-        return b->cu_split ? hipExtStreamCreateWithCUMask(st, 8, mask)
-                           : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+        return b->cu_split ? hipExtStreamCreateWithCUMask(st, 8, mask) : stream_acquire(b->device, st);
     };
     e = mkstream(&b->stream, mask_pg);
     if (e != hipSuccess)
@@ -812,7 +858,14 @@ int Batch::build_work(const jb_batch_opts *opts)
         if (const char *e = getenv("JB_CHUNK_TARGET"))
             target = strtoull(e, nullptr, 10);
         uint64_t c = target ? (sumT + target - 1) / target : 0;
-        ch = (uint32_t)std::max<uint64_t>(c, 4ull * warmup_frames);
+        // A batch that cannot give every SIMD a wave is a latency case: the launch takes as long as ONE
+        // item (warm-up + chunk frames, ~0.25 us per sample), so the chunks shrink until there is an
+        // item per SIMD, down to 16 frames (one 1.4 s sentence: 24.7 -> 17.5 ms per call; below 16 the
+        // extra hand-off positions and their occasional redo round cost more than they save).
+        uint64_t floor_ = std::min<uint64_t>(std::max<uint64_t>((sumT + 1023) / 1024, 16), 4ull * warmup_frames);
+        if (const char *e = getenv("JB_CHUNK_FLOOR"))
+            floor_ = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
+        ch = (uint32_t)std::max<uint64_t>(c, floor_);
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;

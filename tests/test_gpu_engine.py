@@ -213,7 +213,9 @@ def test_synthesize_batch_i16_and_staged_readback(engine):
         assert np.array_equal(np.clip(a, -32768.0, 32767.0).astype(np.int16), b)
     # same utterance twice in the batch, and against the single-utterance entry
     assert np.array_equal(f64[0], f64[5]) and np.array_equal(f64[1], f64[4])
-    assert np.array_equal(f64[3], engine.synthesize(SAMPLE_SENTENCE_2))
+    # (not bitwise: the chunk length of the time-chunked vocoder follows the batch's total length, and
+    # hand-offs are certified to 1e-9 of the filter state, not to the last bit)
+    assert rel_rms(f64[3], engine.synthesize(SAMPLE_SENTENCE_2)) <= 1e-10
 
 
 def test_generator_with_postfilter_equals_synthesize():
