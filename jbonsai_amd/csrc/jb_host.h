@@ -71,6 +71,13 @@ struct Batch {
     VocWork *gen_work_dev = nullptr; // one item per frame of utterance 0 (streaming generator)
     std::vector<std::pair<void *, size_t>> allocs; // device blocks (pointer, pooled size)
     std::map<std::pair<const void *, size_t>, const void *> uploaded;
+    struct UploadChunk { // arena for small input arrays: one H2D copy per chunk
+        uint8_t *dev = nullptr;
+        std::unique_ptr<uint8_t[]> host;
+        size_t used = 0, sent = 0;
+    };
+    std::vector<UploadChunk> up_chunks;
+    int flush_uploads();
 
     ~Batch();
     template <class T> int dalloc(T **p, size_t n, bool zero);
