@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <thread>
@@ -809,113 +810,205 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
         n_samples[u] = 0;
     }
     std::vector<std::unique_ptr<jb::States>> sts(n_utts);
-    std::vector<jb_state_utt> utts(n_utts);
     for (size_t u = 0; u < n_utts; u++)
         sts[u].reset(new jb::States());
-    const jb_pdf_set *pset_ = nullptr;
-    // JB_E2E_TIMING=1: wall time of the four phases on stderr (tools/e2e_engine.py)
+    // JB_E2E_TIMING=1: time spent in the four phases on stderr (tools/e2e_engine.py); with more than
+    // one group they overlap, so their sum exceeds the wall time
     const bool timing = getenv("JB_E2E_TIMING") && atoi(getenv("JB_E2E_TIMING")) != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
         return std::chrono::duration<double, std::milli>(b2 - a).count();
     };
     const auto t_start = now();
-    {
-        // The front half (label parse, tree search, pdf blend, durations: label.rs, model/mod.rs:80-156,
-        // duration.rs) is independent per utterance and read-only on the engine: host threads, one
-        // utterance at a time each (JB_HOST_THREADS, default min(16, cores)).  It is ~90 ms per 128 s
-        // utterance and thread against ~0.5 ms of GPU time, so it is what bounds this entry point.
-        unsigned nt = std::thread::hardware_concurrency();
-        nt = nt ? std::min(nt, 16u) : 1u;
-        if (const char *ev = getenv("JB_HOST_THREADS"))
-            nt = (unsigned)std::max(1, atoi(ev));
-        nt = (unsigned)std::min<size_t>(nt, n_utts);
-        // device-side gather + blend unless JB_HOST_BLEND=1 (A/B: both produce the same bits)
-        const bool host_blend = getenv("JB_HOST_BLEND") && atoi(getenv("JB_HOST_BLEND")) != 0;
-        const jb_pdf_set *pset = nullptr;
-        if (!host_blend) {
-            int dev = device;
-            if (dev < 0 && hipGetDevice(&dev) != hipSuccess) {
-                jb::set_error("no HIP device");
-                return JB_ERR_DEVICE;
-            }
-            int prc = CENG(e)->pdf_set_for(dev, &pset);
-            if (prc)
-                return prc;
-            device = dev;
+    // The front half (label parse, tree search, pdf blend, durations: label.rs, model/mod.rs:80-156,
+    // duration.rs) is independent per utterance and read-only on the engine: host threads, one
+    // utterance at a time each (JB_HOST_THREADS, default min(16, cores)).  It is ~13 ms per 128 s
+    // utterance and thread against ~0.7 ms of GPU time.
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min(nt, 16u) : 1u;
+    if (const char *ev = getenv("JB_HOST_THREADS"))
+        nt = (unsigned)std::max(1, atoi(ev));
+    // device-side gather + blend unless JB_HOST_BLEND=1 (A/B: both produce the same bits)
+    const bool host_blend = getenv("JB_HOST_BLEND") && atoi(getenv("JB_HOST_BLEND")) != 0;
+    const jb_pdf_set *pset = nullptr;
+    if (!host_blend) {
+        int dev = device;
+        if (dev < 0 && hipGetDevice(&dev) != hipSuccess) {
+            jb::set_error("no HIP device");
+            return JB_ERR_DEVICE;
         }
-        const bool indexed = pset != nullptr;
-        pset_ = pset;
-        std::vector<int> rcs(n_utts, JB_OK);
-        std::vector<std::string> errs(n_utts);
-        std::atomic<size_t> next{0};
+        int prc = CENG(e)->pdf_set_for(dev, &pset);
+        if (prc)
+            return prc;
+        device = dev;
+    }
+    const bool indexed = pset != nullptr;
+
+    // A request can go through in groups, three stages overlapped: while the GPU works on group g the
+    // host threads run the front half of group g+1 and a finisher thread brings the PCM of group g-1
+    // back.  Measured for 64 x 157 s (front half / GPU / link = 54 / 46 / 86 ms one after the other):
+    // with f64 PCM the read-back, the longest stage, slows down by more than the overlap gains when
+    // kernels and host threads run beside it (203 -> 242 ms with two groups, 299 ms with four), so f64
+    // requests stay one batch; with the 16-bit sink two groups win (134 -> 113 ms), four do not.
+    // Groups split the utterances by label count; JB_SYNTH_GROUPS overrides.
+    size_t ngroups = 1;
+    const size_t total_lines = n_utts ? line_off[n_utts] - line_off[0] : 0;
+    if (elem == 2 && n_utts >= 8 && total_lines >= 16000)
+        ngroups = 2;
+    if (const char *ev = getenv("JB_SYNTH_GROUPS"))
+        ngroups = (size_t)std::max(1, atoi(ev));
+    ngroups = std::max<size_t>(1, std::min(ngroups, n_utts));
+    std::vector<size_t> glo(ngroups + 1, n_utts);
+    glo[0] = 0;
+    for (size_t g = 1, u = 0; g < ngroups; g++) {
+        const size_t want = line_off[0] + total_lines * g / ngroups;
+        while (u < n_utts && line_off[u] < want)
+            u++;
+        glo[g] = std::max(u, glo[g - 1]);
+    }
+    std::vector<std::unique_ptr<jb::Batch>> batches(ngroups);
+    double t_front = 0, t_create = 0, t_wait = 0, t_d2h = 0;
+
+    auto front = [&](size_t lo, size_t hi) -> int {
+        const auto t0 = now();
+        std::vector<int> rcs(hi - lo, JB_OK);
+        std::vector<std::string> errs(hi - lo);
+        std::atomic<size_t> next{lo};
         auto work = [&]() {
-            for (size_t u; (u = next.fetch_add(1)) < n_utts;) {
-                rcs[u] = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u], indexed);
-                if (rcs[u])
-                    errs[u] = jb::g_err; // the worker's thread-local message
+            for (size_t u; (u = next.fetch_add(1)) < hi;) {
+                rcs[u - lo] = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u], indexed);
+                if (rcs[u - lo])
+                    errs[u - lo] = jb::g_err; // the worker's thread-local message
             }
         };
-        if (nt <= 1) {
+        const unsigned n = (unsigned)std::min<size_t>(nt, hi - lo);
+        if (n <= 1) {
             work();
         } else {
             std::vector<std::thread> pool;
-            for (unsigned k = 0; k < nt; k++)
+            for (unsigned k = 0; k < n; k++)
                 pool.emplace_back(work);
             for (auto &t : pool)
                 t.join();
         }
-        for (size_t u = 0; u < n_utts; u++) {
-            if (rcs[u]) {
-                jb::set_error(errs[u]);
-                return rcs[u];
+        t_front += ms(t0, now());
+        for (size_t u = lo; u < hi; u++)
+            if (rcs[u - lo]) {
+                jb::set_error(errs[u - lo]);
+                return rcs[u - lo];
             }
-            utts[u] = sts[u]->utt;
+        return JB_OK;
+    };
+    auto launch = [&](size_t g) -> int {
+        const auto t0 = now();
+        const size_t lo = glo[g], hi = glo[g + 1];
+        jb_batch_opts opts{};
+        opts.device = device;
+        opts.flags = elem == 2 ? JB_BATCH_PCM_I16 : 0;
+        jb::Batch *b = nullptr;
+        int rc;
+        if (indexed) {
+            std::vector<jb_index_utt> iu(hi - lo);
+            for (size_t u = lo; u < hi; u++)
+                iu[u - lo] = sts[u]->iutt;
+            rc = jb_batch_create_indexed(&CENG(e)->desc, pset, iu.data(), hi - lo, &opts, (jb_batch **)&b);
+        } else {
+            std::vector<jb_state_utt> su(hi - lo);
+            for (size_t u = lo; u < hi; u++)
+                su[u - lo] = sts[u]->utt;
+            rc = jb::Batch::create(&CENG(e)->desc, su.data(), hi - lo, &opts, &b);
         }
-    }
-    const auto t_front = now();
-    jb_batch_opts opts{};
-    opts.device = device;
-    opts.flags = elem == 2 ? JB_BATCH_PCM_I16 : 0;
-    jb::Batch *b = nullptr;
-    int rc;
-    if (pset_) {
-        std::vector<jb_index_utt> iu(n_utts);
-        for (size_t u = 0; u < n_utts; u++)
-            iu[u] = sts[u]->iutt;
-        rc = jb_batch_create_indexed(&CENG(e)->desc, pset_, iu.data(), n_utts, &opts, (jb_batch **)&b);
+        if (rc)
+            return rc;
+        batches[g].reset(b);
+        rc = b->run(false);
+        t_create += ms(t0, now());
+        return rc;
+    };
+    auto finish = [&](size_t g) -> int {
+        const size_t lo = glo[g], hi = glo[g + 1];
+        jb::Batch *b = batches[g].get();
+        auto t0 = now();
+        int rc = b->sync();
+        t_wait += ms(t0, now());
+        if (rc)
+            return rc;
+        t0 = now();
+        for (size_t u = lo; u < hi; u++) {
+            const size_t ns = (size_t)b->T[u - lo] * b->voice.fperiod;
+            n_samples[u] = ns;
+            if (!ns)
+                continue;
+            // 2 MB alignment + MADV_HUGEPAGE: where transparent huge pages are allowed, the first touch of
+            // the buffer (by the scatter threads) takes 512x fewer faults; free() releases it as usual
+            const size_t bytes = ns * elem;
+            if (bytes >= (4u << 20) && posix_memalign(&pcm[u], 2u << 20, bytes) == 0)
+                madvise(pcm[u], bytes, MADV_HUGEPAGE);
+            else
+                pcm[u] = malloc(bytes);
+            if (!pcm[u]) {
+                jb::set_error("out of host memory");
+                return JB_ERR_INVALID;
+            }
+        }
+        // whole slab through the pinned staging ring into the per-utterance buffers
+        rc = b->read_pcm_split(pcm + lo, elem);
+        batches[g].reset(); // device memory and streams back to the pools
+        t_d2h += ms(t0, now());
+        return rc;
+    };
+
+    int rc = JB_OK;
+    if (ngroups == 1) {
+        if (!(rc = front(0, n_utts)) && !(rc = launch(0)))
+            rc = finish(0);
     } else {
-        rc = jb::Batch::create(&CENG(e)->desc, utts.data(), n_utts, &opts, &b);
-    }
-    if (rc)
-        return rc;
-    std::unique_ptr<jb::Batch> guard(b);
-    const auto t_create = now();
-    if ((rc = b->run(false)) || (rc = b->sync()))
-        return rc;
-    const auto t_run = now();
-    for (size_t u = 0; u < n_utts; u++) {
-        size_t ns = (size_t)b->T[u] * b->voice.fperiod;
-        n_samples[u] = ns;
-        if (!ns)
-            continue;
-        // 2 MB alignment + MADV_HUGEPAGE: where transparent huge pages are allowed, the first touch of
-        // the buffer (by the scatter threads) takes 512x fewer faults; free() releases it as usual
-        const size_t bytes = ns * elem;
-        if (bytes >= (4u << 20) && posix_memalign(&pcm[u], 2u << 20, bytes) == 0)
-            madvise(pcm[u], bytes, MADV_HUGEPAGE);
-        else
-            pcm[u] = malloc(bytes);
-        if (!pcm[u]) {
-            jb::set_error("out of host memory");
-            rc = JB_ERR_INVALID;
-            break;
+        // finisher thread: groups in order, as soon as they are launched
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t launched = 0;
+        bool stop = false;
+        int frc = JB_OK;
+        std::string ferr;
+        std::thread finisher([&]() {
+            for (size_t g = 0; g < ngroups; g++) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return launched > g || stop; });
+                    if (launched <= g)
+                        return;
+                }
+                const int r = finish(g);
+                if (r) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    frc = r;
+                    ferr = jb::g_err;
+                    return;
+                }
+            }
+        });
+        for (size_t g = 0; g < ngroups && !rc; g++) {
+            if ((rc = front(glo[g], glo[g + 1])) || (rc = launch(g)))
+                break;
+            std::lock_guard<std::mutex> lk(mu);
+            launched = g + 1;
+            cv.notify_all();
+            if (frc)
+                break;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            cv.notify_all();
+        }
+        finisher.join();
+        if (!rc && frc) {
+            rc = frc;
+            jb::set_error(ferr);
         }
     }
-    // whole slab through the pinned staging ring into the per-utterance buffers
-    if (!rc)
-        rc = b->read_pcm_split(pcm, elem);
     if (rc) {
+        batches.clear();
         for (size_t u = 0; u < n_utts; u++) {
             free(pcm[u]);
             pcm[u] = nullptr;
@@ -924,8 +1017,10 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
         return rc;
     }
     if (timing)
-        fprintf(stderr, "jb_synthesize_batch: front half %.1f ms, upload+create %.1f ms, run %.1f ms, D2H %.1f ms\n",
-                ms(t_start, t_front), ms(t_front, t_create), ms(t_create, t_run), ms(t_run, now()));
+        fprintf(stderr,
+                "jb_synthesize_batch: %zu group(s), wall %.1f ms; front half %.1f ms, upload+create+enqueue %.1f ms, "
+                "wait for the GPU %.1f ms, D2H %.1f ms\n",
+                ngroups, ms(t_start, now()), t_front, t_create, t_wait, t_d2h);
     return JB_OK;
 }
 

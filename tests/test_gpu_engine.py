@@ -234,3 +234,25 @@ def test_generator_with_postfilter_equals_synthesize():
     got = np.concatenate(out + [g.generate_all()])
     assert len(got) == len(whole) == 100800
     assert rel_rms(got, whole) < 1e-12
+
+
+def test_synthesize_batch_in_groups_equals_one_batch(engine, monkeypatch):
+    """jb_synthesize_batch's grouped pipeline (front half of group g+1 and read-back of group g-1
+    beside the GPU work of group g): same lengths, same audio as the one-batch path, empty
+    utterances and group boundaries included."""
+    long = list(SAMPLE_SENTENCE_2) * 6
+    utts = [SAMPLE_SENTENCE_1, long, [], SAMPLE_SENTENCE_2, long, SAMPLE_SENTENCE_1, [], long, SAMPLE_SENTENCE_2]
+    monkeypatch.setenv("JB_SYNTH_GROUPS", "1")
+    one = engine.synthesize_batch(utts)
+    for g in ("2", "3", "9"):
+        monkeypatch.setenv("JB_SYNTH_GROUPS", g)
+        got = engine.synthesize_batch(utts)
+        assert [len(x) for x in got] == [len(x) for x in one]
+        for a, b in zip(got, one):
+            if len(a):
+                assert rel_rms(a, b) <= 1e-10
+    monkeypatch.setenv("JB_SYNTH_GROUPS", "3")
+    i16 = engine.synthesize_batch(utts, i16=True)
+    for a, b in zip(i16, one):
+        assert np.array_equal(a, np.clip(b, -32768.0, 32767.0).astype(np.int16)) or \
+            np.max(np.abs(a.astype(np.float64) - np.clip(b, -32768.0, 32767.0))) <= 1.0
