@@ -130,17 +130,29 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
         vd.counter_start[base + t] = counter;
         int i = 0;
         for (int q = 0; q < nblk; q++) {
-            unsigned long long mask = 0ull;
-            for (int j = 0; j < bs; j++, i++) {
-                // voiced branch of Excitation::get (excitation.rs:73-81)
+            // voiced branch of Excitation::get (excitation.rs:73-81); the pulse bits are gathered in two
+            // 32-bit halves (one select and one shift-or per sample instead of six 64-bit mask operations:
+            // this loop is the latency of the whole LF0 chain for mid-size batches)
+            uint32_t mlo = 0, mhi = 0;
+            const int b32 = bs < 32 ? bs : 32;
+#pragma unroll 4
+            for (int j = 0; j < b32; j++) {
                 counter += 1.0;
-                if (counter >= cur) {
-                    counter -= cur;
-                    mask |= 1ull << j;
-                }
+                const bool fire = counter >= cur;
+                counter = fire ? counter - cur : counter;
+                mlo |= (uint32_t)fire << j;
                 cur += inc;
             }
-            vd.pmask[(base + t) * nblk + q] = mask;
+#pragma unroll 4
+            for (int j = 32; j < bs; j++) {
+                counter += 1.0;
+                const bool fire = counter >= cur;
+                counter = fire ? counter - cur : counter;
+                mhi |= (uint32_t)fire << (j - 32);
+                cur += inc;
+            }
+            i += bs;
+            vd.pmask[(base + t) * nblk + q] = ((unsigned long long)mhi << 32) | mlo;
         }
         prevp = p; // Excitation::end
     }
