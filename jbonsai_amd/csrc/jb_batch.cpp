@@ -899,12 +899,12 @@ int Batch::build_work(const jb_batch_opts *opts)
             target = strtoull(e, nullptr, 10);
         uint64_t c = target ? (sumT + target - 1) / target : 0;
         // A batch that cannot fill the chip is a latency case: the launch takes as long as ONE item
-        // (warm-up + chunk frames), so the chunks shrink, down to 16 frames (one 1.4 s sentence: 24.7 ->
-        // 17.5 ms per call; below 16 the extra hand-off positions and their occasional redo round cost
-        // more than they save) -- but only until there are two items per CU: the wave kernel runs at
-        // 0.25 us per sample with up to two waves on a CU, 0.44 with four and 0.66 with eight (measured,
-        // 16 x 2000 frames), so more, shorter items than 512 make the launch longer again.
-        uint64_t floor_ = std::min<uint64_t>(std::max<uint64_t>((sumT + 511) / 512, 16), 4ull * warmup_frames);
+        // (warm-up + chunk frames at 0.25 us per sample), so the chunks shrink until every SIMD has an
+        // item, down to 16 frames (one 1.4 s sentence: 24.7 -> 17.5 ms per call; below 16 the extra
+        // hand-off positions and their occasional redo round cost more than they save).  More than one
+        // item per SIMD makes the launch longer again (0.47 us per sample with two); the kernel's
+        // four-wave workgroups are what puts exactly one on each.
+        uint64_t floor_ = std::min<uint64_t>(std::max<uint64_t>((sumT + 1023) / 1024, 16), 4ull * warmup_frames);
         if (const char *e = getenv("JB_CHUNK_FLOOR"))
             floor_ = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
         ch = (uint32_t)std::max<uint64_t>(c, floor_);

@@ -652,10 +652,17 @@ __device__ __constant__ double kPPade[6] = {1.00000000000, 0.49993910000, 0.1107
 // filter state layout (doubles): d[TPL][64] | ulane[64] | e11[6] | e12[6] | pad[4]
 __host__ __device__ inline int voc_state_doubles(int tpl) { return 64 * tpl + 64 + 16; }
 
+// Workgroups of four waves, one work item per wave: a workgroup's waves are spread over the four
+// SIMDs of its CU, which one-wave workgroups are not (1008 one-wave workgroups ran at 0.44 us per
+// sample against 0.25 for 512: the dispatcher had doubled them up on SIMDs).
 template <int TPL>
-__global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const VocWork *__restrict__ work)
+__global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const VocWork *__restrict__ work,
+                                                 uint32_t n_items)
 {
-    const VocWork wk = work[blockIdx.x];
+    const uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (item >= n_items)
+        return;
+    const VocWork wk = work[item];
     const int b = (int)wk.utt;
     const uint32_t T = bd.utt[b].T;
     const uint32_t t_begin = wk.t_start, t_out = wk.t_out;
@@ -664,7 +671,7 @@ __global__ __launch_bounds__(64) void k_vocoder(BatchDev bd, VocDev vd, const Vo
         t_end = T;
     if (t_begin >= t_end)
         return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint64_t base = bd.utt[b].frame_off;
     const int nmcp = vd.nmcp, fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
     const int M = nmcp - 1; // live taps 1..M
@@ -1684,22 +1691,22 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
 {
     if (n_items == 0)
         return hipSuccess;
-    dim3 grid(n_items), block(64);
+    dim3 grid((n_items + 3) / 4), block(256);
     switch (tpl_for(vd.nmcp)) {
     case 1:
-        hipLaunchKernelGGL(k_vocoder<1>, grid, block, 0, stream, bd, vd, work_dev);
+        hipLaunchKernelGGL(k_vocoder<1>, grid, block, 0, stream, bd, vd, work_dev, n_items);
         break;
     case 2:
-        hipLaunchKernelGGL(k_vocoder<2>, grid, block, 0, stream, bd, vd, work_dev);
+        hipLaunchKernelGGL(k_vocoder<2>, grid, block, 0, stream, bd, vd, work_dev, n_items);
         break;
     case 3:
-        hipLaunchKernelGGL(k_vocoder<3>, grid, block, 0, stream, bd, vd, work_dev);
+        hipLaunchKernelGGL(k_vocoder<3>, grid, block, 0, stream, bd, vd, work_dev, n_items);
         break;
     case 4:
-        hipLaunchKernelGGL(k_vocoder<4>, grid, block, 0, stream, bd, vd, work_dev);
+        hipLaunchKernelGGL(k_vocoder<4>, grid, block, 0, stream, bd, vd, work_dev, n_items);
         break;
     case 5:
-        hipLaunchKernelGGL(k_vocoder<5>, grid, block, 0, stream, bd, vd, work_dev);
+        hipLaunchKernelGGL(k_vocoder<5>, grid, block, 0, stream, bd, vd, work_dev, n_items);
         break;
     default:
         return hipErrorInvalidValue;
