@@ -893,21 +893,19 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = (uint32_t)std::max<uint64_t>(c, cmin);
         ch = (ch + 3) / 4 * 4;
     } else if (ch == 0) {
-        // auto: enough items to fill 1024 SIMDs several waves deep, chunks >= 4x the warm-up
-        uint64_t target = 24576;
+        // auto (wave kernel): one item per SIMD, two once the batch is large.  The launch takes as long
+        // as ONE item (warm-up + chunk frames at 0.25 us per sample; 0.47 with two items on a SIMD), so a
+        // small batch wants short chunks -- down to 16 frames (one 1.4 s sentence: 24.7 -> 17.5 ms per
+        // call; below 16 the extra hand-off positions and their occasional redo round cost more than
+        // they save) -- but never more items than SIMDs: the kernel's four-wave workgroups are what puts
+        // exactly one on each.  (64 x 2000 frames: 16.0 ms with 1344 items of 96 frames, 11.6 with 1000 of 128.)
+        uint64_t target = sumT >= 400000 ? 2048 : 1024;
         if (const char *e = getenv("JB_CHUNK_TARGET"))
-            target = strtoull(e, nullptr, 10);
-        uint64_t c = target ? (sumT + target - 1) / target : 0;
-        // A batch that cannot fill the chip is a latency case: the launch takes as long as ONE item
-        // (warm-up + chunk frames at 0.25 us per sample), so the chunks shrink until every SIMD has an
-        // item, down to 16 frames (one 1.4 s sentence: 24.7 -> 17.5 ms per call; below 16 the extra
-        // hand-off positions and their occasional redo round cost more than they save).  More than one
-        // item per SIMD makes the launch longer again (0.47 us per sample with two); the kernel's
-        // four-wave workgroups are what puts exactly one on each.
-        uint64_t floor_ = std::min<uint64_t>(std::max<uint64_t>((sumT + 1023) / 1024, 16), 4ull * warmup_frames);
+            target = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+        uint64_t floor_ = 16;
         if (const char *e = getenv("JB_CHUNK_FLOOR"))
             floor_ = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
-        ch = (uint32_t)std::max<uint64_t>(c, floor_);
+        ch = (uint32_t)std::max<uint64_t>((sumT + target - 1) / target, floor_);
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
