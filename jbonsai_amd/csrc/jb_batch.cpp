@@ -868,9 +868,9 @@ int Batch::build_work(const jb_batch_opts *opts)
     uint32_t ch = opts ? opts->chunk_frames : 0;
     // lane-pair throughput kernel: worth it once the batch holds enough frames to give
     // every SIMD 32 chunks that are long against the warm-up
-    // (measured crossover against the wave kernel: between 4 and 8 utterances of 25.5 k frames,
-    // tools/ab_lpmin.sh)
-    uint64_t lp_min = 150000;
+    // (measured crossover against the wave kernel at one item per SIMD: between 6 and 8 utterances of
+    // 25.5 k frames -- 22.4 vs 26.7 ms at 6, 28.5 vs 26.9 at 8; tools/ab_lpmin.sh)
+    uint64_t lp_min = 190000;
     if (const char *e = getenv("JB_LP_MIN_FRAMES"))
         lp_min = strtoull(e, nullptr, 10);
     lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vocoder_ls_supported(vd.nmcp) &&

@@ -371,16 +371,20 @@ def test_many_tiny_utterances(ctx):
 
 
 def test_one_very_long_utterance(ctx):
-    """A single 160,000-frame (13 min) utterance: 79 GV tiles per row, 10,000 states in the state
-    walk, the throughput kernel fed by one utterance only.  HIP vs oracle."""
+    """A single 200,000-frame (17 min) utterance: 98 GV tiles per row, 12,000 states in the state
+    walk, the throughput kernel (batches of >= 190 k frames) fed by one utterance only; the same
+    utterance through the wave kernel at one item per SIMD.  HIP vs oracle."""
     eng, tab, vi = ctx
-    u = synth.synth_utterance(tab, 160000, 77)
+    u = synth.synth_utterance(tab, 200000, 77)
     got, info = run(vi, [u])
-    assert len(got[0]) == 160000 * 240 and info["n_items"] > 1000
+    assert len(got[0]) == 200000 * 240 and info["n_items"] > 1024
     ref, _ = oracle_pcm(vi, u)
     e = rel_rms(got[0], ref)
-    print("160 k frames: rel RMS vs oracle", e, info)
+    print("200 k frames: rel RMS vs oracle", e, info)
     assert e <= 1e-9
+    gotw, infow = run(vi, [u], kernel="wave")
+    assert 512 < infow["n_items"] <= 2048
+    assert rel_rms(gotw[0], ref) <= 1e-9
 
 
 def test_device_pool_reuse_release_and_dirty_blocks(oracle_voice):
