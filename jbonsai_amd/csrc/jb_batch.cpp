@@ -892,6 +892,17 @@ int Batch::build_work(const jb_batch_opts *opts)
             cmin = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
         ch = (uint32_t)std::max<uint64_t>(c, cmin);
         ch = (ch + 3) / 4 * 4;
+        // every utterance rounds its chunk count up: with ragged lengths the items can exceed the two
+        // waves per SIMD the target stands for, and the waves over the limit run as a tail after the
+        // others -- lengthen the chunks until the items fit
+        auto items_at = [&](uint32_t cf) {
+            uint64_t it = 0;
+            for (int i = 0; i < B; i++)
+                it += (T[(size_t)i] + cf - 1) / cf;
+            return it;
+        };
+        for (int guard = 0; guard < 64 && c >= cmin && items_at(ch) > target; guard++)
+            ch += 4;
     } else if (ch == 0) {
         // auto (wave kernel): one item per SIMD, two once the batch is large.  The launch takes as long
         // as ONE item (warm-up + chunk frames at 0.25 us per sample; 0.47 with two items on a SIMD), so a
