@@ -883,11 +883,15 @@ int Batch::build_work(const jb_batch_opts *opts)
         if (const char *e = getenv("JB_LP_TARGET"))
             target = strtoull(e, nullptr, 10);
         uint64_t c = (sumT + target - 1) / target;
-        // while the batch cannot fill the chip the time of the launch is that of ONE chunk
-        // (chunk + warm-up frames), but shorter chunks also mean more hand-off positions and more
-        // of them failing the check: below 2x the warm-up the redo rounds cost what the shorter
-        // chunks save (tools/ab_chmin.sh)
-        uint64_t cmin = 2ull * warmup_frames;
+        // while the batch cannot fill the chip the time of the launch is that of ONE chunk (chunk +
+        // warm-up frames): chunks down to 16 frames.  Shorter chunks mean more hand-off positions and
+        // more of them failing the check, but a failed 16-frame chunk is also redone in a third of the
+        // time of a 48-frame one; with DISTINCT utterances (bench.py --distinct 32) 16 beats the earlier
+        // floor of twice the warm-up on every shape tried -- 32 x 25,546 frames 59.0 -> 43.0 ms per
+        // step, 64 x 4,600 32.7 -> 23.0, 256 x 2,000 33.4 -> 23.5, 1024 x 500 22.8 -> 21.0 -- and 12 or
+        // 8 gain nothing more.  (The earlier floor had been tuned on copies of one utterance, whose
+        // hand-offs all pass.)
+        uint64_t cmin = 16;
         if (const char *e = getenv("JB_CHUNK_MIN"))
             cmin = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
         ch = (uint32_t)std::max<uint64_t>(c, cmin);
