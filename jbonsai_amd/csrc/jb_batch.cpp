@@ -924,6 +924,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
+    vd.ckpt_frames = ch >= 2 * kVocCkptFrames ? kVocCkptFrames : (ch >= kVocCkptFramesShort + 16 ? kVocCkptFramesShort : 0);
     work.clear();
     const int stride = vd.state_stride;
     for (int i = 0; i < B; i++) {
@@ -969,8 +970,9 @@ int Batch::build_work(const jb_batch_opts *opts)
             w.save_end = end_state + (size_t)k * stride;
             w.save_warm = first ? nullptr : warm_state + (size_t)k * stride;
             // checkpoint for the partial redo: only where it saves at least half the chunk
-            w.save_ckpt = (!first && w.t_end - w.t_out >= 2 * kVocCkptFrames) ? ckpt_state + (size_t)k * stride
-                                                                              : nullptr;
+            const uint32_t need = vd.ckpt_frames == kVocCkptFrames ? 2 * kVocCkptFrames : vd.ckpt_frames + 16;
+            w.save_ckpt = (!first && vd.ckpt_frames && w.t_end - w.t_out >= need) ? ckpt_state + (size_t)k * stride
+                                                                                   : nullptr;
         }
     }
     if (n_items)
@@ -1144,7 +1146,7 @@ int Batch::finish_verify()
         return hip_fail(e, "hipMemcpy(bad)");
     // rounds: every failing chunk whose predecessor is final (not itself pending) is
     // recomputed in the same launch; runs of consecutive failures take one round each.
-    // A chunk with a checkpoint is first recomputed only up to it (kVocCkptFrames frames): if the
+    // A chunk with a checkpoint is first recomputed only up to it (vd.ckpt_frames frames): if the
     // recomputed state meets the checkpoint the original chunk left there, the rest of that chunk
     // was computed from a trajectory that had already converged and stands; otherwise the
     // recomputation continues from there to the end of the chunk.
@@ -1188,7 +1190,7 @@ int Batch::finish_verify()
             w.load_state = work[k - 1].save_end;
             w.save_warm = nullptr;
             if (w.save_ckpt) {
-                w.t_end = w.t_out + kVocCkptFrames;
+                w.t_end = w.t_out + vd.ckpt_frames;
                 w.save_end = tmp_state + (size_t)k * stride;
                 part.push_back((uint32_t)j);
             } else {
@@ -1227,7 +1229,7 @@ int Batch::finish_verify()
                 }
                 n_redo_full++;
                 VocWork w = work[k];
-                w.t_start = w.t_out = work[k].t_out + kVocCkptFrames;
+                w.t_start = w.t_out = work[k].t_out + vd.ckpt_frames;
                 w.load_state = tmp_state + (size_t)k * stride;
                 w.save_warm = nullptr;
                 w.save_ckpt = nullptr;

@@ -114,6 +114,7 @@ struct VocDev {
     double *exc;          // optional [sumT*fperiod] excitation before gain, or nullptr
     double *state;        // optional per-utterance filter state (streaming), or nullptr
     int state_stride;     // doubles per utterance
+    uint32_t ckpt_frames; // checkpoint position inside a chunk (frames past t_out); 0 = no checkpoints
 };
 
 // One unit of vocoder work: output frames [t_out, t_end) of utterance `utt`, with the
@@ -124,11 +125,12 @@ struct VocWork {
     const double *load_state; // exact continuation (streaming / re-do), or nullptr
     double *save_warm;        // state on entering t_out (after warm-up), or nullptr
     double *save_end;         // state after t_end, or nullptr
-    double *save_ckpt;        // state on entering frame t_out + kVocCkptFrames, or nullptr (partial redo)
+    double *save_ckpt;        // state on entering frame t_out + VocDev::ckpt_frames, or nullptr (partial redo)
 };
-// A failing chunk is first recomputed only up to this many frames past its start; if the recomputed
-// state meets the checkpoint the original chunk left there, the rest of the chunk stands.
-constexpr uint32_t kVocCkptFrames = 48;
+// A failing chunk is first recomputed only up to VocDev::ckpt_frames frames past its start; if the
+// recomputed state meets the checkpoint the original chunk left there, the rest of the chunk stands.
+// 48 frames for chunks of 96 frames and more, 24 for chunks of 40 to 95, none below.
+constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24;
 
 struct BatchDev {
     int B;

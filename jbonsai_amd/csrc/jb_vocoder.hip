@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
         const bool emit = t >= t_out; // warm-up frames are computed but not stored
         if (t == t_out && t_out > t_begin && wk.save_warm)
             save_state(wk.save_warm);
-        if (t == t_out + kVocCkptFrames && wk.save_ckpt)
+        if (t == t_out + vd.ckpt_frames && wk.save_ckpt)
             save_state(wk.save_ckpt);
         // ---- frame setup (vocoder/mod.rs:116-125) ----
         // c at frame start = previous frame's cc exactly (mod.rs:140); first frame: c = cc.
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
             if (sw_)
                 save_state(sw_);
         }
-        if (act && t == wk.t_out + kVocCkptFrames) {
+        if (act && t == wk.t_out + vd.ckpt_frames) {
             double *sc_ = work[item].save_ckpt;
             if (sc_)
                 save_state(sc_);
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             if (sw_)
                 save_state(sw_);
         }
-        if (act && t == wk.t_out + kVocCkptFrames) {
+        if (act && t == wk.t_out + vd.ckpt_frames) {
             double *sc_ = work[item].save_ckpt;
             if (sc_)
                 save_state(sc_);
