@@ -334,14 +334,19 @@ constexpr int kExwQ = (256 + kExwHalo) / kExw; // LDS row pitch (q = (m + halo) 
 // load + branch and the wave pays one scalar-cache latency per tap (measured 14 ms); known at
 // compile time, the taps arrive in a few wide scalar loads.
 template <int NLPF, bool NOISE_ONLY>
-__global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd)
+__global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int utt_fastest)
 {
     static_assert(NLPF - 1 <= kExwHalo - 2, "history window too short");
     constexpr int kExwWin = NLPF - 1 + kExw; // window e[4j-(NLPF-1) .. 4j+3]
-    const int b = blockIdx.y;
+    // utt_fastest: consecutive workgroups are the SAME four frames of consecutive utterances.  The noise
+    // is one table for all utterances (excitation.rs:177-237, seed fixed), indexed by the sample's
+    // position in its utterance: in this order the workgroups in flight read the same few KB of it (L2
+    // hits) instead of each utterance streaming the whole table from the Infinity Cache again.
+    const int b = utt_fastest ? blockIdx.x : blockIdx.y;
+    const uint32_t bx = utt_fastest ? blockIdx.y : blockIdx.x;
     const UttDev *u = bd.utt + b;
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)wv));
+    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx * 4u + (uint32_t)wv));
     // wave-private LDS images: no block barrier is needed (and a wave past the end of the
     // utterance may leave early), only wave-level ordering of the LDS writes and reads
     if (fr >= u->T)
@@ -1579,10 +1584,14 @@ hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t
     if (bd.B == 0 || bd.maxT == 0 || !excite_is_split(vd))
         return hipSuccess;
     dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
+    static const bool no_swap = getenv("JB_EXCITE_UTT_FASTEST") && atoi(getenv("JB_EXCITE_UTT_FASTEST")) == 0;
+    const int swap = !no_swap && grid.x <= 65535u; // grid.y limit
+    if (swap)
+        grid = dim3(bd.B, (bd.maxT + 3) / 4);
     if (vd.nlpf == 31)
-        hipLaunchKernelGGL((k_excite_w4<31, true>), grid, block, 0, stream, bd, vd);
+        hipLaunchKernelGGL((k_excite_w4<31, true>), grid, block, 0, stream, bd, vd, swap);
     else
-        hipLaunchKernelGGL((k_excite_w4<15, true>), grid, block, 0, stream, bd, vd);
+        hipLaunchKernelGGL((k_excite_w4<15, true>), grid, block, 0, stream, bd, vd, swap);
     return hipGetLastError();
 }
 
@@ -1599,9 +1608,9 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
             else
                 hipLaunchKernelGGL(k_excite_fix<15>, gfix, block, 0, stream, bd, vd);
         } else if (vd.nlpf == 31)
-            hipLaunchKernelGGL((k_excite_w4<31, false>), grid, block, 0, stream, bd, vd);
+            hipLaunchKernelGGL((k_excite_w4<31, false>), grid, block, 0, stream, bd, vd, 0);
         else
-            hipLaunchKernelGGL((k_excite_w4<15, false>), grid, block, 0, stream, bd, vd);
+            hipLaunchKernelGGL((k_excite_w4<15, false>), grid, block, 0, stream, bd, vd, 0);
         return hipGetLastError();
     }
     const uint64_t maxN = (uint64_t)bd.maxT * (uint64_t)vd.fperiod;
