@@ -313,7 +313,10 @@ __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 // kBuildTF contiguous frames per dim.  What depends on the frame alone (state index, MSD
 // boundary distances of the frame and its +-1 neighbours) is looked up once per block.
 // Same arithmetic, in the same order, as build_elem.
-constexpr int kBuildTF = 32;
+#ifndef JB_BUILD_TF
+#define JB_BUILD_TF 32
+#endif
+constexpr int kBuildTF = JB_BUILD_TF;
 constexpr int kMtMaxDim = 60; // (BW+1) * L * (kBuildTF+1) * 8 B <= 64 KiB of LDS for BW = 3
 template <int BW>
 __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd, int si)
