@@ -844,16 +844,16 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
     }
     const bool indexed = pset != nullptr;
 
-    // A request can go through in groups, three stages overlapped: while the GPU works on group g the
-    // host threads run the front half of group g+1 and a finisher thread brings the PCM of group g-1
-    // back.  Measured for 64 x 157 s (front half / GPU / link = 54 / 46 / 86 ms one after the other):
-    // with f64 PCM the read-back, the longest stage, slows down by more than the overlap gains when
-    // kernels and host threads run beside it (203 -> 242 ms with two groups, 299 ms with four), so f64
-    // requests stay one batch; with the 16-bit sink two groups win (134 -> 113 ms), four do not.
+    // A large request goes through in two groups: while the GPU works on the first, the host threads
+    // run the front half of the second.  With the 16-bit sink the read-back of the first group also
+    // runs beside the GPU work of the second (134 -> 113 ms for 64 x 157 s); with f64 PCM a read-back
+    // beside running kernels slows down by more than the overlap gains (203 -> 242 ms), so there all
+    // GPU work comes first and the read-backs after it (203-224 -> 183 ms).  More groups lose (three:
+    // 220 ms): smaller batches fill the chip less well and their blocks miss the pool.
     // Groups split the utterances by label count; JB_SYNTH_GROUPS overrides.
     size_t ngroups = 1;
     const size_t total_lines = n_utts ? line_off[n_utts] - line_off[0] : 0;
-    if (elem == 2 && n_utts >= 8 && total_lines >= 16000)
+    if (n_utts >= 8 && total_lines >= 16000)
         ngroups = 2;
     if (const char *ev = getenv("JB_SYNTH_GROUPS"))
         ngroups = (size_t)std::max(1, atoi(ev));
@@ -925,15 +925,17 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
         t_create += ms(t0, now());
         return rc;
     };
-    auto finish = [&](size_t g) -> int {
+    auto finish_sync = [&](size_t g) -> int {
+        const auto t0 = now();
+        const int rc = batches[g]->sync();
+        t_wait += ms(t0, now());
+        return rc;
+    };
+    auto finish_read = [&](size_t g) -> int {
         const size_t lo = glo[g], hi = glo[g + 1];
         jb::Batch *b = batches[g].get();
-        auto t0 = now();
-        int rc = b->sync();
-        t_wait += ms(t0, now());
-        if (rc)
-            return rc;
-        t0 = now();
+        int rc = JB_OK;
+        const auto t0 = now();
         for (size_t u = lo; u < hi; u++) {
             const size_t ns = (size_t)b->T[u - lo] * b->voice.fperiod;
             n_samples[u] = ns;
@@ -957,6 +959,13 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
         t_d2h += ms(t0, now());
         return rc;
     };
+    auto finish = [&](size_t g) -> int {
+        const int rc = finish_sync(g);
+        return rc ? rc : finish_read(g);
+    };
+    // f64 in groups (JB_SYNTH_GROUPS only): all groups' GPU work first, then the read-backs, so that no
+    // read-back runs beside kernels
+    const bool d2h_last = elem == 8;
 
     int rc = JB_OK;
     if (ngroups == 1) {
@@ -978,7 +987,16 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
                     if (launched <= g)
                         return;
                 }
-                const int r = finish(g);
+                const int r = d2h_last ? finish_sync(g) : finish(g);
+                if (r) {
+                    std::lock_guard<std::mutex> lk(mu);
+                    frc = r;
+                    ferr = jb::g_err;
+                    return;
+                }
+            }
+            for (size_t g = 0; d2h_last && g < ngroups; g++) {
+                const int r = finish_read(g);
                 if (r) {
                     std::lock_guard<std::mutex> lk(mu);
                     frc = r;
