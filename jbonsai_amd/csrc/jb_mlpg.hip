@@ -1146,7 +1146,7 @@ constexpr int kFlMovers = kFlNT - 64;
 // the divisions were 45 % of it (13 instructions each).  Bit-identical to `a / d` wherever the
 // scaling steps are the identity, i.e. for finite non-zero d and quotients away from the ends of the
 // exponent range -- D_t is a sum of inverse variances (|ivar| <= 1e38, mean_vari.rs:21-31); the
-// tracks' hashes are unchanged (tools/ab_bits.py) and the oracle comparisons stay bitwise.
+// tracks' hashes are unchanged (tests/tools/ab_bits.py) and the oracle comparisons stay bitwise.
 __device__ __forceinline__ double fb_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);

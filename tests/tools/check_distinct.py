@@ -1,9 +1,9 @@
 """Parity spot check at scale: B distinct 128 s utterances through the default path, a few of them
-against the oracle (each ~1.3 s of CPU).  Usage: python tools/check_distinct.py [B]"""
+against the oracle (each ~1.3 s of CPU).  Usage: python tests/tools/check_distinct.py [B]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np  # noqa: E402
 
 import jbonsai_amd as J  # noqa: E402

@@ -5,6 +5,6 @@ cd "$(dirname "$0")/.."
 for def in "" "-DJB_ABL_NO_PHASE_A" "-DJB_ABL_NO_PHASE_B"; do
   (cd jbonsai_amd/csrc && rm -f build/jb_vocoder.o && HIPCC="/opt/rocm/bin/hipcc $def" ./build.sh >/dev/null)
   echo "== build [$def]"
-  python tools/probe_time.py 2000 256 2>/dev/null | grep "B=256" | tail -1
+  python tests/tools/probe_time.py 2000 256 2>/dev/null | grep "B=256" | tail -1
 done
 (cd jbonsai_amd/csrc && rm -f build/jb_vocoder.o && ./build.sh >/dev/null)
