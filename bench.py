@@ -4,20 +4,31 @@ path on MI355X (BASELINE.json metric), one process per GPU.
 
 A "step" = one pass of the whole hot path (MLPG+GV x3 -> frame prologue -> pulse
 schedule -> excitation + MLSA cascade) over one batch of synthetic utterances
-whose state-level inputs are already resident in HBM.  N=1 workload = BASELINE
-config 2: batch of 256 copies of the ~128 s utterance (T = 25,546 frames,
-6,131,040 samples each) built from real nitech pdfs (jbonsai_amd/synth.py).
-N>1: every rank runs the same per-GPU workload (weak scaling, no data-path
-collective: utterances are independent); RCCL is used only for the barrier and
-the max-over-ranks of the timed region.
+whose state-level inputs are already resident in HBM.
 
-Prints ONE JSON line on rank 0.
+Workloads (--job):
+  config2 (default, the headline): BASELINE config 2 per GPU -- a batch of 256 copies of the
+      ~128 s utterance (T = 25,546 frames, 6,131,040 samples each) built from real nitech pdfs
+      (jbonsai_amd/synth.py).  N > 1: every rank runs the per-GPU workload (weak scaling).
+  config3: BASELINE config 3 as ONE job -- the seed-fixed list of 4096 mixed-length utterances
+      (synth.mixed_lengths) is built once, LPT-partitioned over the N ranks (jbonsai_amd/shard.py)
+      and every rank synthesises its share in sub-batches that fit HBM (strong scaling: total work
+      fixed).  At N > 1 a short config-3 pass is also appended to the default run and reported
+      under "config3_strong" (outside `value`).
+Utterances are independent, so there is no data-path collective; RCCL carries the barrier, the
+max-over-ranks of the timed region and -- with --gather -- the PCM gather onto rank 0.
+
+Launch: `python bench.py --gpus N` spawns its N ranks itself (fresh child processes, started
+before this process touches HIP or torch.cuda); under torch.distributed.run (WORLD_SIZE set) the
+process is one rank.  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -34,8 +45,91 @@ FLOP_PER_SAMPLE = 1.39e3      # algorithmic f64 flops per output sample (SURVEY.
 FP64_VALU_PEAK_TFLOPS = 78.6
 DEFAULT_CU_SPLIT = 0  # CU partition off: measured slower at every split
 VOICE = ROOT / "tests" / "golden" / "voice" / "nitech_jp_atr503_m001.htsvoice"
+CONFIG3_UTTS = 4096           # BASELINE config 3: "Batch=4096 mixed-length synthetic ... sequences"
+SUB_BATCH_FRAMES = 7_000_000  # frames per sub-batch of the config-3 job (config 2 is 6.54 M: ~62 GB of HBM)
 
 
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--job", choices=("config2", "config3"), default="config2",
+                    help="config2: the headline (per-GPU batch of copies, weak scaling); config3: the 4096 "
+                         "mixed-length utterances as one LPT-sharded job (strong scaling)")
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU (config2 job)")
+    ap.add_argument("--frames", type=int, default=0, help="frames per utterance (0 = 25,546 = ~128 s)")
+    ap.add_argument("--utts", type=int, default=CONFIG3_UTTS, help="utterances of the config3 job (whole job)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements appended to the default line (distinct utterances, "
+                         "D2H-inclusive, labels -> PCM, config3_strong at N > 1); none of them enters `value`")
+    ap.add_argument("--cu-split", type=int, default=-1,
+                    help="CUs per XCD (of 32) given to parameter generation when two batches are in "
+                         "flight; the vocoder gets the rest (jb_batch_opts.mlpg_cus_per_xcd); "
+                         "-1 = default (0 with --pipeline 1)")
+    ap.add_argument("--distinct", type=int, default=1,
+                    help="number of DISTINCT synthetic utterances tiled over the batch (default 1 = BASELINE "
+                         "config 2's copies of one utterance); >1 shows the cost of real hand-off failures")
+    ap.add_argument("--mixed", action="store_true",
+                    help="config2 job on BASELINE config 3's per-GPU share instead: --batch distinct utterances "
+                         "of seed-fixed lengths U[400, 25546] frames, resident before the timed region")
+    ap.add_argument("--gather", action="store_true",
+                    help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
+                         "(point-to-point over xGMI) and report its time as gather_ms; "
+                         "never part of `value` (SURVEY 8e)")
+    ap.add_argument("--beta", type=float, default=0.0,
+                    help="post-filter coefficient (off-config: BASELINE's metric is quoted at beta = 0)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
+                         "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
+    return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------
+# launcher: `bench.py --gpus N` without a torchrun environment spawns its own ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n: int) -> int:
+    """N fresh child processes, one per GPU, started BEFORE this process makes any HIP / torch.cuda
+    call (it never does).  Rank 0 prints the JSON line on the inherited stdout."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                r = p.poll()
+                if r is None:
+                    continue
+                pending.remove(p)
+                if r != 0 and rc == 0:
+                    rc = r
+                    # a failed rank leaves the others waiting at a collective: end exactly the
+                    # children this launcher started
+                    for q in pending:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
 def cpu_baseline(utt, vi, n_utts_per_thread=2):
     """The oracle (C restatement of jbonsai's CPU path, kind="port") on the host cores
     of this box, on a bounded sample of the same workload."""
@@ -78,8 +172,8 @@ def cpu_baseline(utt, vi, n_utts_per_thread=2):
 def pcm_slab_tensor(batch):
     """The batch's PCM slab (jb_batch_device_pcm) as a zero-copy torch tensor on its device (f64,
     or i16 for a pcm_i16 batch), for an RCCL gather by the caller.  The tensor aliases
-    library-owned memory: valid until the batch is closed, contents valid after sync().  Lives
-    here, not in the package: the product does not import torch."""
+    library-owned memory: valid until the batch is closed.  Lives here, not in the package: the
+    product does not import torch."""
     import torch
 
     p, n = batch.device_pcm()
@@ -93,100 +187,162 @@ def pcm_slab_tensor(batch):
     return torch.as_tensor(_Slab(), device=torch.device("cuda", dev))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
-    ap.add_argument("--frames", type=int, default=0, help="frames per utterance (0 = 25,546 = ~128 s)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cu-split", type=int, default=-1,
-                    help="CUs per XCD (of 32) given to parameter generation when two batches are in "
-                         "flight; the vocoder gets the rest (jb_batch_opts.mlpg_cus_per_xcd); "
-                         "-1 = default (0 with --pipeline 1)")
-    ap.add_argument("--distinct", type=int, default=1,
-                    help="number of DISTINCT synthetic utterances tiled over the batch (default 1 = BASELINE "
-                         "config 2's copies of one utterance); >1 shows the cost of real hand-off failures")
-    ap.add_argument("--mixed", action="store_true",
-                    help="BASELINE config 3's per-GPU share instead of config 2: --batch distinct utterances "
-                         "of seed-fixed lengths U[400, 25546] frames (synth.mixed_lengths); not the headline line")
-    ap.add_argument("--gather", action="store_true",
-                    help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
-                         "(torch.distributed gather over xGMI) and report its time as gather_ms; "
-                         "never part of `value` (SURVEY 8e)")
-    ap.add_argument("--beta", type=float, default=0.0,
-                    help="post-filter coefficient (off-config: BASELINE's metric is quoted at beta = 0)")
-    ap.add_argument("--pipeline", type=int, default=1,
-                    help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
-                         "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
-    args = ap.parse_args()
+class Ranks:
+    """Rendezvous of the N ranks (torch.distributed; backend nccl = RCCL, or gloo on host tensors in
+    the one-GPU rehearsal mode JB_BENCH_REHEARSE=1 where every rank uses device 0)."""
 
-    import torch  # first: so that this process uses ONE HIP runtime (same SONAME as ours)
+    def __init__(self):
+        import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
+        self.torch = torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # JB_BENCH_DRYRUN=1 (CPU test of the launcher and the rank plumbing, tests/test_shard_dist.py):
+        # rendezvous over gloo, the config-3 plan is built, no batch is created and nothing is measured
+        self.dry = os.environ.get("JB_BENCH_DRYRUN", "0") != "0"
+        self.rehearse = self.dry or os.environ.get("JB_BENCH_REHEARSE", "0") != "0"
+        self.dist = None
+        if self.rehearse:
+            self.local_rank = 0
+        if self.world > 1:
+            import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # JB_BENCH_REHEARSE=1: rehearsal of the multi-rank path on a ONE-GPU box -- every rank uses
-    # device 0 and the collectives run over gloo on host tensors (RCCL refuses two ranks on one
-    # device).  Numbers from such a run mean nothing; it only exercises the code path.
-    rehearse = os.environ.get("JB_BENCH_REHEARSE", "0") != "0"
-    if rehearse:
-        local_rank = 0
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        if rehearse:
-            dist.init_process_group(backend="gloo")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.dist = dist
+            if not self.dry:
+                torch.cuda.set_device(self.local_rank)
+            if self.rehearse:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank))
+        if not self.dry:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+            torch.cuda.set_device(self.local_rank)
+        self.tdev = "cpu" if self.rehearse else "cuda"
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        if not self.dry:
+            self.torch.cuda.synchronize()
+
+    def max(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.tdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather_floats(self, xs):
+        """[world][len(xs)] of every rank's list."""
+        if self.dist is None:
+            return [list(xs)]
+        t = self.torch.tensor(list(xs), dtype=self.torch.float64, device=self.tdev)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [[float(v) for v in o.tolist()] for o in out]
+
+    def gather_slabs(self, slab):
+        """Every rank's PCM slab onto rank 0 (north_star's optional sink).  The slabs differ in length
+        (config 3 shares), so this is point-to-point: rank 0 posts one receive per peer, every peer
+        one send -- over xGMI each peer uses its own link into rank 0.  Returns the time in ms."""
+        if self.dist is None:
+            return None
+        torch, dist = self.torch, self.dist
+        if self.rehearse:
+            slab = slab.cpu()
+        n = torch.tensor([slab.numel()], dtype=torch.int64, device=self.tdev)
+        sizes = [torch.empty_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        bufs = None
+        if self.rank == 0:
+            bufs = [torch.empty(int(s.item()), dtype=slab.dtype, device=slab.device) for s in sizes[1:]]
+        self.barrier()
+        t0 = time.perf_counter()
+        if self.rank == 0:
+            ops = [dist.P2POp(dist.irecv, b, r + 1) for r, b in enumerate(bufs) if b.numel()]
         else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
+            ops = [dist.P2POp(dist.isend, slab, 0)] if slab.numel() else []
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        self.barrier()
+        ms = (time.perf_counter() - t0) * 1e3
+        del bufs
+        return ms
 
-    import jbonsai_amd as J
-    from jbonsai_amd import synth
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
 
-    eng = J.Engine.load([VOICE])
-    tab = synth.VoiceTables(eng)
-    vi = eng.voice_info()
-    vi.beta = args.beta
-    frames = args.frames or synth.T_128S
-    # every utterance of the batch is the same sequence (BASELINE config 2: "256 copies"),
-    # uploaded once and aliased; outputs / workspace / filter state are per utterance
-    utt = synth.synth_utterance(tab, frames, 0)
-    nd = max(1, min(args.distinct, args.batch))
-    utts = [utt] + [synth.synth_utterance(tab, frames, 1000 + i) for i in range(1, nd)]
-    depth = max(1, args.pipeline)
-    cu_split = args.cu_split if args.cu_split >= 0 else (DEFAULT_CU_SPLIT if depth > 1 else 0)
-    if args.mixed:
-        lens = synth.mixed_lengths(args.batch, seed=3 + rank)
-        batch_utts = [synth.synth_utterance(tab, T, 2000 + i) for i, T in enumerate(lens)]
-    else:
-        batch_utts = [utts[i % nd] for i in range(args.batch)]
-    batches = [J.Batch(vi, batch_utts, device=local_rank, mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
-    batch = batches[0]
-    samples_per_step = batch.total_samples
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+def roofline_block(samples_per_launch, voc_ms, info, traffic):
+    """The dominant kernel against the bound that binds it (FP64 VALU issue), with the HBM view the
+    metric is defined on as the secondary record."""
+    tflops = FLOP_PER_SAMPLE * samples_per_launch / (voc_ms * 1e-3) / 1e12
+    gbs = B_ALG * samples_per_launch / (voc_ms * 1e-3) / 1e9
+    sq = None
+    for name in ("r02_pmc_sq_k_vocoder_lt.txt", "r01_v9_pmc_sq_k_vocoder_lt.txt"):
+        f = ROOT / "profiles" / name
+        if f.exists():
+            vals = {}
+            for ln in f.read_text().splitlines():
+                p = ln.split()
+                if len(p) >= 2 and p[0].startswith("SQ_"):
+                    try:
+                        vals[p[0]] = float(p[1])
+                    except ValueError:
+                        pass
+            if "SQ_ACTIVE_INST_VALU" in vals and "SQ_WAVE_CYCLES" in vals:
+                # two waves per SIMD share one VALU: busy = active / (wave cycles / 2)
+                sq = {"source": f"profiles/{name} (rocprofv3 --pmc, separate run of the same command)",
+                      "SQ_ACTIVE_INST_VALU": vals["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": vals["SQ_WAVE_CYCLES"],
+                      "SQ_INSTS_VALU": vals.get("SQ_INSTS_VALU"),
+                      "valu_busy": vals["SQ_ACTIVE_INST_VALU"] / (vals["SQ_WAVE_CYCLES"] / 2.0)}
+            break
+    lt = bool(info["chunk_frames"]) and info["n_items"] >= 16384
+    return {
+        "bound": "valu_f64", "kernel": "k_vocoder_lt" if lt else "k_vocoder",
+        "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+        "kernel_ms": voc_ms, "alg_flop_per_sample": FLOP_PER_SAMPLE,
+        "note": "recursive IIR: bound by FP64 VALU issue, not by HBM (DESIGN.md section 4); achieved = useful "
+                "f64 flops of the path (SURVEY 8d: 1.39 kflop per output sample) / kernel time",
+        "sq_counters": sq,
+        "traffic": traffic,
+        # the HBM view (SURVEY 8d's per-unit figure x samples per launch / kernel time against 8 TB/s)
+        "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "alg_bytes_per_sample": B_ALG, "traffic": traffic},
+    }
 
-    for _ in range(max(args.warmup, 0)):
-        for b_ in batches:
-            b_.run()
-        for b_ in batches:
-            b_.sync()
-    barrier()
+
+def read_traffic(batch, frames):
+    """HBM bytes of the dominant kernel per launch from the committed PMC run of this command
+    (tools/traffic.sh -> profiles/*traffic.json); counters cannot be read inside an ordinary run."""
+    for name in ("r02_traffic.json", "traffic.json"):
+        tf = ROOT / "profiles" / name
+        if tf.exists():
+            try:
+                tj = json.loads(tf.read_text())
+                if tj.get("batch") == batch and tj.get("frames") == frames:
+                    return tj.get("hbm_bytes_per_launch"), f"profiles/{name}"
+            except Exception:
+                pass
+    return None, None
+
+
+# ---------------------------------------------------------------------------------------------
+def timed_steps(batches, steps, R):
+    """EXACTLY `steps` steps over the resident batches, bracketed by barrier + synchronize; returns
+    (seconds = max over ranks, vocoder kernel ms of every step)."""
+    depth = len(batches)
+    R.barrier()
     t0 = time.perf_counter()
     voc_ms = []
     inflight = [False] * depth
-    for k in range(args.steps):
+    for k in range(steps):
         # step k runs on batch k % depth; its stream is independent of the other batch's,
         # so parameter generation of this step overlaps the vocoder of the previous one
         j = k % depth
@@ -199,45 +355,267 @@ def main():
         if inflight[j]:
             batches[j].sync()
             voc_ms.append(batches[j].last_timing()[1])
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    R.barrier()
+    return R.max(time.perf_counter() - t0), voc_ms
+
+
+def config3_shard(R, tab, n_utts):
+    """This rank's share of the ONE config-3 job: the seed-fixed list of n_utts mixed lengths, LPT over
+    the ranks, then LPT of the share into sub-batches that fit HBM.  Returns (lens of the whole list,
+    [[IndexUtterance ...] per sub-batch], frames of this rank)."""
+    from jbonsai_amd import shard, synth
+
+    lens = synth.mixed_lengths(n_utts)  # the same list on every rank
+    mine = shard.shard_for_rank(lens, R.rank, R.world)
+    my_frames = sum(lens[i] for i in mine)
+    k = max(1, -(-my_frames // SUB_BATCH_FRAMES))
+    subs = shard.lpt_partition([lens[i] for i in mine], k)
+    out = []
+    for sb in subs:
+        ids = [mine[j] for j in sb]
+        out.append([synth.synth_utterance(tab, lens[i], 2000 + i, indexed=True) for i in ids])
+    return lens, out, my_frames
+
+
+def run_config3(R, J, tab, vi, pset, args, steps, warmup):
+    """The strong-scaling job.  A step = the whole 4096-utterance list once: every rank walks its
+    sub-batches; a sub-batch is created from pdf row indices (12 B per state cross PCIe; gather + blend
+    on the device), run, certified and released INSIDE the timed region -- the shares of 1, 2 and 4
+    ranks do not fit HBM as one batch.  The pdf tables are resident before it starts.
+    A rank whose local work fails still joins every collective (the others must not hang on it) and
+    the record carries the failure."""
+    from jbonsai_amd import shard, synth
+
+    lens = synth.mixed_lengths(args.utts)
+    total_samples = sum(lens) * vi.fperiod
+    err, subs, my_frames = None, [], 0
+    try:
+        lens, subs, my_frames = config3_shard(R, tab, args.utts)
+    except Exception as e:
+        err = repr(e)
+
+    def one_pass():
+        for utts in subs:
+            b = J.Batch(vi, utts, device=R.local_rank, pdf_set=pset)
+            try:
+                b.run()
+                b.sync()
+            finally:
+                b.close()
+
+    def passes(n):
+        nonlocal err
+        if err is not None or R.dry:
+            return
+        try:
+            for _ in range(n):
+                one_pass()
+        except Exception as e:
+            err = repr(e)
+
+    passes(max(warmup, 0))
+    R.barrier()
+    t0 = time.perf_counter()
+    passes(steps)
+    t_mine = time.perf_counter() - t0
+    R.barrier()
+    dt = R.max(time.perf_counter() - t0)
+    per_rank = R.all_gather_floats([t_mine / steps * 1e3, float(my_frames), float(len(subs)),
+                                    0.0 if err is None else 1.0])
+    parts = shard.lpt_partition(lens, R.world)
+    rec = {
+        "workload": f"ONE job of {args.utts} distinct synthetic utterances, lengths U[400, 25546] frames (seed-fixed, "
+                    f"BASELINE config 3), LPT-sharded over {R.world} rank(s); each rank walks its share in "
+                    f"sub-batches of <= {SUB_BATCH_FRAMES} frames created from pdf row indices, run and released "
+                    "inside the timed region",
+        "value": total_samples * steps / dt, "unit": "samples/s", "scaling": "strong",
+        "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+        "realtime_factor": total_samples * steps / dt / vi.sampling_frequency,
+        "total_samples_per_step": total_samples,
+        "per_rank_ms": [p[0] for p in per_rank], "per_rank_frames": [int(p[1]) for p in per_rank],
+        "per_rank_sub_batches": [int(p[2]) for p in per_rank],
+        "imbalance_max_over_mean_frames": shard.imbalance(lens, parts),
+    }
+    if any(p[3] != 0.0 for p in per_rank):
+        rec["error"] = f"rank(s) {[i for i, p in enumerate(per_rank) if p[3] != 0.0]} failed" + (f": {err}" if err else "")
+        rec["value"] = None
+    return rec
+
+
+def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_step, R):
+    """Secondary records of the N = 1 line; none of them enters `value`."""
+    import numpy as np
+    from jbonsai_amd import synth
+    from tests.golden.labels import SAMPLE_SENTENCE_2
+
+    ex = {}
+
+    def host_mem_ok(nbytes):
+        try:
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemAvailable:"):
+                    return int(ln.split()[1]) * 1024 > 3 * nbytes
+        except OSError:
+            pass
+        return False
+
+    # (1) PCM on the host: the step plus the staged D2H of the whole slab (f64, and the fused 16-bit sink)
+    try:
+        if not host_mem_ok(batch.total_samples * 8):
+            raise MemoryError("host memory too small for the PCM of this batch")
+        bufs = [np.empty(batch.num_samples(i), dtype=np.float64) for i in range(len(batch))]
+        batch.pcm_all(bufs)  # first read touches the pages; the timed one below is at link rate
+        t0 = time.perf_counter()
+        batch.pcm_all(bufs)
+        d2h = (time.perf_counter() - t0) * 1e3
+        nbytes = sum(b.nbytes for b in bufs)
+        ex["d2h_inclusive"] = {"f64": {"d2h_ms": d2h, "ms_per_step": ms_per_step + d2h, "GBps": nbytes / d2h / 1e6,
+                                       "bytes": nbytes}}
+        del bufs
+        b16 = J.Batch(vi, batch_utts, device=R.local_rank, pcm_i16=True)
+        b16.run()
+        b16.sync()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            b16.run()
+            b16.sync()
+        step16 = (time.perf_counter() - t0) / 2 * 1e3
+        bufs = [np.empty(b16.num_samples(i), dtype=np.int16) for i in range(len(b16))]
+        b16.pcm_all(bufs)
+        t0 = time.perf_counter()
+        b16.pcm_all(bufs)
+        d2h = (time.perf_counter() - t0) * 1e3
+        ex["d2h_inclusive"]["i16"] = {"d2h_ms": d2h, "ms_per_step": step16 + d2h, "step_ms": step16,
+                                      "GBps": sum(b.nbytes for b in bufs) / d2h / 1e6}
+        del bufs
+        b16.close()
+    except Exception as e:  # a secondary record must not cost the headline
+        ex["d2h_inclusive"] = {"error": repr(e)}
+    # (2) config 2 with 64 DISTINCT utterances tiled over the batch: real hand-off failures and redo
+    try:
+        nd = 64
+        du = [batch_utts[0]] + [synth.synth_utterance(tab, frames, 1000 + i) for i in range(1, nd)]
+        bd = J.Batch(vi, [du[i % nd] for i in range(args.batch)], device=R.local_rank)
+        bd.run()
+        bd.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            bd.run()
+            bd.sync()
+        ex["distinct_64"] = {"ms_per_step": (time.perf_counter() - t0) / 3 * 1e3,
+                             "chunks_redone": bd.info()["n_redo"],
+                             "settled_at_checkpoint": bd.redo_stats()[0], "redone_to_end": bd.redo_stats()[1]}
+        bd.close()
+    except Exception as e:
+        ex["distinct_64"] = {"error": repr(e)}
+    # (3) labels -> PCM on the host through the engine entry (front half on host threads, device gather,
+    #     GPU hot path, staged D2H): 64 utterances of 75 x SAMPLE_SENTENCE_2
+    try:
+        utt = list(SAMPLE_SENTENCE_2) * 75
+        lb = [utt] * 64
+        eng.synthesize_batch(lb[:2])
+        rec = {}
+        for key, i16 in (("f64", False), ("i16", True)):
+            outs = None
+            t0 = time.perf_counter()
+            outs = eng.synthesize_batch(lb, i16=i16)
+            dt = time.perf_counter() - t0
+            ns = sum(len(o) for o in outs)
+            rec[key] = {"wall_ms": dt * 1e3, "samples": ns, "realtime_factor": ns / dt / vi.sampling_frequency}
+        rec["workload"] = f"jb_synthesize_batch: 64 utterances x {len(outs[0]) / vi.sampling_frequency:.0f} s (labels in, PCM on the host out)"
+        outs = None
+        ex["labels_to_pcm"] = rec
+    except Exception as e:
+        ex["labels_to_pcm"] = {"error": repr(e)}
+    return ex
+
+
+def run_rank(args):
+    import torch  # first: so that this process uses ONE HIP runtime (same SONAME as ours)
+
+    R = Ranks()
+    import jbonsai_amd as J
+    from jbonsai_amd import synth
+
+    eng = J.Engine.load([VOICE])
+    tab = synth.VoiceTables(eng)
+    vi = eng.voice_info()
+    vi.beta = args.beta
+    frames = args.frames or synth.T_128S
+    out = None
+
+    if R.dry:
+        rec = run_config3(R, J, tab, vi, None, args, 1, 0)
+        gms = R.gather_slabs(torch.arange(1000 * (R.rank + 1), dtype=torch.float64))
+        if R.rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": R.world, "gather_ms": gms, "config3_plan": rec}), flush=True)
+        R.close()
+        return
+    if args.job == "config3":
+        pset = tab.pdf_set(R.local_rank)
+        rec = run_config3(R, J, tab, vi, pset, args, args.steps, args.warmup)
+        if R.rank == 0:
+            out = {
+                "metric": "48 kHz PCM samples/sec (whole node), batched utterances",
+                "value": rec["value"], "unit": "samples/s", "n_gpus": R.world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": rec["workload"], "utterances": args.utts,
+                           "parallelism": f"utterance-sharded x{R.world} (LPT by frames)"},
+                "realtime_factor": rec["realtime_factor"],
+                "per_rank_ms": rec["per_rank_ms"], "per_rank_frames": rec["per_rank_frames"],
+                "per_rank_sub_batches": rec["per_rank_sub_batches"],
+                "imbalance_max_over_mean_frames": rec["imbalance_max_over_mean_frames"],
+            }
+            print(json.dumps(out), flush=True)
+        pset.close()
+        R.close()
+        return
+
+    # ---- config 2 (headline): every utterance of the batch is the same sequence ("256 copies"),
+    # uploaded once and aliased; outputs / workspace / filter state are per utterance
+    utt = synth.synth_utterance(tab, frames, 0)
+    nd = max(1, min(args.distinct, args.batch))
+    utts = [utt] + [synth.synth_utterance(tab, frames, 1000 + i) for i in range(1, nd)]
+    depth = max(1, args.pipeline)
+    cu_split = args.cu_split if args.cu_split >= 0 else (DEFAULT_CU_SPLIT if depth > 1 else 0)
+    if args.mixed:
+        lens = synth.mixed_lengths(args.batch, seed=3 + R.rank)
+        batch_utts = [synth.synth_utterance(tab, T, 2000 + i) for i, T in enumerate(lens)]
+    else:
+        batch_utts = [utts[i % nd] for i in range(args.batch)]
+    batches = [J.Batch(vi, batch_utts, device=R.local_rank, mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
+    batch = batches[0]
+    samples_per_step = batch.total_samples
+
+    for _ in range(max(args.warmup, 0)):
+        for b_ in batches:
+            b_.run()
+        for b_ in batches:
+            b_.sync()
+    dt, voc_ms = timed_steps(batches, args.steps, R)
 
     gather_ms = None
-    if args.gather and dist is not None and not rehearse:
+    if args.gather and R.world > 1:
         # optional sink of north_star: PCM of all ranks on GPU 0.  The slab is library-owned device
         # memory viewed zero-copy; rank 0 needs world x 12.6 GB of HBM for config 2.
-        slab = pcm_slab_tensor(batch)
-        dest = [torch.empty_like(slab) for _ in range(world)] if rank == 0 else None
-        barrier()
-        tg = time.perf_counter()
-        dist.gather(slab, dest, dst=0)
-        barrier()
-        gather_ms = (time.perf_counter() - tg) * 1e3
-        del dest
+        gather_ms = R.gather_slabs(pcm_slab_tensor(batch))
 
-    if rank == 0:
-        total = samples_per_step * world * args.steps
+    info = batch.info()
+    redo_stats = batch.redo_stats()
+    ms_per_step = dt / args.steps * 1e3
+    for b_ in batches[1:]:
+        b_.close()
+
+    if R.rank == 0:
+        total = samples_per_step * R.world * args.steps
         value = total / dt
         voc_avg_ms = sum(voc_ms) / len(voc_ms)
-        achieved = B_ALG * samples_per_step / (voc_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tf = ROOT / "profiles" / "traffic.json"
-        if tf.exists():
-            try:
-                tj = json.loads(tf.read_text())
-                if tj.get("batch") == args.batch and tj.get("frames") == frames:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        info = batch.info()
+        traffic, traffic_src = read_traffic(args.batch, frames)
         out = {
             "metric": "48 kHz PCM samples/sec (whole node), batched utterances",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "value": value, "unit": "samples/s", "n_gpus": R.world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {
@@ -248,36 +626,49 @@ def main():
                              f"({frames * vi.fperiod / vi.sampling_frequency:.1f} s) synthetic state-level "
                              "utterance from real nitech pdfs (BASELINE config 2), nitech voice"),
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
-                "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{world}",
+                "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{R.world}",
                 "batches_in_flight": depth, "mlpg_cus_per_xcd": cu_split, "distinct_utterances": nd,
                 "beta": args.beta,
-                "chunks_settled_at_checkpoint_last_step": batch.redo_stats()[0],
+                "chunks_settled_at_checkpoint_last_step": redo_stats[0],
                 "vocoder_chunk_frames": info["chunk_frames"], "vocoder_warmup_frames": info["warmup_frames"],
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
             "realtime_factor": value / vi.sampling_frequency,
             **({"gather_ms": gather_ms} if gather_ms is not None else {}),
-            "roofline": {
-                "bound": "hbm", "kernel": "k_vocoder_lt" if info["chunk_frames"] and info["n_items"] >= 16384 else "k_vocoder", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel_ms": voc_avg_ms, "alg_bytes_per_sample": B_ALG,
-                "note": "recursive IIR: FP64 VALU-issue bound, not HBM bound (DESIGN.md section 4); see valu_f64",
-                # the bound that actually binds: useful f64 flops of the path (1.39 kflop per
-                # output sample) over the same kernel time, against the FP64 vector peak of the guide
-                "valu_f64": {"achieved_tflops": FLOP_PER_SAMPLE * samples_per_step / (voc_avg_ms * 1e-3) / 1e12,
-                             "peak_tflops": FP64_VALU_PEAK_TFLOPS,
-                             "frac": FLOP_PER_SAMPLE * samples_per_step / (voc_avg_ms * 1e-3) / 1e12
-                                     / FP64_VALU_PEAK_TFLOPS},
-            },
+            "roofline": roofline_block(samples_per_step, voc_avg_ms, info, traffic),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        out["roofline"]["traffic_source"] = traffic_src
+    if R.world == 1 and not args.no_extras:
+        ex = extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_step, R)
+        if out is not None:
+            out.update(ex)
+    batch.close()
+    if R.world > 1 and not args.no_extras:
+        # the strong-scaling job beside the headline: one warm-up pass and two timed passes of this
+        # rank's share of the 4096-utterance list
+        pset = None
+        try:
+            pset = tab.pdf_set(R.local_rank)
+        except Exception:
+            pass  # run_config3 reports it: creating a batch over a missing set fails on this rank only
+        rec = run_config3(R, J, tab, vi, pset, args, 2, 1)
+        if pset is not None:
+            pset.close()
+        if out is not None:
+            out["config3_strong"] = rec
+    if R.rank == 0:
+        if R.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(utt, vi)
         print(json.dumps(out), flush=True)
-    for b_ in batches:
-        b_.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    R.close()
+
+
+def main():
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no torchrun around us: be the launcher.  Nothing above has imported torch or touched HIP.
+        sys.exit(spawn_ranks(args.gpus))
+    run_rank(args)
 
 
 if __name__ == "__main__":

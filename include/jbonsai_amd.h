@@ -189,11 +189,19 @@ size_t jb_batch_size(const jb_batch *b);
 size_t jb_batch_num_frames(const jb_batch *b, size_t utt);
 size_t jb_batch_num_samples(const jb_batch *b, size_t utt);
 size_t jb_batch_total_samples(const jb_batch *b);
-/* Copy utterance `utt`'s PCM (f64, un-clipped, as Vec<f64> of src/engine.rs:294). */
+/* The read entries below (and jb_batch_device_pcm) wait for the batch's pending run and for the
+ * hand-off certification + redo first, as jb_batch_sync does: what they return is the finished result.
+ * Copy utterance `utt`'s PCM (f64, un-clipped, as Vec<f64> of src/engine.rs:294). */
 int jb_batch_read_pcm(jb_batch *b, size_t utt, double *dst, size_t cap);
 /* Same for a batch created with JB_BATCH_PCM_I16 (16-bit PCM as written to WAV by the reference's
  * examples, examples/is-bonsai/main.rs:37-49). */
 int jb_batch_read_pcm_i16(jb_batch *b, size_t utt, int16_t *dst, size_t cap);
+/* Whole batch at once: dst[u] must hold jb_batch_num_samples(b, u) samples (may be NULL for empty
+ * utterances).  The slab streams through a ring of pinned slots at link rate while worker threads
+ * scatter finished slots into the caller's buffers (what jb_synthesize_batch uses): several times the
+ * rate of one pageable copy per utterance. */
+int jb_batch_read_pcm_all(jb_batch *b, double *const *dst);
+int jb_batch_read_pcm_i16_all(jb_batch *b, int16_t *const *dst);
 /* Parameter track of stream s ([T][L], NODATA in unvoiced frames); needs KEEP_TRACKS. */
 int jb_batch_read_track(jb_batch *b, size_t utt, uint32_t stream, double *dst, size_t cap);
 /* Device memory and HIP streams of freed batches are kept per device for the next batch
@@ -224,6 +232,18 @@ void jb_batch_free(jb_batch *b);
  * n_samples[i] doubles; call with pcm==NULL to get n_samples only. */
 int jb_paramgen_vocode_batch(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
                              const jb_batch_opts *opts, double *const *pcm, size_t *n_samples);
+
+/* ---- multi-GPU (SURVEY 8b "device_ids[] / n_devices", 8e) ----------------------------------
+ * Utterances are independent, so a batch shards over the GPUs of a node with no data-path
+ * collective: static LPT partition by length, one host thread per device, results in the caller's
+ * order.  A device may be listed more than once (two shares run side by side on it). */
+/* part_of[i] = bin of item i: items heaviest first (ties: lower index), each onto the currently
+ * lightest bin (ties: lower bin).  The rule jbonsai_amd/shard.py states for one-process-per-GPU drivers. */
+int jb_lpt_partition(const uint64_t *weights, size_t n, size_t n_parts, uint32_t *part_of);
+/* jb_paramgen_vocode_batch over a device list (weights = frames per utterance; opts->device is ignored). */
+int jb_paramgen_vocode_batch_multi(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
+                                   const jb_batch_opts *opts, const int32_t *devices, size_t n_devices,
+                                   double *const *pcm, size_t *n_samples);
 
 /* ------------------------------------------------------------------------ */
 /* (2) engine level                                                         */
@@ -291,6 +311,15 @@ int jb_synthesize_batch_i16(const jb_engine *e, const char *const *label_lines,
                             const size_t *line_off, size_t n_utts, int32_t device,
                             int16_t **pcm, size_t *n_samples);
 void jb_pcm_i16_free(int16_t *pcm);
+/* The same two over a device list: the utterances are split by LPT on their label counts (the frame
+ * counts are known only after the front half), one host thread per device runs jb_synthesize_batch's
+ * path on its share (front half on that thread's workers, GPU work on that device). */
+int jb_synthesize_batch_multi(const jb_engine *e, const char *const *label_lines, const size_t *line_off,
+                              size_t n_utts, const int32_t *devices, size_t n_devices, double **pcm,
+                              size_t *n_samples);
+int jb_synthesize_batch_i16_multi(const jb_engine *e, const char *const *label_lines, const size_t *line_off,
+                                  size_t n_utts, const int32_t *devices, size_t n_devices, int16_t **pcm,
+                                  size_t *n_samples);
 
 /* Host front half only (tree search + durations): fills a state-level utterance
  * owned by the returned handle; used by tests and by jb_synthesize itself. */

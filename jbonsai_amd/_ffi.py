@@ -82,6 +82,34 @@ class StateUtt(C.Structure):
     ]
 
 
+MAX_VOICES = 8
+
+
+class PdfTable(C.Structure):
+    _fields_ = [("rows", C.POINTER(C.c_float)), ("n_rows", C.c_uint32), ("row_len", C.c_uint32)]
+
+
+class IndexStream(C.Structure):
+    _fields_ = [
+        ("row", C.POINTER(C.c_uint32) * MAX_VOICES),
+        ("weight", C.POINTER(C.c_double)),
+        ("gv_mean", C.POINTER(C.c_double)),
+        ("gv_var", C.POINTER(C.c_double)),
+        ("gv_switch", C.POINTER(C.c_uint8)),
+        ("gv_weight", C.c_double),
+        ("msd_threshold", C.c_double),
+    ]
+
+
+class IndexUtt(C.Structure):
+    _fields_ = [
+        ("num_states", C.c_uint32),
+        ("durations", C.POINTER(C.c_uint32)),
+        ("stream", IndexStream * MAX_STREAM),
+        ("lf0_offset", C.c_double),
+    ]
+
+
 class BatchOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("chunk_frames", C.c_uint32),
                 ("warmup_frames", C.c_uint32), ("verify_tol", C.c_double), ("mlpg_cus_per_xcd", C.c_uint32), ("reserved", C.c_uint32)]
@@ -91,7 +119,7 @@ class BatchOpts(C.Structure):
 SYMBOLS = [
     "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_last_timing", "jb_batch_size",
     "jb_batch_num_frames", "jb_batch_num_samples", "jb_batch_total_samples", "jb_batch_read_pcm",
-    "jb_batch_read_pcm_i16", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_batch_read_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
+    "jb_batch_read_pcm_i16", "jb_batch_read_pcm_all", "jb_batch_read_pcm_i16_all", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_batch_read_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
     "jb_batch_info", "jb_batch_redo_stats", "jb_batch_free", "jb_paramgen_vocode_batch",
     "jb_engine_load", "jb_engine_load_from_bytes", "jb_engine_free",
     "jb_engine_set_sampling_frequency", "jb_engine_get_sampling_frequency",
@@ -107,6 +135,7 @@ SYMBOLS = [
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
     "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",
     "jb_generator_total_frames", "jb_generator_step", "jb_generator_free",
+    "jb_lpt_partition", "jb_paramgen_vocode_batch_multi", "jb_synthesize_batch_multi", "jb_synthesize_batch_i16_multi",
     "jb_last_error", "jb_device_count", "jb_device_arch", "jb_version",
 ]
 
@@ -142,6 +171,11 @@ def lib():
     L.jb_device_arch.argtypes = [C.c_int, C.c_char_p, sz]
     L.jb_batch_create.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz, C.POINTER(BatchOpts),
                                   C.POINTER(vp)]
+    L.jb_pdf_set_create.argtypes = [C.POINTER(PdfTable), C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(vp)]
+    L.jb_pdf_set_free.argtypes = [vp]
+    L.jb_pdf_set_free.restype = None
+    L.jb_batch_create_indexed.argtypes = [C.POINTER(VoiceDesc), vp, C.POINTER(IndexUtt), sz, C.POINTER(BatchOpts),
+                                          C.POINTER(vp)]
     L.jb_batch_run.argtypes = [vp]
     L.jb_batch_sync.argtypes = [vp]
     L.jb_batch_run_timed.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -153,6 +187,8 @@ def lib():
         getattr(L, n).restype = sz
         getattr(L, n).argtypes = [vp, sz]
     L.jb_batch_read_pcm.argtypes = [vp, sz, vp, sz]
+    L.jb_batch_read_pcm_all.argtypes = [vp, C.POINTER(vp)]
+    L.jb_batch_read_pcm_i16_all.argtypes = [vp, C.POINTER(vp)]
     L.jb_batch_read_track.argtypes = [vp, sz, C.c_uint32, vp, sz]
     L.jb_batch_read_coefficients.argtypes = [vp, sz, vp, sz]
     L.jb_batch_read_pcm_i16.argtypes = [vp, sz, vp, sz]
@@ -165,6 +201,9 @@ def lib():
     L.jb_batch_free.restype = None
     L.jb_paramgen_vocode_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz,
                                            C.POINTER(BatchOpts), C.POINTER(dp), C.POINTER(sz)]
+    L.jb_lpt_partition.argtypes = [C.POINTER(C.c_uint64), sz, sz, C.POINTER(C.c_uint32)]
+    L.jb_paramgen_vocode_batch_multi.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz, C.POINTER(BatchOpts),
+                                                 C.POINTER(C.c_int32), sz, C.POINTER(dp), C.POINTER(sz)]
     L.jb_write_wav_i16.argtypes = [C.c_char_p, vp, sz, C.c_uint32]
     L.jb_write_wav_f64.argtypes = [C.c_char_p, vp, sz, C.c_uint32]
     _lib = L

@@ -92,20 +92,98 @@ class Utterance:
         return u
 
 
+class PdfSet:
+    """Device-resident pdf tables of a voice set (jb_pdf_set_create): tables[v][s] = float32 array
+    [n_rows, row_len] of stream s of voice v, all trees of the stream concatenated."""
+
+    def __init__(self, tables: Sequence[Sequence[np.ndarray]], device: int = -1):
+        L = F.lib()
+        self._L = L
+        nv, ns = len(tables), len(tables[0])
+        self._keep = [[np.ascontiguousarray(t, dtype=np.float32) for t in row] for row in tables]
+        arr = (F.PdfTable * (nv * ns))()
+        for v in range(nv):
+            for s in range(ns):
+                t = self._keep[v][s]
+                arr[v * ns + s].rows = t.ctypes.data_as(C.POINTER(C.c_float))
+                arr[v * ns + s].n_rows, arr[v * ns + s].row_len = t.shape
+        h = C.c_void_p()
+        F.check(L.jb_pdf_set_create(arr, nv, ns, device, C.byref(h)))
+        self._h, self.n_voices, self.nstream, self.device = h, nv, ns, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.jb_pdf_set_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class IndexStreamStates:
+    """One stream of an utterance as pdf row indices (jb_index_stream): rows[v] = uint32 [S] rows of
+    voice v's table; weights [n_voices]."""
+    rows: List[np.ndarray]
+    weights: np.ndarray
+    gv_mean: Optional[np.ndarray] = None
+    gv_var: Optional[np.ndarray] = None
+    gv_switch: Optional[np.ndarray] = None
+    gv_weight: float = 1.0
+    msd_threshold: float = 0.5
+
+    def __post_init__(self):
+        f = lambda a, t: None if a is None else np.ascontiguousarray(a, dtype=t)
+        self.rows = [np.ascontiguousarray(r, dtype=np.uint32) for r in self.rows]
+        self.weights = np.ascontiguousarray(self.weights, dtype=np.float64)
+        self.gv_mean, self.gv_var = f(self.gv_mean, np.float64), f(self.gv_var, np.float64)
+        self.gv_switch = f(self.gv_switch, np.uint8)
+
+
+@dataclass
+class IndexUtterance:
+    durations: np.ndarray
+    streams: List[IndexStreamStates] = field(default_factory=list)
+    lf0_offset: float = 0.0
+
+    def __post_init__(self):
+        self.durations = np.ascontiguousarray(self.durations, dtype=np.uint32)
+
+    def c_struct(self):
+        u = F.IndexUtt()
+        u.num_states = len(self.durations)
+        u.durations = self.durations.ctypes.data_as(C.POINTER(C.c_uint32))
+        u.lf0_offset = self.lf0_offset
+        for i, s in enumerate(self.streams):
+            d = u.stream[i]
+            for v, r in enumerate(s.rows):
+                d.row[v] = r.ctypes.data_as(C.POINTER(C.c_uint32))
+            d.weight = _dp(s.weights)
+            d.gv_mean, d.gv_var = _dp(s.gv_mean), _dp(s.gv_var)
+            d.gv_switch = s.gv_switch.ctypes.data_as(C.POINTER(C.c_uint8)) if s.gv_switch is not None else None
+            d.gv_weight, d.msd_threshold = s.gv_weight, s.msd_threshold
+        return u
+
+
 class Batch:
-    """A batch of utterances resident in HBM (jb_batch_*)."""
+    """A batch of utterances resident in HBM (jb_batch_*).  `utts` are state-level utterances
+    (Utterance), or -- with `pdf_set` -- pdf row indices (IndexUtterance: the per-state Gaussians are
+    gathered and blended on the device, jb_batch_create_indexed)."""
 
     def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
                  keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
                  kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False,
-                 mlpg_cus_per_xcd: int = 0):
+                 mlpg_cus_per_xcd: int = 0, pdf_set: Optional[PdfSet] = None):
         L = F.lib()
         self._L = L
         self.voice = voice
         self._utts = list(utts)  # keep host arrays alive during create
         vd, keep = voice.c_struct()
-        arr = (F.StateUtt * max(1, len(utts)))()
+        arr = ((F.IndexUtt if pdf_set is not None else F.StateUtt) * max(1, len(utts)))()
         for i, u in enumerate(self._utts):
             arr[i] = u.c_struct()
         opts = F.BatchOpts()
@@ -118,7 +196,10 @@ class Batch:
         opts.mlpg_cus_per_xcd = mlpg_cus_per_xcd
         self.flags, self.device = opts.flags, device
         h = C.c_void_p()
-        F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
+        if pdf_set is not None:
+            F.check(L.jb_batch_create_indexed(C.byref(vd), pdf_set._h, arr, len(utts), C.byref(opts), C.byref(h)))
+        else:
+            F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
         self._h = h
         self._keep = keep
 
@@ -169,6 +250,19 @@ class Batch:
         n = self.num_samples(i)
         out = np.empty(n, dtype=np.int16)
         F.check(self._L.jb_batch_read_pcm_i16(self._h, i, out.ctypes.data, n))
+        return out
+
+    def pcm_all(self, out: Optional[List[np.ndarray]] = None) -> List[np.ndarray]:
+        """Every utterance's PCM through the staged whole-slab read (jb_batch_read_pcm_all /
+        _i16_all); `out` re-uses caller buffers (already touched pages: the read then runs at link rate)."""
+        i16 = bool(self.flags & F.BATCH_PCM_I16)
+        dt = np.int16 if i16 else np.float64
+        n = len(self)
+        if out is None:
+            out = [np.empty(self.num_samples(i), dtype=dt) for i in range(n)]
+        ptrs = (C.c_void_p * max(1, n))(*[o.ctypes.data if o.size else None for o in out])
+        fn = self._L.jb_batch_read_pcm_i16_all if i16 else self._L.jb_batch_read_pcm_all
+        F.check(fn(self._h, ptrs))
         return out
 
     def track(self, i, stream) -> np.ndarray:
@@ -222,9 +316,27 @@ class Batch:
         self.close()
 
 
-def paramgen_vocode_batch(voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1):
-    """One-shot jb_paramgen_vocode_batch: returns a list of f64 PCM arrays."""
-    with Batch(voice, utts, device=device) as b:
-        b.run()
-        b.sync()
-        return [b.pcm(i) for i in range(len(utts))]
+def paramgen_vocode_batch(voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
+                          devices: Optional[Sequence[int]] = None):
+    """One-shot jb_paramgen_vocode_batch: returns a list of f64 PCM arrays.  With `devices` the batch
+    goes through jb_paramgen_vocode_batch_multi: LPT split by frames over the listed GPUs, one host
+    thread per device (a device may be listed more than once)."""
+    if devices is None:
+        with Batch(voice, utts, device=device) as b:
+            b.run()
+            b.sync()
+            return [b.pcm(i) for i in range(len(utts))]
+    L = F.lib()
+    vd, keep = voice.c_struct()
+    arr = (F.StateUtt * max(1, len(utts)))()
+    for i, u in enumerate(utts):
+        arr[i] = u.c_struct()
+    fp = voice.fperiod
+    out = [np.empty(int(u.durations.sum()) * fp, dtype=np.float64) for u in utts]
+    ptrs = (C.POINTER(C.c_double) * max(1, len(utts)))(*[_dp(o) for o in out])
+    ns = (C.c_size_t * max(1, len(utts)))()
+    dv = (C.c_int32 * max(1, len(devices)))(*[int(d) for d in devices])
+    F.check(L.jb_paramgen_vocode_batch_multi(C.byref(vd), arr, len(utts), None, dv, len(devices), ptrs, ns))
+    assert all(ns[i] == len(out[i]) for i in range(len(utts)))
+    del keep
+    return out

@@ -68,22 +68,39 @@ struct NoiseCache {
     std::vector<double> host; // always a multiple of 64 long
     uint32_t lcg = 1;
     size_t have = 0;
-    std::map<int, std::pair<double *, size_t>> dev; // device -> (ptr, len)
+    std::map<int, std::shared_ptr<NoiseDev>> dev; // device -> current table
 };
-static NoiseCache g_noise;
+// never destroyed: its tables would be freed after the HIP runtime has shut down
+static NoiseCache &g_noise = *new NoiseCache();
 
-int noise_table(int device, size_t need, const double **ptr, size_t *len)
+NoiseDev::~NoiseDev()
+{
+    if (ptr) {
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device)
+            hipSetDevice(device);
+        hipFree(ptr);
+        if (cur >= 0 && cur != device)
+            hipSetDevice(cur);
+    }
+}
+
+// The table of a device grows geometrically (a creeping maximum length does not reallocate every
+// time); a superseded table lives on while a Batch still holds it and is freed with the last one.
+int noise_table(int device, size_t need, std::shared_ptr<NoiseDev> *out)
 {
     std::lock_guard<std::mutex> lk(g_noise.mu);
     need = (need + 63) / 64 * 64;
     if (need == 0)
         need = 64;
     auto it = g_noise.dev.find(device);
-    if (it != g_noise.dev.end() && it->second.second >= need) {
-        *ptr = it->second.first;
-        *len = it->second.second;
+    if (it != g_noise.dev.end() && it->second->len >= need) {
+        *out = it->second;
         return JB_OK;
     }
+    if (it != g_noise.dev.end())
+        need = std::max(need, 2 * it->second->len);
     if (g_noise.have < need) {
         // restart from the stored LCG state at a refill boundary
         std::vector<double> &h = g_noise.host;
@@ -96,15 +113,16 @@ int noise_table(int device, size_t need, const double **ptr, size_t *len)
     if (e != hipSuccess)
         return hip_fail(e, "hipMalloc(noise)");
     e = hipMemcpy(d, g_noise.host.data(), need * sizeof(double), hipMemcpyHostToDevice);
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+        hipFree(d);
         return hip_fail(e, "hipMemcpy(noise)");
-    if (it != g_noise.dev.end()) {
-        // older, shorter table: leave it alive (batches may still point at it)
-        g_noise.dev.erase(it);
     }
-    g_noise.dev[device] = {d, need};
-    *ptr = d;
-    *len = need;
+    std::shared_ptr<NoiseDev> nd(new NoiseDev());
+    nd->device = device;
+    nd->ptr = d;
+    nd->len = need;
+    g_noise.dev[device] = nd; // the older, shorter table stays alive in the batches that hold it
+    *out = nd;
     return JB_OK;
 }
 
@@ -835,12 +853,10 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.state_stride = vocoder_state_doubles(vd.nmcp);
     if ((rc = b->dalloc(&vd.state, (size_t)vd.state_stride * n, true)))
         return rc;
-    const double *np;
-    size_t nl;
-    if ((rc = noise_table(dev, (size_t)maxT * (size_t)vd.fperiod, &np, &nl)))
+    if ((rc = noise_table(dev, (size_t)maxT * (size_t)vd.fperiod, &b->noise)))
         return rc;
-    vd.noise = np;
-    vd.noise_len = nl;
+    vd.noise = b->noise->ptr;
+    vd.noise_len = b->noise->len;
     if (vd.beta > 0.0 && (e = launch_pf_table(vd, b->stream)) != hipSuccess)
         return hip_fail(e, "k_pf_table");
     if ((rc = b->build_work(opts)))
@@ -1114,8 +1130,8 @@ int Batch::run(bool timed)
         hipEventRecord(ev2, stream_voc);
     if (chunk_frames != 0 && n_items > 0) {
         hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
-        if ((e = launch_voc_verify(work_dev, n_items, vd.state_stride, verify_tol, bad_dev, nbad_dev,
-                                   stream_voc)) != hipSuccess)
+        if ((e = launch_voc_verify(work_dev, n_items, vd.state_stride, vd.nmcp - 1, verify_tol, bad_dev,
+                                   nbad_dev, stream_voc)) != hipSuccess)
             return hip_fail(e, "k_voc_verify");
         verify_pending = true;
     }
@@ -1150,7 +1166,7 @@ int Batch::finish_verify()
     // recomputed state meets the checkpoint the original chunk left there, the rest of that chunk
     // was computed from a trajectory that had already converged and stands; otherwise the
     // recomputation continues from there to the end of the chunk.
-    n_redo_partial = n_redo_full = 0;
+    n_redo_partial = n_redo_full = n_recert_failed = 0;
     const size_t stride = state_stride;
     int rc;
     if (!redo_dev && (rc = dalloc(&redo_dev, n_items, false)))
@@ -1182,7 +1198,8 @@ int Batch::finish_verify()
             break;
         // stage A: up to the checkpoint (or the whole chunk where there is none)
         std::vector<VocWork> round;
-        std::vector<uint32_t> part; // positions in ids with a checkpoint
+        std::vector<uint32_t> part;     // positions in ids with a checkpoint
+        std::vector<uint32_t> full_ids; // chunks recomputed to their end in this round
         for (size_t j = 0; j < ids.size(); j++) {
             const uint32_t k = ids[j];
             VocWork w = work[k];
@@ -1195,6 +1212,7 @@ int Batch::finish_verify()
                 part.push_back((uint32_t)j);
             } else {
                 n_redo_full++;
+                full_ids.push_back(k);
             }
             w.save_ckpt = nullptr;
             round.push_back(w);
@@ -1228,6 +1246,7 @@ int Batch::finish_verify()
                     continue;
                 }
                 n_redo_full++;
+                full_ids.push_back(k);
                 VocWork w = work[k];
                 w.t_start = w.t_out = work[k].t_out + vd.ckpt_frames;
                 w.load_state = tmp_state + (size_t)k * stride;
@@ -1240,13 +1259,48 @@ int Batch::finish_verify()
         }
         for (uint32_t k : ids)
             pending[k] = 0;
+        // Re-certification.  Chunk k+1 was checked against the end state chunk k left in the first
+        // pass -- the end of a trajectory now known to have started wrong.  Where chunk k has been
+        // recomputed to its end, that dump now holds the exact state: compare it with the warm state of
+        // chunk k+1 again and put k+1 on the list if it fails.  (A chunk settled at its checkpoint kept
+        // its first-pass end state, whose trajectory was certified at the checkpoint: nothing to re-check.)
+        std::vector<uint32_t> succ;
+        for (uint32_t k : full_ids)
+            if (k + 1 < n_items && work[k + 1].utt == work[k].utt && work[k + 1].save_warm && !pending[k + 1] &&
+                work[k].save_end)
+                succ.push_back(k + 1);
+        if (!succ.empty()) {
+            std::vector<const double *> pairs(2 * succ.size());
+            for (size_t q = 0; q < succ.size(); q++) {
+                pairs[2 * q] = work[succ[q]].save_warm;
+                pairs[2 * q + 1] = work[succ[q] - 1].save_end;
+            }
+            hipMemcpy(pairs_dev, pairs.data(), sizeof(double *) * pairs.size(), hipMemcpyHostToDevice);
+            hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
+            if ((e = launch_voc_verify_pairs(pairs_dev, (uint32_t)succ.size(), vd.state_stride, vd.nmcp - 1, verify_tol,
+                                             bad_dev, nbad_dev, stream_voc)) != hipSuccess)
+                return hip_fail(e, "k_voc_verify_pairs(successors)");
+            std::vector<uint8_t> bad3(succ.size());
+            if ((e = hipMemcpyAsync(bad3.data(), bad_dev, succ.size(), hipMemcpyDeviceToHost, stream_voc)) !=
+                    hipSuccess ||
+                (e = hipStreamSynchronize(stream_voc)) != hipSuccess)
+                return hip_fail(e, "hipMemcpy(bad3)");
+            for (size_t q = 0; q < succ.size(); q++)
+                if (bad3[q]) {
+                    pending[succ[q]] = 1;
+                    n_redo++;
+                    n_recert_failed++;
+                }
+        }
     }
     return JB_OK;
 }
 
 int Batch::sync()
 {
-    hipError_t e = hipStreamSynchronize(stream_voc);
+    hipError_t e = hipSetDevice(device); // the redo rounds of finish_verify launch kernels
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(stream_voc);
     if (e == hipSuccess && stream_voc != stream)
         e = hipStreamSynchronize(stream);
     if (e != hipSuccess)
@@ -1254,11 +1308,15 @@ int Batch::sync()
     return finish_verify();
 }
 
-int Batch::read(const void *dev, void *dst, size_t bytes)
+// Every read entry waits for the batch's own streams first (they are non-blocking streams: a plain
+// hipMemcpy does not order behind them) and lets the hand-off certification finish, so that what
+// is read is the certified result.  Cheap when nothing is pending.
+int Batch::read(const void *dev, void *dst, size_t bytes, bool do_sync)
 {
-    hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess)
-        e = hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost);
+    int rc = do_sync ? sync() : JB_OK;
+    if (rc)
+        return rc;
+    hipError_t e = hipMemcpy(dst, dev, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
         return hip_fail(e, "hipMemcpy(D2H)");
     return JB_OK;
@@ -1316,12 +1374,12 @@ int Batch::read_pcm_split(void *const *dst, size_t elem)
     const size_t total = total_samples * elem;
     if (total == 0)
         return JB_OK;
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess)
-        return hip_fail(e, "hipSetDevice");
-    StageRing *ring = nullptr;
-    int rc = stage_ring(device, &ring);
+    int rc = sync();
     if (rc)
+        return rc;
+    hipError_t e = hipSuccess;
+    StageRing *ring = nullptr;
+    if ((rc = stage_ring(device, &ring)))
         return rc;
     std::lock_guard<std::mutex> lk(ring->mu);
     // byte offset of every utterance in the slab (utterances are contiguous, in batch order)
@@ -1560,6 +1618,8 @@ void *jb_batch_device_pcm(jb_batch *hb, size_t *n)
         return nullptr;
     if (n)
         *n = b->total_samples;
+    if (b->sync()) // the slab is handed out finished and certified
+        return nullptr;
     return b->vd.pcm ? (void *)b->vd.pcm : (void *)b->vd.pcm16; // i16 slab for JB_BATCH_PCM_I16 batches
 }
 
@@ -1603,6 +1663,22 @@ int jb_batch_read_pcm_i16(jb_batch *hb, size_t i, int16_t *dst, size_t cap)
     if (!dst)
         return JB_ERR_INVALID;
     return b->read(b->vd.pcm16 + (size_t)b->frame_off[i] * b->voice.fperiod, dst, ns * sizeof(int16_t));
+}
+
+int jb_batch_read_pcm_all(jb_batch *hb, double *const *dst)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || (b->B && !dst))
+        return JB_ERR_INVALID;
+    return b->read_pcm_split((void *const *)dst, sizeof(double));
+}
+
+int jb_batch_read_pcm_i16_all(jb_batch *hb, int16_t *const *dst)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || (b->B && !dst))
+        return JB_ERR_INVALID;
+    return b->read_pcm_split((void *const *)dst, sizeof(int16_t));
 }
 
 int jb_batch_read_track(jb_batch *hb, size_t i, uint32_t si, double *dst, size_t cap)

@@ -192,7 +192,8 @@ hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork
                              const uint32_t *order_dev, uint32_t n_items, hipStream_t stream);
 // compares save_warm of item i with save_end of item i-1 (same utterance): bad[i]=1 and
 // ++*n_bad when max|diff| > tol * max|state|
-hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, double tol,
+// (carried-state slots only: ntaps = nmcp - 1 live taps, see voc_state_differs)
+hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, int ntaps, double tol,
                              uint8_t *bad, uint32_t *n_bad, hipStream_t stream);
 int vocoder_state_doubles(int nmcp);
 // bad[j] = 1 (and ++*n_bad) when states pairs[2j] and pairs[2j+1] differ by more than tol * max|state|

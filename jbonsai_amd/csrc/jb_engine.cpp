@@ -799,9 +799,11 @@ int jb_write_wav_f64(const char *path, const double *pcm, size_t n, uint32_t fs)
     return write_wav(path, q.data(), n, fs);
 }
 
+} // extern "C"
+
 // elem = 8: f64 PCM (Engine::synthesize's Vec<f64>); elem = 2: the fused 16-bit sink
-static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, const size_t *line_off,
-                                 size_t n_utts, int32_t device, size_t elem, void **pcm, size_t *n_samples)
+int jb::synthesize_batch_impl(const jb_engine *e, const char *const *lines, const size_t *line_off, size_t n_utts,
+                              int32_t device, size_t elem, void **pcm, size_t *n_samples, unsigned host_threads)
 {
     if (!e || !pcm || !n_samples || (n_utts && !line_off))
         return JB_ERR_INVALID;
@@ -826,6 +828,8 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
     // utterance and thread against ~0.7 ms of GPU time.
     unsigned nt = std::thread::hardware_concurrency();
     nt = nt ? std::min(nt, 16u) : 1u;
+    if (host_threads) // a multi-device call shares the host cores between its device threads
+        nt = host_threads;
     if (const char *ev = getenv("JB_HOST_THREADS"))
         nt = (unsigned)std::max(1, atoi(ev));
     // device-side gather + blend unless JB_HOST_BLEND=1 (A/B: both produce the same bits)
@@ -1042,16 +1046,18 @@ static int synthesize_batch_impl(const jb_engine *e, const char *const *lines, c
     return JB_OK;
 }
 
+extern "C" {
+
 int jb_synthesize_batch(const jb_engine *e, const char *const *lines, const size_t *line_off,
                         size_t n_utts, int32_t device, double **pcm, size_t *n_samples)
 {
-    return synthesize_batch_impl(e, lines, line_off, n_utts, device, sizeof(double), (void **)pcm, n_samples);
+    return jb::synthesize_batch_impl(e, lines, line_off, n_utts, device, sizeof(double), (void **)pcm, n_samples);
 }
 
 int jb_synthesize_batch_i16(const jb_engine *e, const char *const *lines, const size_t *line_off,
                             size_t n_utts, int32_t device, int16_t **pcm, size_t *n_samples)
 {
-    return synthesize_batch_impl(e, lines, line_off, n_utts, device, sizeof(int16_t), (void **)pcm, n_samples);
+    return jb::synthesize_batch_impl(e, lines, line_off, n_utts, device, sizeof(int16_t), (void **)pcm, n_samples);
 }
 
 void jb_pcm_i16_free(int16_t *p) { free(p); }
@@ -1120,7 +1126,7 @@ long jb_generator_step(jb_generator *hg, double *buf, size_t buf_len)
     int rc = b->sync();
     if (rc)
         return rc;
-    if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, buf, g->fperiod * sizeof(double))))
+    if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, buf, g->fperiod * sizeof(double), false)))
         return rc;
     g->next++;
     return (long)g->fperiod;

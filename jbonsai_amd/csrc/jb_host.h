@@ -15,8 +15,20 @@ namespace jb {
 extern thread_local std::string g_err;
 void set_error(const std::string &s);
 int hip_fail(hipError_t e, const char *what);
-int noise_table(int device, size_t need, const double **ptr, size_t *len);
+// Device copy of the shared Gaussian noise stream; a Batch keeps the table it was created with alive
+struct NoiseDev {
+    int device = -1;
+    double *ptr = nullptr;
+    size_t len = 0;
+    ~NoiseDev();
+};
+int noise_table(int device, size_t need, std::shared_ptr<NoiseDev> *out);
 void release_cached_memory(); // empties the per-device pools of finished batches' memory
+// jb_synthesize_batch[_i16] on one device (jb_engine.cpp); host_threads = 0: default front-half thread count
+int synthesize_batch_impl(const jb_engine *e, const char *const *lines, const size_t *line_off, size_t n_utts,
+                          int32_t device, size_t elem, void **pcm, size_t *n_samples, unsigned host_threads = 0);
+// static LPT partition (jb_multi.cpp): part_of[i] = bin of item i
+void lpt_partition(const uint64_t *weights, size_t n, size_t n_parts, uint32_t *part_of);
 
 // Device-resident pdf tables of a voice set (jb_pdf_set) and an indexed batch source
 struct PdfSet {
@@ -52,6 +64,7 @@ struct Batch {
     BatchDev bd{};
     StreamDev sd[kMaxStream]{};
     VocDev vd{};
+    std::shared_ptr<NoiseDev> noise;         // vd.noise points into it
     // vocoder work items
     std::vector<VocWork> work;       // host copy
     VocWork *work_dev = nullptr;
@@ -61,6 +74,7 @@ struct Batch {
     double *ckpt_state = nullptr, *tmp_state = nullptr; // partial redo: checkpoints / recomputed states
     const double **pairs_dev = nullptr;
     uint32_t n_redo_partial = 0, n_redo_full = 0;   // of the last run: settled at the checkpoint / redone to the end
+    uint32_t n_recert_failed = 0;                   // successors of fully redone chunks that failed re-certification
     size_t state_stride = 0;
     uint8_t *bad_dev = nullptr;
     uint32_t *nbad_dev = nullptr;
@@ -93,7 +107,7 @@ struct Batch {
     int finish_verify();
     int run(bool timed);
     int sync();
-    int read(const void *dev, void *dst, size_t bytes);
+    int read(const void *dev, void *dst, size_t bytes, bool do_sync = true); // do_sync: wait for the batch's streams + certification first
     // whole PCM slab -> one host buffer per utterance (dst[u] may be null for empty utterances);
     // elem = 8 (f64) or 2 (JB_BATCH_PCM_I16)
     int read_pcm_split(void *const *dst, size_t elem);

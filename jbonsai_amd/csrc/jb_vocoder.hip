@@ -1452,62 +1452,19 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
 // Certification of time-chunked execution: a chunk that started from zero state
 // W frames early must have reached the same filter state as its predecessor's end
 // state.  One wave per item; the excitation ring is feed-forward and not compared.
-__global__ __launch_bounds__(64) void k_voc_verify(const VocWork *__restrict__ work, uint32_t n_items,
-                                                    int nfilt /* doubles to compare */, double tol,
-                                                    uint8_t *bad, uint32_t *n_bad)
+//
+// The two dumps of a comparison may come from different kernels (first pass: throughput kernel;
+// redo: wave kernel).  They agree on everything that is carried state; the wave kernel also
+// leaves values in slots that are not: the u row holds per-lane temporaries except at the head
+// lane of each 12-lane stage segment, and the tap slots past the last tap (12 groups x TPL
+// slots for ntaps taps) and of lanes 60..63 carry the remainder through.  Those are skipped in
+// EVERY comparison (a redo overwrites an end-state dump of the first pass in place, and the
+// dump is compared again on the next run of the same batch).
+__device__ __forceinline__ bool voc_state_differs(const double *__restrict__ a, const double *__restrict__ r,
+                                                  int nfilt, int ntaps, double tol, int lane, double *md_out,
+                                                  double *mr_out)
 {
-    const uint32_t i = blockIdx.x;
-    if (i >= n_items)
-        return;
-    const VocWork wk = work[i];
-    const int lane = threadIdx.x;
-    if (!wk.save_warm || i == 0) {
-        if (lane == 0)
-            bad[i] = 0;
-        return;
-    }
-    const double *a = wk.save_warm, *r = work[i - 1].save_end;
     double md = 0.0, mr = 0.0;
-    for (int k = lane; k < nfilt; k += 64) {
-        const double x = a[k], y = r[k];
-        md = fmax(md, fabs(x - y));
-        mr = fmax(mr, fabs(y));
-        if (!(x == x) || !(y == y))
-            md = 1e300; // NaN anywhere => redo
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        md = fmax(md, __shfl_xor(md, o));
-        mr = fmax(mr, __shfl_xor(mr, o));
-    }
-    if (lane == 0) {
-        const bool isbad = md > tol * mr && md > 1e-300;
-        bad[i] = isbad;
-        if (isbad)
-            atomicAdd(n_bad, 1u);
-#ifdef JB_VERIFY_DEBUG
-        if (isbad)
-            printf("handoff item %u utt %u t_out %u: max|diff| %.3e max|state| %.3e ratio %.3e\n", i, wk.utt,
-                   wk.t_out, md, mr, md / mr);
-#endif
-    }
-}
-
-// same comparison for explicit pairs of states (partial redo: recomputed state vs checkpoint)
-__global__ __launch_bounds__(64) void k_voc_verify_pairs(const double *const *__restrict__ pairs, uint32_t n_pairs,
-                                                          int nfilt, int ntaps, double tol, uint8_t *bad,
-                                                          uint32_t *n_bad)
-{
-    const uint32_t i = blockIdx.x;
-    if (i >= n_pairs)
-        return;
-    const int lane = threadIdx.x;
-    const double *a = pairs[2 * i], *r = pairs[2 * i + 1];
-    double md = 0.0, mr = 0.0;
-    // The two dumps may come from different kernels (checkpoint: throughput kernel, recomputed
-    // state: wave kernel).  They agree on everything that is carried state; the wave kernel also
-    // leaves values in slots that are not: the u row holds per-lane temporaries except at the head
-    // lane of each 12-lane stage segment, and the tap slots past the last tap (12 groups x TPL
-    // slots for ntaps taps) and of lanes 60..63 carry the remainder through.  Those are skipped.
     const int urow = nfilt - 76; // 64*TPL: start of the u row (layout: d[TPL][64] | u[64] | e11[6] | e12[6])
     const int tpl = urow / 64;
     for (int k = lane; k < nfilt; k += 64) {
@@ -1522,19 +1479,63 @@ __global__ __launch_bounds__(64) void k_voc_verify_pairs(const double *const *__
         md = fmax(md, fabs(x - y));
         mr = fmax(mr, fabs(y));
         if (!(x == x) || !(y == y))
-            md = 1e300;
+            md = 1e300; // NaN anywhere => redo
     }
     for (int o = 32; o > 0; o >>= 1) {
         md = fmax(md, __shfl_xor(md, o));
         mr = fmax(mr, __shfl_xor(mr, o));
     }
+    *md_out = md;
+    *mr_out = mr;
+    return md > tol * mr && md > 1e-300;
+}
+
+__global__ __launch_bounds__(64) void k_voc_verify(const VocWork *__restrict__ work, uint32_t n_items,
+                                                    int nfilt /* doubles to compare */, int ntaps, double tol,
+                                                    uint8_t *bad, uint32_t *n_bad)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= n_items)
+        return;
+    const VocWork wk = work[i];
+    const int lane = threadIdx.x;
+    if (!wk.save_warm || i == 0) {
+        if (lane == 0)
+            bad[i] = 0;
+        return;
+    }
+    double md, mr;
+    const bool isbad = voc_state_differs(wk.save_warm, work[i - 1].save_end, nfilt, ntaps, tol, lane, &md, &mr);
     if (lane == 0) {
-        const bool isbad = md > tol * mr && md > 1e-300;
         bad[i] = isbad;
         if (isbad)
             atomicAdd(n_bad, 1u);
 #ifdef JB_VERIFY_DEBUG
-        printf("checkpoint pair %u: max|diff| %.3e max|state| %.3e %s\n", i, md, mr, isbad ? "FAIL" : "ok");
+        if (isbad)
+            printf("handoff item %u utt %u t_out %u: max|diff| %.3e max|state| %.3e ratio %.3e\n", i, wk.utt,
+                   wk.t_out, md, mr, md / mr);
+#endif
+    }
+}
+
+// same comparison for explicit pairs of states (partial redo: recomputed state vs checkpoint;
+// re-certification of a successor against the exact end state of a fully redone chunk)
+__global__ __launch_bounds__(64) void k_voc_verify_pairs(const double *const *__restrict__ pairs, uint32_t n_pairs,
+                                                          int nfilt, int ntaps, double tol, uint8_t *bad,
+                                                          uint32_t *n_bad)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= n_pairs)
+        return;
+    const int lane = threadIdx.x;
+    double md, mr;
+    const bool isbad = voc_state_differs(pairs[2 * i], pairs[2 * i + 1], nfilt, ntaps, tol, lane, &md, &mr);
+    if (lane == 0) {
+        bad[i] = isbad;
+        if (isbad)
+            atomicAdd(n_bad, 1u);
+#ifdef JB_VERIFY_DEBUG
+        printf("state pair %u: max|diff| %.3e max|state| %.3e %s\n", i, md, mr, isbad ? "FAIL" : "ok");
 #endif
     }
 }
@@ -1634,13 +1635,13 @@ hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream
     return hipGetLastError();
 }
 
-hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, double tol,
+hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, int ntaps, double tol,
                              uint8_t *bad, uint32_t *n_bad, hipStream_t stream)
 {
     if (n_items == 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_voc_verify, dim3(n_items), dim3(64), 0, stream, work_dev, n_items,
-                       state_doubles - 4, tol, bad, n_bad);
+                       state_doubles - 4, ntaps, tol, bad, n_bad);
     return hipGetLastError();
 }
 

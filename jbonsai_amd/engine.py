@@ -56,6 +56,10 @@ def _bind(L):
     L.jb_synthesize_batch.argtypes = [vp, cpp, C.POINTER(sz), sz, C.c_int32, C.POINTER(dp), C.POINTER(sz)]
     L.jb_synthesize_batch_i16.argtypes = [vp, cpp, C.POINTER(sz), sz, C.c_int32,
                                           C.POINTER(C.POINTER(C.c_int16)), C.POINTER(sz)]
+    L.jb_synthesize_batch_multi.argtypes = [vp, cpp, C.POINTER(sz), sz, C.POINTER(C.c_int32), sz, C.POINTER(dp),
+                                            C.POINTER(sz)]
+    L.jb_synthesize_batch_i16_multi.argtypes = [vp, cpp, C.POINTER(sz), sz, C.POINTER(C.c_int32), sz,
+                                                C.POINTER(C.POINTER(C.c_int16)), C.POINTER(sz)]
     L.jb_pcm_i16_free.argtypes = [C.POINTER(C.c_int16)]
     L.jb_pcm_i16_free.restype = None
     L.jb_engine_states.argtypes = [vp, cpp, sz, C.POINTER(vp)]
@@ -242,9 +246,11 @@ class Engine:
                 self._L.jb_pcm_free(pcm)
 
     def synthesize_batch(self, utterances: Sequence[Sequence[str]], device: int = -1,
-                         i16: bool = False) -> List[np.ndarray]:
-        """jb_synthesize_batch / jb_synthesize_batch_i16.  The arrays view the library-owned buffers
-        (no copy); each is released with jb_pcm_free / jb_pcm_i16_free when its array dies."""
+                         i16: bool = False, devices: Sequence[int] = None) -> List[np.ndarray]:
+        """jb_synthesize_batch / jb_synthesize_batch_i16 (or, with `devices`, their _multi forms: the
+        utterances are LPT-split over the listed GPUs, one host thread per device).  The arrays view
+        the library-owned buffers (no copy); each is released with jb_pcm_free / jb_pcm_i16_free when
+        its array dies."""
         flat = [l for u in utterances for l in u]
         off = np.cumsum([0] + [len(u) for u in utterances]).astype(np.uint64)
         B = len(utterances)
@@ -252,9 +258,14 @@ class Engine:
         ety = C.c_int16 if i16 else C.c_double
         pcm = (C.POINTER(ety) * max(1, B))()
         ns = (C.c_size_t * max(1, B))()
-        fn = self._L.jb_synthesize_batch_i16 if i16 else self._L.jb_synthesize_batch
         free = self._L.jb_pcm_i16_free if i16 else self._L.jb_pcm_free
-        F.check(fn(self._h, _lines(flat), offs, B, device, pcm, ns))
+        if devices is not None:
+            fn = self._L.jb_synthesize_batch_i16_multi if i16 else self._L.jb_synthesize_batch_multi
+            dv = (C.c_int32 * max(1, len(devices)))(*[int(d) for d in devices])
+            F.check(fn(self._h, _lines(flat), offs, B, dv, len(devices), pcm, ns))
+        else:
+            fn = self._L.jb_synthesize_batch_i16 if i16 else self._L.jb_synthesize_batch
+            F.check(fn(self._h, _lines(flat), offs, B, device, pcm, ns))
         out = []
         for i in range(B):
             if not ns[i]:

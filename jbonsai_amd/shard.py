@@ -25,6 +25,24 @@ def lpt_partition(lengths: Sequence[int], n_parts: int) -> List[List[int]]:
     return parts
 
 
+def lpt_partition_native(lengths: Sequence[int], n_parts: int) -> List[List[int]]:
+    """The same partition from the library (jb_lpt_partition, the rule the multi-device entries
+    jb_synthesize_batch_multi / jb_paramgen_vocode_batch_multi split by); needs no GPU."""
+    import ctypes as C
+
+    from . import _ffi as F
+
+    n = len(lengths)
+    w = (C.c_uint64 * max(1, n))(*[int(x) for x in lengths])
+    part = (C.c_uint32 * max(1, n))()
+    F.check(F.lib().jb_lpt_partition(w, n, n_parts, part))
+    parts: List[List[int]] = [[] for _ in range(n_parts)]
+    # bins list their items heaviest first, as lpt_partition does
+    for i in sorted(range(n), key=lambda i: (-int(lengths[i]), i)):
+        parts[part[i]].append(i)
+    return parts
+
+
 def shard_for_rank(lengths: Sequence[int], rank: int, world: int) -> List[int]:
     return lpt_partition(lengths, world)[rank]
 

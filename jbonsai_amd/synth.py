@@ -11,7 +11,7 @@ from typing import List
 
 import numpy as np
 
-from .batch import StreamStates, Utterance
+from .batch import IndexStreamStates, IndexUtterance, PdfSet, StreamStates, Utterance
 from .engine import Engine
 
 MASK = (1 << 64) - 1
@@ -51,14 +51,25 @@ class VoiceTables:
                 self.gv.append(eng.pdf_table(4 + s, 0))
             else:
                 self.gv.append(None)
+        # all trees of a stream concatenated (the layout of jb_pdf_table) and each tree's first row
+        self.concat = [np.concatenate(t, axis=0) for t in self.stream]
+        self.tree_off = [np.cumsum([0] + [len(x) for x in t[:-1]]) for t in self.stream]
+
+    def pdf_set(self, device: int = -1) -> PdfSet:
+        """The voice's stream tables resident on `device` (for indexed batches)."""
+        return PdfSet([self.concat], device=device)
 
 
-def synth_utterance(tab: VoiceTables, target_frames: int, utt_id: int = 0) -> Utterance:
+def synth_utterance(tab: VoiceTables, target_frames: int, utt_id: int = 0, indexed: bool = False):
+    """indexed=False: state-level Utterance (per-state Gaussians expanded on the host);
+    indexed=True: the SAME utterance as pdf row indices (IndexUtterance) for a batch created over
+    VoiceTables.pdf_set() -- 12 bytes per state cross PCIe instead of 2.2 kB."""
     rng = SplitMix64(SEED ^ utt_id)
     ns = tab.nstate
     nstream = len(tab.stream)
     durs: List[int] = []
     rows = [[] for _ in range(nstream)]
+    ridx = [[] for _ in range(nstream)]
     total = 0
     while total < target_frames:
         dp = tab.dur[rng.below(len(tab.dur))]
@@ -73,8 +84,11 @@ def synth_utterance(tab: VoiceTables, target_frames: int, utt_id: int = 0) -> Ut
             durs.append(d)
             total += d
             for s in range(nstream):
-                tbl = tab.stream[s][min(k, len(tab.stream[s]) - 1)]
-                rows[s].append(tbl[leaf[s][k]])
+                tk = min(k, len(tab.stream[s]) - 1)
+                if indexed:
+                    ridx[s].append(int(tab.tree_off[s][tk]) + leaf[s][k])
+                else:
+                    rows[s].append(tab.stream[s][tk][leaf[s][k]])
             if total >= target_frames:
                 break
     S = len(durs)
@@ -83,6 +97,16 @@ def synth_utterance(tab: VoiceTables, target_frames: int, utt_id: int = 0) -> Ut
     sw[:ns] = 0                      # first / last phone behave like silence: GV off
     sw[(nphone - 1) * ns:] = 0
     streams = []
+    if indexed:
+        one = np.ones(1)
+        for s in range(nstream):
+            si = tab.vi.streams[s]
+            gm = gv = gs = None
+            if si.use_gv:
+                g = tab.gv[s][0].astype(np.float64)
+                gm, gv, gs = g[:si.vector_length], g[si.vector_length:], sw
+            streams.append(IndexStreamStates([np.asarray(ridx[s], dtype=np.uint32)], one, gm, gv, gs, 1.0, 0.5))
+        return IndexUtterance(np.asarray(durs, dtype=np.uint32), streams)
     for s in range(nstream):
         si = tab.vi.streams[s]
         WL = si.vector_length * len(si.windows)

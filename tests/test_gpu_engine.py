@@ -1,7 +1,8 @@
 """Engine-level drop-in tests on the GPU, written after the reference's own
 end-to-end tests (src/lib.rs:38-160): same labels, same golden samples.  The
 reference asserts abs 1e-10 in f64 on the CPU; the HIP path re-associates sums
-(DPP scans), so the gate here is abs 1e-6 on O(1e3) samples (relative ~1e-9)."""
+(DPP scans, FMAs), so the gate here is abs 1e-8 on O(1e3) samples (relative ~1e-11;
+observed ~2e-11 absolute)."""
 import numpy as np
 import pytest
 
@@ -11,7 +12,7 @@ from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
 from tests.helpers import rel_rms
 
 pytestmark = pytest.mark.gpu
-EPS = 1e-6
+EPS = 1e-8
 
 
 @pytest.fixture(scope="module")

@@ -1,7 +1,12 @@
-"""N>1 path on CPU: the LPT utterance partition and the rendezvous / max-over-ranks
-plumbing bench.py uses, with world_size-2 gloo (no GPU)."""
+"""N>1 path on CPU: the LPT utterance partition (Python rule and the library's jb_lpt_partition,
+which the multi-device entries split by), the rendezvous / max-over-ranks plumbing, and bench.py's
+own launcher + rank code with world_size 2 over gloo (no GPU)."""
+import json
 import os
 import socket
+import subprocess
+import sys
+from pathlib import Path
 
 import pytest
 import torch
@@ -24,6 +29,43 @@ def test_lpt_partition_properties():
     assert shard.lpt_partition([5], 2) == [[0], []]
     with pytest.raises(ValueError):
         shard.lpt_partition([1], 0)
+
+
+def test_native_lpt_equals_python_rule():
+    """jb_lpt_partition (jb_multi.cpp: what jb_synthesize_batch_multi / jb_paramgen_vocode_batch_multi
+    split by) and shard.lpt_partition (what bench.py's ranks split by) are the same rule."""
+    lens = synth.mixed_lengths(4096)
+    for world in (1, 2, 3, 8):
+        assert shard.lpt_partition_native(lens, world) == shard.lpt_partition(lens, world)
+    ties = [7, 7, 7, 3, 3, 9, 0, 0, 7]
+    for world in (1, 2, 4, 16):
+        assert shard.lpt_partition_native(ties, world) == shard.lpt_partition(ties, world)
+    assert shard.lpt_partition_native([], 3) == [[], [], []]
+    import jbonsai_amd as J
+    with pytest.raises(J.JbError):
+        shard.lpt_partition_native([1], 0)
+
+
+def test_bench_launcher_spawns_ranks_and_plans_config3():
+    """`bench.py --gpus 2` with no torchrun environment spawns its two ranks itself; in dry-run mode
+    (no GPU) the ranks rendezvous over gloo, build their LPT shares of the config-3 job (pdf row
+    indices, sub-batches), exchange per-rank records and run the variable-length gather."""
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["JB_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--utts", "96"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["gather_ms"] is not None
+    plan = d["config3_plan"]
+    lens = synth.mixed_lengths(96)
+    assert sum(plan["per_rank_frames"]) == sum(lens)
+    assert plan["per_rank_frames"] == [sum(lens[i] for i in p) for p in shard.lpt_partition(lens, 2)]
+    assert plan["imbalance_max_over_mean_frames"] < 1.05 and plan["scaling"] == "strong"
+    assert "error" not in plan
 
 
 def _free_port():
