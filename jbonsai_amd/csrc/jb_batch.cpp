@@ -790,6 +790,19 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                 if ((rc = b->dalloc(&sd.gv_part, 7 * nbl * (size_t)sd.gv_ntile * 4, false)) ||
                     (rc = b->dalloc(&sd.gv_scal, 6 * nbl * 4, false)))
                     return rc;
+                // resident GV (one persistent launch, jb_gv_gang.hip) unless JB_GV_GANG=0 or the CUs are
+                // partitioned (its grid is sized for the whole device)
+                static const bool gang_off = getenv("JB_GV_GANG") && atoi(getenv("JB_GV_GANG")) == 0;
+                int tiles = 0, gangs = 0;
+                if (!gang_off && !b->cu_split && maxT > 0 &&
+                    gv_gang_plan(dev, maxT, (uint32_t)nbl, &tiles, &gangs)) {
+                    uint8_t *ctl;
+                    if ((rc = b->dalloc(&ctl, gv_gang_ctl_bytes(gangs), true)))
+                        return rc;
+                    sd.gv_gang_ctl = ctl;
+                    sd.gv_gang_n = gangs;
+                    sd.gv_gang_tiles = tiles;
+                }
             }
         }
         if ((rc = b->dalloc(&sd.out, nfl, false)))
@@ -1061,10 +1074,18 @@ static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
             return e;
     }
     hipEventRecord(b->ev_lpf, b->stream_lpf);
-    hipStreamWaitEvent(stream, b->ev_prep, 0); // voiced flags (LF0 state walk)
-    hipStreamWaitEvent(stream, b->ev_lpf, 0);  // LPF track
-    e = launch_excite_noise(b->bd, b->vd, stream);
-    hipEventRecord(b->ev_build, stream); // "pulse-free excitation done"
+    // The pulse-free excitation pass goes onto the main stream between band solve and GV.  Beside
+    // either it stretches both by more than its own time -- the phase is throughput bound as a whole:
+    // with the resident GV kernel, 12.9 + 16.3 ms side by side against 6.2 + 9.1 ms one after the
+    // other, step 103.3 against 101.5 ms (JB_EXCITE_SIDE=1 puts it on the LPF stream, A/B aid).
+    static const bool side_env = getenv("JB_EXCITE_SIDE") && atoi(getenv("JB_EXCITE_SIDE")) != 0;
+    const bool side = side_env && b->stream_lpf != stream;
+    hipStream_t es = side ? b->stream_lpf : stream;
+    hipStreamWaitEvent(es, b->ev_prep, 0); // voiced flags (LF0 state walk)
+    if (!side)
+        hipStreamWaitEvent(es, b->ev_lpf, 0); // LPF track
+    e = launch_excite_noise(b->bd, b->vd, es);
+    hipEventRecord(b->ev_build, es); // "pulse-free excitation done"
     return e;
 }
 
@@ -1308,6 +1329,18 @@ int Batch::sync()
         e = hipStreamSynchronize(stream);
     if (e != hipSuccess)
         return hip_fail(e, "stream sync");
+    for (int si = 0; si < kMaxStream; si++)
+        if (sd[si].gv_gang_ctl) {
+            // the persistent GV kernel bounds its spins; an overrun is reported, never waited out
+            uint32_t err = 0;
+            if ((e = hipMemcpy(&err, &((const GvGangCtl *)sd[si].gv_gang_ctl)->err, sizeof err, hipMemcpyDeviceToHost)) !=
+                hipSuccess)
+                return hip_fail(e, "hipMemcpy(gv gang err)");
+            if (err) {
+                set_error("k_mlpg_gv_gang: an exchange between the workgroups of a gang timed out");
+                return JB_ERR_DEVICE;
+            }
+        }
     return finish_verify();
 }
 

@@ -60,6 +60,10 @@ struct StreamDev {
     double *gv_part;          // [7 passes][B][L][gv_ntile][4]
     double *gv_scal;          // [6][B][L][4] = {mean, step, obj, -}
     uint32_t gv_ntile;
+    // resident GV (k_mlpg_gv_gang): control block + gang records (device), gangs and tiles per gang of
+    // this batch; null = the multi-launch sweeps (k_mlpg_gv_tp)
+    void *gv_gang_ctl;
+    int gv_gang_n, gv_gang_tiles;
     // ---- per-state scratch written by k_prep_states (concatenated states) ----
     uint32_t *s_start;  // [sumS] first frame of state
     uint32_t *s_vpre;   // [sumS] voiced frames before state (compaction offset)
@@ -83,6 +87,20 @@ struct StreamDev {
     double *g;          // forward-substitution result / GV gradient
     double *par;        // compacted solution
     double *out;        // [sumT][L] scattered parameter track (NODATA in unvoiced frames)
+};
+
+// Control block of one launch of k_mlpg_gv_gang (zeroed before the launch) and per-gang records.
+constexpr int kGvGangMaxTiles = 32; // workgroups per gang: rows of up to 32 x 3,904 frames
+struct GvGangCtl {
+    uint32_t tickets;  // next workgroup to start -> (gang, tile)
+    uint32_t next_row; // row queue: (utterance, dim) rows in launch order
+    uint32_t err;      // a bounded spin ran out
+    uint32_t pad[29];
+};
+struct GvGang {
+    uint32_t cnt; // arrivals: formation, then one per tile and exchange
+    uint32_t pad[31];
+    double rec[2][kGvGangMaxTiles][4]; // {S1, S2, H, next row} per tile, two alternating slots
 };
 
 struct VocDev {
@@ -164,6 +182,11 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index
 typedef hipError_t (*jb_enqueue_hook)(void *ctx, hipStream_t stream);
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream,
                        hipEvent_t after_build, jb_enqueue_hook between = nullptr, void *between_ctx = nullptr);
+// resident GV: plan (0 = not applicable: row too long for a gang, no device capacity), bytes of the
+// control block for n gangs, launch (memset of the control block + the persistent kernel)
+int gv_gang_plan(int device, uint32_t maxT, uint32_t n_rows, int *tiles_per_gang, int *n_gangs);
+size_t gv_gang_ctl_bytes(int n_gangs);
+hipError_t launch_gv_gang(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream);
 int mlpg_mt_max_dim();      // largest vector length served by the [dim][frame] fast path
 int mlpg_gv_tile_frames();  // frames per block of the time-parallel GV sweeps
 hipError_t launch_pitch(const BatchDev &bd, const VocDev &vd, hipStream_t stream);

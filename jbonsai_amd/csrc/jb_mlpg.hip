@@ -2118,7 +2118,12 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
                 return he;
             between = nullptr;
         }
-        if (tp) {
+        if (tp && sd.gv_gang_ctl) {
+            // resident form: one persistent launch, band matrix in registers (jb_gv_gang.hip)
+            hipError_t he = launch_gv_gang(bd, sd, si, stream);
+            if (he != hipSuccess)
+                return he;
+        } else if (tp) {
             // par -> g -> par -> ... : conv_gv + five iterations = six writes, result back in par
             dim3 gg(sd.gv_ntile, sd.L, bd.B), gb(kGvNT);
             hipLaunchKernelGGL(k_mlpg_gv_tp<0>, gg, gb, 0, stream, bd, sd, si, 0, sd.par, (double *)nullptr, 1);

@@ -316,14 +316,21 @@ def test_device_pcm_slab_as_torch_tensor(have_gpu):
 
 def test_cu_partition_gives_identical_pcm(oracle_voice, have_gpu):
     """jb_batch_opts.mlpg_cus_per_xcd: parameter generation and vocoder on disjoint CU sets
-    (masked streams, separate vocoder stream).  Scheduling only: the PCM must not change."""
+    (masked streams, separate vocoder stream).  Scheduling only: the PCM must not depend on the
+    split.  (A partitioned batch keeps the multi-launch GV sweeps -- the resident GV kernel sizes its
+    grid for the whole device -- whose sums have another fixed shape: against the unpartitioned
+    batch the PCM agrees to rounding, not bitwise.)"""
     v = oracle_voice
     d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
     d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
     utts = [to_utt(d2, s2), to_utt(d1, s1)] * 3
     ref, _ = _run(v, utts, chunk_frames=64, kernel="pair")
+    first = None
     for k in (8, 31):
         got, info = _run(v, utts, chunk_frames=64, kernel="pair", mlpg_cus_per_xcd=k)
         assert info["n_redo"] == 0
-        for a, b in zip(ref, got):
-            assert np.array_equal(a, b)
+        if first is None:
+            first = got
+        for a, b, c in zip(ref, got, first):
+            assert np.array_equal(b, c)
+            assert rel_rms(b, a) <= 1e-12

@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=gpurun_out/kstats
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats -d $out -o k --output-format csv -- python3 bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline "$@" > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
+rocprofv3 --kernel-trace --stats -d $out -o k --output-format csv -- python3 bench.py --steps ${STEPS:-2} --warmup 1 --no-cpu-baseline --no-extras "$@" > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
 tail -1 $out/bench.log | cut -c1-200
 python3 - $out ${STEPS:-2} <<'PY'
 import sys,glob,csv,collections

@@ -10,7 +10,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT" \
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace -d $out/p$i -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline $BENCH_ARGS > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; exit 1; }
+  rocprofv3 --pmc $set --kernel-trace -d $out/p$i -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras $BENCH_ARGS > $out/p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $out/p$i.log; exit 1; }
   python3 - "$out/p$i" "${KERNEL:-k_vocoder_l}" <<'PY'
 import sys,glob,csv,collections
 f=glob.glob(sys.argv[1]+"/**/*counter_collection.csv",recursive=True)

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 out=gpurun_out/traffic
 rm -rf $out; mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $out/$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/$c.log 2>&1 || { echo "$c pass failed"; tail -5 $out/$c.log; exit 1; }
+  rocprofv3 --pmc $c --kernel-trace -d $out/$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/$c.log 2>&1 || { echo "$c pass failed"; tail -5 $out/$c.log; exit 1; }
 done
 python3 - $out <<'PY'
 import sys, glob, csv, json, collections
