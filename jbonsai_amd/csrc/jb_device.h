@@ -95,7 +95,8 @@ struct GvGangCtl {
     uint32_t tickets;  // next workgroup to start -> (gang, tile)
     uint32_t next_row; // row queue: (utterance, dim) rows in launch order
     uint32_t err;      // a bounded spin ran out
-    uint32_t pad[29];
+    uint32_t pad[13];
+    unsigned long long prof[8]; // -DJB_GG_PROFILE: shader-clock ticks of thread 0 of every workgroup, by section
 };
 struct GvGang {
     uint32_t cnt; // arrivals: formation, then one per tile and exchange

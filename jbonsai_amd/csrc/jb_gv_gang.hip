@@ -16,7 +16,7 @@
 // and operations as their owner's copy, so they are bit-identical to it.
 //
 // Arithmetic: the reference's expressions in the reference's order (FP contraction off), as in
-// k_mlpg_gv_tp; the sums have a fixed shape (8 frames per lane ascending, xor butterfly over the
+// k_mlpg_gv_tp; the sums have a fixed shape (8 frames per lane ascending, DPP tree over the
 // wave, waves in order, tiles in order), so the result is deterministic and independent of which
 // gang took the row, but -- like k_mlpg_gv_tp's -- not the reference's serial order (~1e-15
 // relative; JB_BATCH_SERIAL_GV keeps the bit-exact kernel).
@@ -53,13 +53,32 @@ namespace jb {
                     // the kernels of the other chains beside it
 #endif
 #ifndef JB_GG_FENCE
-#define JB_GG_FENCE 1 // frames of a lane one after the other (the scheduler otherwise interleaves all eight
+#define JB_GG_FENCE 0 // 1: frames of a lane one after the other (the scheduler otherwise interleaves all eight
                       // and needs ~90 more VGPRs for their temporaries)
 #endif
 #if JB_GG_FENCE
 #define JB_GG_FRAME_FENCE __builtin_amdgcn_sched_barrier(0)
 #else
 #define JB_GG_FRAME_FENCE (void)0
+#endif
+#ifndef JB_GG_A0_LDS
+#define JB_GG_A0_LDS 0 // 1: A0 stays in a second LDS image per wave as well (16 VGPRs less)
+#endif
+#ifndef JB_GG_PROFILE
+#define JB_GG_PROFILE 0 // 1: thread 0 of every workgroup adds its shader-clock ticks per section to ctl->prof
+#endif
+#if JB_GG_PROFILE
+#define GG_T(k)                                                                                    \
+    do {                                                                                           \
+        const long long now_ = clock64();                                                          \
+        prof_[k] += now_ - tprev_;                                                                 \
+        tprev_ = now_;                                                                             \
+    } while (0)
+#else
+#define GG_T(k) (void)0
+#endif
+#ifndef JB_GG_KEEPG
+#define JB_GG_KEEPG (JB_GG_WPS <= 2) // band product kept in 16 VGPRs across the exchange instead of evaluated twice
 #endif
 #ifndef JB_GG_FPT
 #define JB_GG_FPT 8
@@ -84,6 +103,18 @@ template <int CTRL> __device__ __forceinline__ double gg_dpp(double v)
     lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+}
+// sum over the 64 lanes with DPP (row_shr 1/2/4/8, row_bcast 15, row_bcast 31): the total is in lane 63.
+// A fixed shape, like the xor butterfly it replaces, without its twelve LDS round trips per value.
+__device__ __forceinline__ double gg_wave_sum63(double v)
+{
+    v += gg_dpp<0x111>(v);
+    v += gg_dpp<0x112>(v);
+    v += gg_dpp<0x114>(v);
+    v += gg_dpp<0x118>(v);
+    v += gg_dpp<0x142>(v);
+    v += gg_dpp<0x143>(v);
+    return v;
 }
 constexpr int GG_WAVE_SHL1 = 0x130, GG_WAVE_SHR1 = 0x138; // lane i <- lane i+1 / lane i-1 (0 at the wave's end)
 
@@ -157,10 +188,14 @@ __device__ __forceinline__ double gg_recip(double d)
     return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
 }
 
-// LDS image of a wave window, 8 doubles + 2 of padding per lane so that both the coalesced side
-// (lane = frame) and the thread-contiguous side (8 frames per lane, ds_read_b128) spread over the banks
-__device__ __forceinline__ int gg_idx(int w) { return w + 2 * (w >> 3); }
-constexpr int kGgXs = kGgWin + 2 * 64; // doubles per wave image
+// LDS image of a wave window: 512 doubles, lane i's eight frames in row i (64 B) with the four 16-byte
+// granules of a row XOR-swizzled by (i >> 2) & 3, so that both the coalesced side (lane = frame,
+// ds_write_b64) and the thread-contiguous side (8 frames per lane, ds_read_b128: lanes i, i+4, i+8, i+12
+// of a 16-lane pass would otherwise share their four banks) spread over all banks without padding.
+static_assert(kGgFPT == 8, "the image layout is written for eight frames per lane");
+__device__ __forceinline__ int gg_gran(int row, int j) { return 4 * row + (j ^ ((row >> 2) & 3)); } // double2 index
+__device__ __forceinline__ int gg_idx(int w) { return 2 * gg_gran(w >> 3, (w >> 1) & 3) + (w & 1); }
+constexpr int kGgXs = kGgWin; // doubles per wave image
 
 __device__ __forceinline__ void gg_wave_sync()
 {
@@ -199,10 +234,10 @@ __device__ __forceinline__ void gg_turn(double (&r)[kGgFPT], double *xs, int lan
     for (int j = 0; j < kGgFPT; j++)
         xs[gg_idx(64 * j + lane)] = r[j];
     gg_wave_sync();
-    const double2 *q = reinterpret_cast<const double2 *>(xs + gg_idx(kGgFPT * lane));
+    const double2 *q = reinterpret_cast<const double2 *>(xs);
 #pragma unroll
     for (int j = 0; j < kGgFPT / 2; j++) {
-        const double2 d2 = q[j];
+        const double2 d2 = q[gg_gran(lane, j)];
         r[2 * j] = d2.x;
         r[2 * j + 1] = d2.y;
     }
@@ -212,7 +247,10 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
                                                             GvGang *gangs, int NTg, int n_gangs)
 {
     __shared__ double xs_all[kGgWaves][kGgXs];
-    __shared__ double red[kGgWaves][4];
+#if JB_GG_A0_LDS
+    __shared__ double ys_all[kGgWaves][kGgXs];
+#endif
+    __shared__ double red[2][kGgWaves][4]; // two slots: a wave may write the next phase's sums while wave 0 adds up
     __shared__ double recs[kGvGangMaxTiles][4];
     __shared__ int sh_i[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -266,15 +304,31 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
     // propagation plus one load round trip per exchange instead of store, wait, counter add, counter
     // poll, record loads.  Records alternate between two slots: a member can run at most one exchange
     // ahead of the slowest reader of the previous one (it needs that reader's record to go on).
+#if JB_GG_PROFILE
+    long long prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; // 0 row setup+load, 1 statistics, 2 block sum, 3 exchange, 4 step, 5 store
+    long long tprev_ = clock64();
+#endif
     uint32_t kbar = 0;
     bool dead = false;
-    auto exchange = [&](double v0, double v1, double v2, double v3) {
-        __syncthreads(); // every thread is done with the records of the previous exchange
+    // from_red: the first three values are the workgroup sums of block_sum (added up here, waves in order)
+    auto exchange = [&](bool from_red, double v0, double v1, double v2, double v3) {
+        __syncthreads(); // every thread is done with the records of the previous exchange; red[] is written
         if (wv == 0) {
             typedef unsigned long long u64;
             unsigned long long *slot = reinterpret_cast<unsigned long long *>(&G->rec[kbar & 1][0][0]);
             const u64 tagbase = 0x9E3779B97F4A7C15ull * (u64)(kbar + 1u);
             if (lane == 0) {
+                if (from_red) {
+                    v0 = red[kbar & 1][0][0];
+                    v1 = red[kbar & 1][0][1];
+                    v2 = red[kbar & 1][0][2];
+#pragma unroll
+                    for (int w = 1; w < kGgWaves; w++) {
+                        v0 += red[kbar & 1][w][0];
+                        v1 += red[kbar & 1][w][1];
+                        v2 += red[kbar & 1][w][2];
+                    }
+                }
                 const double v[4] = {v0, v1, v2, v3};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -346,31 +400,16 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         S2 = gg_uni(S2);
         H = gg_uni(H);
     };
-    // workgroup sums: xor butterfly inside each wave, then the waves in order; returns on thread 0
+    // workgroup sums: DPP sum inside each wave, the per-wave sums through LDS; wave 0 adds them
+    // in wave order at the head of the exchange (one barrier for both)
     auto block_sum = [&](double &a, double &b2, double &c) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            a += __shfl_xor(a, o);
-            b2 += __shfl_xor(b2, o);
-            c += __shfl_xor(c, o);
-        }
-        __syncthreads(); // red[] of the previous phase has been read
-        if (lane == 0) {
-            red[wv][0] = a;
-            red[wv][1] = b2;
-            red[wv][2] = c;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            a = red[0][0];
-            b2 = red[0][1];
-            c = red[0][2];
-#pragma unroll
-            for (int w = 1; w < kGgWaves; w++) {
-                a += red[w][0];
-                b2 += red[w][1];
-                c += red[w][2];
-            }
+        a = gg_wave_sum63(a);
+        b2 = gg_wave_sum63(b2);
+        c = gg_wave_sum63(c);
+        if (lane == 63) {
+            red[kbar & 1][wv][0] = a;
+            red[kbar & 1][wv][1] = b2;
+            red[kbar & 1][wv][2] = c;
         }
     };
 
@@ -378,32 +417,60 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
     double nxt = 0.0;
     if (tile == 0 && tid == 0)
         nxt = (double)atomicAdd(&ctl->next_row, 1u);
-    exchange(0.0, 0.0, 0.0, nxt);
+    exchange(false, 0.0, 0.0, 0.0, nxt);
     if (dead)
         return;
     uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs[0][3]);
 
-    while (row < total_rows) {
-        const int b = (int)bd.order[row / (uint32_t)sd.L], m = (int)(row % (uint32_t)sd.L);
+    // Everything a row needs from the descriptor tables (a chain of four dependent scalar loads: launch
+    // order -> utterance -> stream states -> GV pdf) is fetched one row ahead, while the current row's
+    // phases run, so that a row starts with its vector loads.
+    struct RowInfo {
+        uint32_t n, gvl;
+        int m;
+        bool live;
+        uint64_t rowoff, frame_off;
+        double gv_mean, gv_vari;
+    };
+    auto row_info = [&](uint32_t r) -> RowInfo {
+        RowInfo ri{};
+        if (r >= total_rows)
+            return ri;
+        const int b = (int)bd.order[r / (uint32_t)sd.L];
+        ri.m = (int)(r % (uint32_t)sd.L);
         const UttDev *up = bd.utt + b;
-        const uint32_t n = sd.Tv[b], gvl = sd.gvlen[b];
+        ri.n = sd.Tv[b];
+        ri.gvl = sd.gvlen[b];
         const StreamStatesDev st = up->st[si];
-        const bool live = st.gv_mean != nullptr && n > 0 && gvl > 0; // the same answer in every member
+        ri.live = st.gv_mean != nullptr && ri.n > 0 && ri.gvl > 0; // the same answer in every member
+        ri.frame_off = up->frame_off;
+        ri.rowoff = up->frame_off * (uint64_t)sd.L + (uint64_t)ri.m * (uint64_t)up->T;
+        if (ri.live) {
+            ri.gv_mean = st.gv_mean[ri.m] * st.gv_weight; // mlpg.rs:135-137
+            ri.gv_vari = st.gv_var[ri.m];
+        }
+        return ri;
+    };
+    RowInfo cur = row_info(row), ahead{};
+
+    while (row < total_rows) {
+        const uint32_t n = cur.n, gvl = cur.gvl;
         // the next row's number rides on this row's first exchange
         nxt = 0.0;
         if (tile == 0 && tid == 0)
             nxt = (double)atomicAdd(&ctl->next_row, 1u);
-        if (!live) {
-            exchange(0.0, 0.0, 0.0, nxt);
+        if (!cur.live) {
+            exchange(false, 0.0, 0.0, 0.0, nxt);
             if (dead)
                 return;
             row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs[0][3]);
+            cur = row_info(row);
             continue;
         }
-        const uint64_t rowoff = up->frame_off * (uint64_t)sd.L + (uint64_t)m * (uint64_t)up->T;
+        const uint64_t rowoff = cur.rowoff;
         const double *A0 = sd.A[0] + rowoff, *A1 = sd.A[1] + rowoff, *A2 = sd.A[2] + rowoff, *Bv = sd.bvec + rowoff;
         double *P = sd.par + rowoff;
-        const uint8_t *sw = sd.vsw + up->frame_off;
+        const uint8_t *sw = sd.vsw + cur.frame_off;
         // (frame indices are 32-bit: a row has < 2^31 frames.  The opaque copy of `lane` keeps the
         // compiler from hoisting every per-lane index and bounds test of the row out of the row loop
         // and then spilling them: they cost a few integer instructions per row)
@@ -419,7 +486,15 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         // wave's LDS image, where the load left it: 16 VGPRs less, which is what keeps the kernel from
         // spilling at four waves per SIMD
         double a0[kGgFPT], a1[kGgFPT], a2[kGgFPT], p[kGgFPT];
-        const double2 *bq = reinterpret_cast<const double2 *>(xs + gg_idx(kGgFPT * lane_v));
+        const double2 *bq2 = reinterpret_cast<const double2 *>(xs);
+#define GG_B(f) (((f)&1) ? bq2[gg_gran(lane_v, (f) >> 1)].y : bq2[gg_gran(lane_v, (f) >> 1)].x)
+#if JB_GG_A0_LDS
+        double *ys = ys_all[wv];
+        const double2 *aq2 = reinterpret_cast<const double2 *>(ys);
+#define GG_A0(f) (((f)&1) ? aq2[gg_gran(lane_v, (f) >> 1)].y : aq2[gg_gran(lane_v, (f) >> 1)].x)
+#else
+#define GG_A0(f) a0[f]
+#endif
         double a1m = 0.0, a2m = 0.0, a2mm = 0.0; // A1[t0-1], A2[t0-1], A2[t0-2]
         uint32_t onbits = 0, ownbits = 0;
         if (busy) {
@@ -432,14 +507,22 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
                 gg_fetch<true>(a2, A2, ws, n_i, lane_v);
                 gg_fetch<true>(p, P, ws, n_i, lane_v);
                 gg_fetch<true>(btmp, Bv, ws, n_i, lane_v);
+#if JB_GG_A0_LDS
+                gg_turn(a0, ys, lane_v);
+#else
                 gg_turn(a0, xs, lane_v);
+#endif
                 gg_turn(a1, xs, lane_v);
                 gg_turn(a2, xs, lane_v);
                 gg_turn(p, xs, lane_v);
             } else {
                 // window over an end of the row: clamped addresses (one per load), array by array
                 gg_fetch<false>(a0, A0, ws, n_i, lane_v);
+#if JB_GG_A0_LDS
+                gg_turn(a0, ys, lane_v);
+#else
                 gg_turn(a0, xs, lane_v);
+#endif
                 gg_fetch<false>(a1, A1, ws, n_i, lane_v);
                 gg_turn(a1, xs, lane_v);
                 gg_fetch<false>(a2, A2, ws, n_i, lane_v);
@@ -467,8 +550,8 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
             for (int f = 0; f < kGgFPT; f++)
                 a0[f] = a1[f] = a2[f] = p[f] = 0.0;
         }
-        const double gv_mean = st.gv_mean[m] * st.gv_weight; // mlpg.rs:135-137
-        const double gv_vari = st.gv_var[m];
+        GG_T(0);
+        const double gv_mean = cur.gv_mean, gv_vari = cur.gv_vari;
         const double glen = (double)gvl;
         const double wgt = 1.0 / (double)((uint64_t)sd.W * (uint64_t)n);
         const double length = (double)n;
@@ -488,46 +571,55 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
             const double pl2 = gg_dpp<GG_WAVE_SHR1>(p[kGgFPT - 2]), pl1 = gg_dpp<GG_WAVE_SHR1>(p[kGgFPT - 1]);
             const double pr1 = gg_dpp<GG_WAVE_SHL1>(p[0]), pr2 = gg_dpp<GG_WAVE_SHL1>(p[1]);
             double s1 = 0.0, s2 = 0.0, hh = 0.0;
+#if JB_GG_KEEPG
+            double g[kGgFPT];
+#endif
             if (busy) { // an idle wave of a short row only takes part in the exchanges
                 double o2 = pl2, o1 = pl1;
 #pragma unroll
                 for (int f = 0; f < kGgFPT; f++) {
                     const double pf = p[f];
-                    if (ownbits >> f & 1u) {
-                        if (onbits >> f & 1u) {
-                            const double dlt = pf - K;
-                            s1 += dlt;
-                            s2 += dlt * dlt;
-                        }
-                        if (it > 0) {
-                            // calc_hmmobj_derivative (mlpg.rs:205-229), the reference's order of additions;
-                            // operands outside [0, n) are zeros, which leaves the sum bit-identical
-                            const double pp1 = f + 1 < kGgFPT ? p[f + 1 < kGgFPT ? f + 1 : 0] : pr1;
-                            const double pp2 =
-                                f + 2 < kGgFPT ? p[f + 2 < kGgFPT ? f + 2 : 0] : (f + 2 == kGgFPT ? pr1 : pr2);
-                            const double am1 = f >= 1 ? a1[f >= 1 ? f - 1 : 0] : a1m;
-                            const double am2 = f >= 2 ? a2[f >= 2 ? f - 2 : 0] : (f == 1 ? a2m : a2mm);
-                            double gg = a0[f] * pf;
-                            gg += a1[f] * pp1;
-                            gg += am1 * o1;
-                            gg += a2[f] * pp2;
-                            gg += am2 * o2;
-                            const double2 b2 = bq[f >> 1];
-                            const double bf = (f & 1) ? b2.y : b2.x;
-                            hh += 1.0 * wgt * pf * (bf - 0.5 * gg);
-                        }
+                    const bool own = ownbits >> f & 1u;
+                    if (own && (onbits >> f & 1u)) {
+                        const double dlt = pf - K;
+                        s1 += dlt;
+                        s2 += dlt * dlt;
+                    }
+                    if (it > 0 && (own || JB_GG_KEEPG)) {
+                        // calc_hmmobj_derivative (mlpg.rs:205-229), the reference's order of additions;
+                        // operands outside [0, n) are zeros, which leaves the sum bit-identical
+                        const double pp1 = f + 1 < kGgFPT ? p[f + 1 < kGgFPT ? f + 1 : 0] : pr1;
+                        const double pp2 =
+                            f + 2 < kGgFPT ? p[f + 2 < kGgFPT ? f + 2 : 0] : (f + 2 == kGgFPT ? pr1 : pr2);
+                        const double am1 = f >= 1 ? a1[f >= 1 ? f - 1 : 0] : a1m;
+                        const double am2 = f >= 2 ? a2[f >= 2 ? f - 2 : 0] : (f == 1 ? a2m : a2mm);
+                        double gg = GG_A0(f) * pf;
+                        gg += a1[f] * pp1;
+                        gg += am1 * o1;
+                        gg += a2[f] * pp2;
+                        gg += am2 * o2;
+#if JB_GG_KEEPG
+                        g[f] = gg;
+#endif
+                        if (own)
+                            hh += 1.0 * wgt * pf * (GG_B(f) - 0.5 * gg);
                     }
                     o2 = o1;
                     o1 = pf;
                     JB_GG_FRAME_FENCE;
                 }
             }
+            GG_T(1);
             block_sum(s1, s2, hh);
-            exchange(s1, s2, hh, nxt);
+            GG_T(2);
+            exchange(true, s1, s2, hh, nxt);
+            GG_T(3);
             if (dead)
                 return;
-            if (it == 0)
+            if (it == 0) {
                 next_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs[0][3]);
+                ahead = row_info(next_row);
+            }
             double S1, S2, H;
             gather(S1, S2, H);
             const double mean = K + S1 / glen;
@@ -553,23 +645,28 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
                 // frame f are carried along (o2, o1), the ones to its right have not been touched yet
                 const double dv = -2.0 * gv_vari * (vari - gv_mean) / length;
                 if (busy) {
+#if !JB_GG_KEEPG
                     double o2 = pl2, o1 = pl1;
+#endif
 #pragma unroll
                     for (int f = 0; f < kGgFPT; f++) {
                         const double pf = p[f];
+#if JB_GG_KEEPG
+                        const double gg = g[f];
+#else
                         const double pp1 = f + 1 < kGgFPT ? p[f + 1 < kGgFPT ? f + 1 : 0] : pr1;
                         const double pp2 =
                             f + 2 < kGgFPT ? p[f + 2 < kGgFPT ? f + 2 : 0] : (f + 2 == kGgFPT ? pr1 : pr2);
                         const double am1 = f >= 1 ? a1[f >= 1 ? f - 1 : 0] : a1m;
                         const double am2 = f >= 2 ? a2[f >= 2 ? f - 2 : 0] : (f == 1 ? a2m : a2mm);
-                        double gg = a0[f] * pf;
+                        double gg = GG_A0(f) * pf;
                         gg += a1[f] * pp1;
                         gg += am1 * o1;
                         gg += a2[f] * pp2;
                         gg += am2 * o2;
-                        const double2 b2 = bq[f >> 1];
-                        const double bf = (f & 1) ? b2.y : b2.x;
-                        const double h = -1.0 * wgt * a0[f] -
+#endif
+                        const double bf = GG_B(f);
+                        const double h = -1.0 * wgt * GG_A0(f) -
                                          1.0 * 2.0 / ll *
                                              (lm1 * gv_vari * (vari - gv_mean) +
                                               2.0 * gv_vari * (pf - mean) * (pf - mean));
@@ -579,23 +676,26 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
                             next_g = rh * (1.0 * wgt * (-gg + bf) + 1.0 * dv * (pf - mean));
                         else
                             next_g = rh * (1.0 * wgt * (-gg + bf));
+#if !JB_GG_KEEPG
                         o2 = o1;
                         o1 = pf;
+#endif
                         p[f] = pf + step * next_g;
                         JB_GG_FRAME_FENCE;
                     }
                 }
             }
             K = mean;
+            GG_T(4);
         }
 
         // ---- store the frames this wave owns: back through the LDS image, coalesced ----
         if (busy) {
             gg_wave_sync();
-            double2 *q = reinterpret_cast<double2 *>(xs + gg_idx(kGgFPT * lane_v));
+            double2 *q = reinterpret_cast<double2 *>(xs);
 #pragma unroll
             for (int j = 0; j < kGgFPT / 2; j++)
-                q[j] = make_double2(p[2 * j], p[2 * j + 1]);
+                q[gg_gran(lane_v, j)] = make_double2(p[2 * j], p[2 * j + 1]);
             gg_wave_sync();
             const int own_hi = own_lo + kGgOwn < n_i ? own_lo + kGgOwn : n_i;
 #pragma unroll
@@ -606,7 +706,14 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
             }
         }
         row = next_row;
+        cur = ahead;
+        GG_T(5);
     }
+#if JB_GG_PROFILE
+    if (tid == 0)
+        for (int k = 0; k < 8; k++)
+            atomicAdd(&ctl->prof[k], (unsigned long long)prof_[k]);
+#endif
 }
 
 // Workgroups that fit the device at once for this kernel (what the register budget of its launch
