@@ -101,7 +101,8 @@ struct GvGangCtl {
 struct GvGang {
     uint32_t cnt; // arrivals: formation, then one per tile and exchange
     uint32_t pad[31];
-    double rec[2][kGvGangMaxTiles][4]; // {S1, S2, H, next row} per tile, two alternating slots
+    // {S1, S2, H, next row} per tile as four 16-byte granules {value, value ^ tag}, two alternating slots
+    unsigned long long rec[2][kGvGangMaxTiles][8];
 };
 
 struct VocDev {

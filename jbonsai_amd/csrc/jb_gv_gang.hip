@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         __syncthreads(); // every thread is done with the records of the previous exchange; red[] is written
         if (wv == 0) {
             typedef unsigned long long u64;
-            unsigned long long *slot = reinterpret_cast<unsigned long long *>(&G->rec[kbar & 1][0][0]);
+            unsigned long long *slot = &G->rec[kbar & 1][0][0];
             const u64 tagbase = 0x9E3779B97F4A7C15ull * (u64)(kbar + 1u);
             if (lane == 0) {
                 if (from_red) {

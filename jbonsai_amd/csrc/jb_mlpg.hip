@@ -1389,6 +1389,95 @@ __global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd
 }
 
 // --------------------------------------------------------------------------
+// A5/A6 for an MSD stream with one dimension (LF0): ONE LANE PER VOICED RUN.
+// The compacted system (mlpg.rs:79-115 on the frames that pass the mask, mod.rs:81) is block
+// diagonal: a dynamic window that touches an MSD boundary has its inverse variance zeroed
+// (mod.rs:69-80), so the band entries that would couple the last frame of a voiced run to the first
+// of the next are exact zeros -- A1[t_e], A2[t_e - 1], A2[t_e] -- and with them L1[t_e], L2[t_e - 1],
+// L2[t_e] (0 - L*0*D = 0, 0 / D = 0).  The serial recurrences therefore subtract exact zeros at every
+// run start, and a run solved on its own (first frame treated like t = 0, last like t = n - 1) gives
+// the same bits.  k_mlpg_fb_lds walks the 15 k voiced frames of an utterance on ONE lane (4.2 ms for
+// 128 s); here the ~400 runs of an utterance are walked side by side, the longest run (a few
+// hundred frames) setting the time.  Same operations in the same order as k_mlpg_fb_lds's passes.
+__global__ __launch_bounds__(64) void k_mlpg_fb_runs(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = (int)bd.order[blockIdx.y];
+    const UttDev *up = bd.utt + b;
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= sd.nruns[b])
+        return;
+    const uint64_t base = up->frame_off, sb = up->state_off;
+    const uint32_t T = up->T;
+    const uint32_t t0 = sd.run_list[sb + r];
+    // entries of the run list: first frame of a voiced run; a zero-length voiced state can repeat an
+    // entry or leave one that continues the previous run (k_prep_states)
+    if (t0 >= T || !sd.voiced[base + t0] || (t0 > 0 && sd.voiced[base + t0 - 1]))
+        return;
+    if (r > 0 && sd.run_list[sb + r - 1] == t0)
+        return;
+    const uint32_t s0 = sd.fstate[base + t0];
+    const uint32_t k0 = sd.s_vpre[sb + s0] + (t0 - sd.s_start[sb + s0]); // compacted index of the run's first frame
+    const uint32_t len = sd.s_rend[sb + s0] - t0 + 1;
+    const double *A0 = sd.A[0] + base + k0, *A1 = sd.A[1] + base + k0, *A2 = sd.A[2] + base + k0;
+    const double *Bv = sd.bvec + base + k0;
+    double *F0 = sd.F[0] + base + k0, *F1 = sd.F[1] + base + k0, *F2 = sd.F[2] + base + k0, *G = sd.g + base + k0;
+    double *P = sd.par + base + k0;
+    // ---- ldl_factorization + forward substitution (mlpg.rs:79-105) ----
+    {
+        double p1_0 = 0, p1_1 = 0, p1_2 = 0, p2_0 = 0, p2_2 = 0, g1 = 0, g2 = 0;
+        double n0 = A0[0], n1 = A1[0], n2 = A2[0], nb = Bv[0]; // one frame ahead of the recurrence
+        for (uint32_t t = 0; t < len; t++) {
+            double r0 = n0, r1 = n1, r2 = n2, g = nb;
+            if (t + 1 < len) {
+                n0 = A0[t + 1];
+                n1 = A1[t + 1];
+                n2 = A2[t + 1];
+                nb = Bv[t + 1];
+            }
+            if (t >= 1)
+                r0 -= p1_1 * p1_1 * p1_0;
+            if (t >= 2)
+                r0 -= p2_2 * p2_2 * p2_0;
+            if (t >= 1)
+                r1 -= p1_1 * p1_2 * p1_0;
+            const double rr = fb_rcp(r0);
+            r1 = fb_div(r1, r0, rr);
+            r2 = fb_div(r2, r0, rr);
+            if (t >= 1)
+                g -= p1_1 * g1;
+            if (t >= 2)
+                g -= p2_2 * g2;
+            F0[t] = r0;
+            F1[t] = r1;
+            F2[t] = r2;
+            G[t] = g;
+            p2_0 = p1_0;
+            p2_2 = p1_2;
+            g2 = g1;
+            p1_0 = r0;
+            p1_1 = r1;
+            p1_2 = r2;
+            g1 = g;
+        }
+    }
+    // ---- backward substitution (mlpg.rs:106-113), t descending; the lane reads back its own stores ----
+    {
+        double q1 = 0, q2 = 0;
+        for (uint32_t t = len; t-- > 0;) {
+            const double d = F0[t];
+            double p = fb_div(G[t], d, fb_rcp(d));
+            if (t + 1 < len)
+                p -= F1[t] * q1;
+            if (t + 2 < len)
+                p -= F2[t] * q2;
+            P[t] = p;
+            q2 = q1;
+            q1 = p;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------
 // A8 GV ascent with LANES OVER TIME (mlpg.rs:145-292).  The 13 sweeps of conv_gv and the
 // five parmgen iterations are elementwise in t plus reductions; only the ORDER of the
 // additions is serial.  One wave per (utterance, dim): 64 frames per vector instruction for
@@ -2155,8 +2244,13 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             dim3 gvgrid(sd.L, bd.B);
             if (sd.is_msd) {
                 if (gv_vt) {
-                    // L == 1: [frame][1] is [1][frame]; the LDS-staged sweeps run the same arithmetic
-                    if (sd.L == 1)
+                    // L == 1: [frame][1] is [1][frame]; one lane per voiced run (the compacted system is block
+                    // diagonal), or the LDS-staged sweeps over the whole utterance (JB_FB_RUNS=0): same bits
+                    static const bool runs_off = getenv("JB_FB_RUNS") && atoi(getenv("JB_FB_RUNS")) == 0;
+                    if (sd.L == 1 && !runs_off && bd.maxS > 0) {
+                        dim3 rg((bd.maxS + 63) / 64, bd.B);
+                        hipLaunchKernelGGL(k_mlpg_fb_runs, rg, dim3(64), 0, stream, bd, sd, si);
+                    } else if (sd.L == 1)
                         launch_fb(bd, sd, si, stream);
                     else
                         hipLaunchKernelGGL((k_mlpg_solve3<false, false>), grid, block, 0, stream, bd, sd, si);

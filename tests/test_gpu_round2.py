@@ -291,3 +291,19 @@ def test_noise_table_growth_keeps_old_batches_valid(ctx):
         assert n2 == 70000 * 240
         b.run()
         assert np.array_equal(b.pcm(0), before)
+
+
+def test_resident_gv_with_many_tiles_per_row(ctx):
+    """k_mlpg_gv_gang with long rows: 70,000 frames = 18 workgroups per gang, and the limit case of
+    32 (124,000 frames); rows longer than that take the multi-launch sweeps.  Tracks against the
+    serial-order kernel (rtol 1e-12) -- every tile's record has to reach every other tile."""
+    eng, tab, vi = ctx
+    for T in (70000, 124000, 126000):
+        u = synth.synth_utterance(tab, T, 77)
+        res = []
+        for kw in (dict(), dict(serial_gv=True)):
+            with J.Batch(vi, [u], keep_tracks=True, **kw) as b:
+                b.run()
+                b.sync()
+                res.append(b.track(0, 0))
+        np.testing.assert_allclose(res[0], res[1], rtol=1e-12, atol=1e-13)
