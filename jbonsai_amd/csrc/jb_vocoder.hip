@@ -1137,11 +1137,17 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
 // state VGPRs per lane => the compiler spills ~10 values inside the sample loop and each
 // reload is a memory round trip).  Here the five Pade stages are spread over three lanes,
 // {1,2} {3,4} {5,-}: 68 state doubles per lane, nothing spills, and there is room to keep
-// LDS reads in flight.  Five triples per 16-lane DPP row (lane 15 of each row idle), so
-// 20 chunks per wave; the per-sample exchange is one row_shr:1 (stage outputs to the next
-// lane) and two row_shl (Pade partial sums to the first lane of the triple).
-constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102;
-constexpr int kLtChunks = 20;
+// LDS reads in flight.  21 triples over lanes 0..62 of the wave (lane 63 idle), so 21 chunks per
+// wave; the per-sample exchange uses the whole-wave DPP shifts (a triple may straddle a 16-lane DPP
+// row): one wave_shr:1 (stage outputs to the next lane) and, per Pade partial sum, two wave_shl:1
+// that fold positions 2 -> 1 -> 0 of the triple.  (Five triples per 16-lane row with lane 15 of each
+// row idle -- row_shr / row_shl -- gave 20 chunks per wave: one more chunk per wave is 5 % more work
+// per launch for the same instructions.)
+constexpr int DPP_WAVE_SHL1 = 0x130;
+#ifndef JB_LT_CHUNKS
+#define JB_LT_CHUNKS 21
+#endif
+constexpr int kLtChunks = JB_LT_CHUNKS;
 #ifndef JB_LT_PF
 #define JB_LT_PF 4
 #endif
@@ -1158,11 +1164,18 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
     constexpr int M = NM - 1; // live taps 1..M
     constexpr int NS = 2;     // stage slots per lane
     const int lane = threadIdx.x;
+#if JB_LT_CHUNKS == 21
+    const bool idle = lane == 63;
+    // pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 63 behaves like pos 2)
+    const int pos = idle ? 2 : lane % 3;
+    const int ci = idle ? 20 : lane / 3; // chunk slot of this lane within the wave
+#else
     const int row = lane >> 4, p16 = lane & 15;
     const bool idle = p16 == 15;
     // pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 15 behaves like pos 2)
     const int tri = p16 / 3, pos = idle ? 2 : p16 % 3;
     const int ci = row * 5 + (idle ? 4 : tri); // chunk slot of this lane within the wave
+#endif
     const uint32_t slot = blockIdx.x * (uint32_t)kLtChunks + (uint32_t)ci;
     const bool has = !idle && slot < n_items;
     const bool lead = has && pos == 0;
@@ -1407,9 +1420,16 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, gathered on the lead lane ----
             const double v0 = w0 * y[0], v1 = w1 * y[1];
             const double sb = v0 + v1, sa = v0 - v1;
-            const double ssum = (sa + dpp_f64<DPP_ROW_SHL1>(sa)) + dpp_f64<DPP_ROW_SHL2>(sa);
-            const double psum = (sb + dpp_f64<DPP_ROW_SHL1>(sb)) + dpp_f64<DPP_ROW_SHL2>(sb);
+#if JB_LT_CHUNKS == 21
+            // fold position 2 into 1, then 1 into 0: sum(pos 0) = s0 + (s1 + s2)
+            const double ssum = sa + dpp_f64<DPP_WAVE_SHL1>(sa + dpp_f64<DPP_WAVE_SHL1>(sa));
+            const double psum = sb + dpp_f64<DPP_WAVE_SHL1>(sb + dpp_f64<DPP_WAVE_SHL1>(sb));
+            const double yprev = dpp_f64<DPP_WAVE_SHR1>(y[1]); // previous lane's second stage
+#else
+            const double ssum = (sa + dpp_f64<0x101>(sa)) + dpp_f64<0x102>(sa);
+            const double psum = (sb + dpp_f64<0x101>(sb)) + dpp_f64<0x102>(sb);
             const double yprev = dpp_f64<DPP_ROW_SHR1>(y[1]); // previous lane's second stage
+#endif
             const double xmid = x + ssum; // d22[0] (valid on the lead lane)
             x = xmid + psum;
             // next-sample slot inputs: stage s+1 <- y of stage s; stage 0 <- xmid

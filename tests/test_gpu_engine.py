@@ -242,7 +242,9 @@ def test_generator_with_postfilter_equals_synthesize():
         out.append(buf.copy())
     got = np.concatenate(out + [g.generate_all()])
     assert len(got) == len(whole) == 100800
-    assert rel_rms(got, whole) < 1e-12
+    # the generator is the serial recursion, synthesize() runs time-chunked: equal to the hand-off
+    # tolerance (1e-9 of the filter state, certified), not to rounding
+    assert rel_rms(got, whole) < 1e-10
 
 
 def test_synthesize_batch_in_groups_equals_one_batch(engine, monkeypatch):
