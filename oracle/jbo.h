@@ -131,6 +131,24 @@ void jbo_freqt(const double *c1, size_t n1, double *out /*[m2+1]*/, size_t m2, d
 void jbo_c2ir(const double *c, size_t nc, double *ir, size_t len);
 double jbo_b2en(const double *b, size_t n, double alpha);
 void jbo_postfilter_mcp(double *mc, size_t n, double alpha, double beta);
+/* X2: Stage::NonZero (GAMMA != 0: LSP spectra, MGLSA filter).  PARITY UNPINNED (no reference test or
+ * voice reaches it): src/vocoder/{lsp.rs, generalized.rs, cepstrum.rs:69-103, mglsa.rs, mod.rs:90-107,142-176}. */
+void jbo_lsp2lpc(const double *lsp, size_t m, double *out /*[m+1]*/);
+void jbo_gnorm(double *c, size_t n, double gamma);
+void jbo_ignorm(double *c, size_t n, double gamma);
+void jbo_gc2gc(const double *c1, size_t n1, double g1, double *c2 /*[m2+1]*/, size_t m2, double g2);
+void jbo_mgc2mgc(const double *c1, size_t n1, double a1, double g1, double *out /*[m2+1]*/, size_t m2, double a2,
+                 double g2);
+void jbo_lsp2mgc(const double *lsp, size_t n, double alpha, int use_log_gain, size_t stage, double gamma,
+                 double *mgc /*[n]*/);
+void jbo_postfilter_lsp(double *lsp, size_t n, double alpha, int use_log_gain, size_t stage, double gamma, double beta);
+void jbo_check_lsp_stability(double *lsp, size_t n);
+void jbo_stage_coefficients(const double *spectrum, size_t n, double alpha, double beta, int use_log_gain,
+                            size_t stage, int filtered, double *cc /*[n]*/);
+void jbo_mglsa_df(double *d /*[stage][n]*/, size_t stage, size_t n, double *x, double alpha, const double *c);
+int jbo_vocoder_stage(int fs, int fperiod, double alpha, double beta, double volume, int stage, int use_log_gain,
+                      int nmcp, int nlpf, size_t T, const double *lf0, const double *mcp, const double *lpf,
+                      double *pcm, double *exc);
 /* Random::nrandom stream (src/vocoder/excitation.rs:177-237), seed next=1. */
 void jbo_noise(double *out, size_t n);
 

@@ -671,6 +671,304 @@ void jbo_postfilter_mcp(double *mc, size_t n, double alpha, double beta)
     free(b);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * X2: Stage::NonZero (voices with GAMMA != 0: the spectrum stream holds [gain, LSP...]), restated
+ * from src/vocoder/{lsp.rs, generalized.rs, cepstrum.rs:69-103, mglsa.rs, mod.rs:90-107,142-176}.
+ * PARITY UNPINNED: no reference test reaches this branch and no voice with GAMMA != 0 exists here;
+ * the restatement follows the reference as written (including lsp2lpc taking ALL len() entries of
+ * the buffer -- the gain slot too -- as line spectral frequencies, lsp.rs:27-43, where hts_engine
+ * passes lsp + 1) and is held by the identities of tests/test_oracle_stage.py. */
+
+/* LineSpectralPairs::lsp2lpc (lsp.rs:27-94): out[m + 1], m = number of entries of lsp */
+void jbo_lsp2lpc(const double *lsp, size_t m, double *out)
+{
+    const size_t mh1 = (m % 2 == 0) ? m / 2 : (m + 1) / 2, mh2 = (m % 2 == 0) ? m / 2 : (m - 1) / 2;
+    double *p = (double *)calloc(mh1 + 1, sizeof(double)), *q = (double *)calloc(mh2 + 1, sizeof(double));
+    double *a0 = (double *)calloc(mh1 + 1, sizeof(double)), *a1 = (double *)calloc(mh1 + 1, sizeof(double));
+    double *a2 = (double *)calloc(mh1 + 1, sizeof(double)), *b0 = (double *)calloc(mh2 + 1, sizeof(double));
+    double *b1 = (double *)calloc(mh2 + 1, sizeof(double)), *b2 = (double *)calloc(mh2 + 1, sizeof(double));
+    for (size_t i = 0, k = 0; k < m; i++, k += 2)
+        p[i] = -2.0 * cos(lsp[k]);
+    for (size_t i = 0, k = 1; k < m; i++, k += 2)
+        q[i] = -2.0 * cos(lsp[k]);
+    double xff = 0.0, xf = 0.0;
+    for (size_t i = 0; i <= m; i++)
+        out[i] = 0.0;
+    for (size_t k = 0; k <= m; k++) {
+        const double xx = k == 0 ? 1.0 : 0.0;
+        if (m % 2 == 1) {
+            a0[0] = xx;
+            b0[0] = xx - xff;
+            xff = xf;
+            xf = xx;
+        } else {
+            a0[0] = xx + xf;
+            b0[0] = xx - xf;
+            xf = xx;
+        }
+        for (size_t i = 0; i < mh1; i++) {
+            a0[i + 1] = a0[i] + p[i] * a1[i] + a2[i];
+            a2[i] = a1[i];
+            a1[i] = a0[i];
+        }
+        for (size_t i = 0; i < mh2; i++) {
+            b0[i + 1] = b0[i] + q[i] * b1[i] + b2[i];
+            b2[i] = b1[i];
+            b1[i] = b0[i];
+        }
+        if (k > 0)
+            out[k - 1] = -0.5 * (a0[mh1] + b0[mh2]);
+    }
+    for (size_t i = m; i-- > 0;)
+        out[i + 1] = -out[i];
+    out[0] = 1.0;
+    free(p); free(q); free(a0); free(a1); free(a2); free(b0); free(b1); free(b2);
+}
+
+/* Generalized::gnorm / ignorm (generalized.rs:6-38), in place */
+void jbo_gnorm(double *c, size_t n, double gamma)
+{
+    if (gamma != 0.0) {
+        const double k = 1.0 + gamma * c[0];
+        c[0] = pow(k, 1.0 / gamma);
+        for (size_t i = 1; i < n; i++)
+            c[i] = c[i] / k;
+    } else {
+        c[0] = exp(c[0]);
+    }
+}
+void jbo_ignorm(double *c, size_t n, double gamma)
+{
+    if (gamma != 0.0) {
+        const double k = pow(c[0], gamma);
+        c[0] = (k - 1.0) / gamma;
+        for (size_t i = 1; i < n; i++)
+            c[i] = c[i] * k;
+    } else {
+        c[0] = log(c[0]);
+    }
+}
+
+/* MelGeneralizedCepstrum::gc2gc (cepstrum.rs:69-92): c1[n1] with gamma g1 -> c2[m2 + 1] with gamma g2 */
+void jbo_gc2gc(const double *c1, size_t n1, double g1, double *c2, size_t m2, double g2)
+{
+    c2[0] = c1[0];
+    for (size_t i = 1; i <= m2; i++) {
+        double ss1 = 0.0, ss2 = 0.0;
+        const size_t kend = n1 < i ? n1 : i;
+        for (size_t k = 1; k < kend; k++) {
+            const size_t mk = i - k;
+            const double cc = c1[k] * c2[mk];
+            ss1 += (double)mk * cc;
+            ss2 += (double)k * cc;
+        }
+        if (i < n1)
+            c2[i] = c1[i] + (g2 * ss2 - g1 * ss1) / (double)i;
+        else
+            c2[i] = (g2 * ss2 - g1 * ss1) / (double)i;
+    }
+}
+
+/* MelGeneralizedCepstrum::mgc2mgc (cepstrum.rs:94-102): c1[n1] (alpha a1, gamma g1) -> out[m2 + 1] */
+void jbo_mgc2mgc(const double *c1, size_t n1, double a1, double g1, double *out, size_t m2, double a2, double g2)
+{
+    double *t;
+    size_t nt;
+    if (a1 == a2) {
+        nt = n1;
+        t = (double *)malloc(sizeof(double) * nt);
+        memcpy(t, c1, sizeof(double) * nt);
+    } else {
+        const double a = (a2 - a1) / (1.0 - a1 * a2); /* cepstrum.rs:98: 1.0 - self.alpha * alpha */
+        nt = m2 + 1;
+        t = (double *)malloc(sizeof(double) * nt);
+        jbo_freqt(c1, n1, t, m2, a);
+    }
+    jbo_gnorm(t, nt, g1);
+    jbo_gc2gc(t, nt, g1, out, m2, g2);
+    jbo_ignorm(out, m2 + 1, g2);
+    free(t);
+}
+
+/* LineSpectralPairs::lsp2mgc (lsp.rs:96-107): lsp[n] -> mgc[n] */
+void jbo_lsp2mgc(const double *lsp, size_t n, double alpha, int use_log_gain, size_t stage, double gamma, double *mgc)
+{
+    double *lpc = (double *)malloc(sizeof(double) * (n + 1));
+    jbo_lsp2lpc(lsp, n, lpc);
+    lpc[0] = use_log_gain ? exp(lsp[0]) : lsp[0];
+    jbo_ignorm(lpc, n + 1, gamma);
+    for (size_t i = 1; i < n + 1; i++)
+        lpc[i] *= -(double)stage;
+    jbo_mgc2mgc(lpc, n + 1, alpha, gamma, mgc, n - 1, alpha, gamma);
+    free(lpc);
+}
+
+static double lsp2en(const double *lsp, size_t n, double alpha, int use_log_gain, size_t stage, double gamma)
+{
+    double *m = (double *)malloc(sizeof(double) * n);
+    jbo_lsp2mgc(lsp, n, alpha, use_log_gain, stage, gamma, m);
+    double e = 0.0;
+    for (size_t i = 0; i < n; i++)
+        e += m[i] * m[i];
+    free(m);
+    return e;
+}
+
+/* LineSpectralPairs::postfilter_lsp (lsp.rs:113-139), in place */
+void jbo_postfilter_lsp(double *lsp, size_t n, double alpha, int use_log_gain, size_t stage, double gamma, double beta)
+{
+    if (!(beta > 0.0 && n > 2))
+        return;
+    double *buf = (double *)calloc(n, sizeof(double));
+    const double en1 = lsp2en(lsp, n, alpha, use_log_gain, stage, gamma);
+    for (size_t i = 0; i < n; i++) {
+        if (i > 1 && i < n - 1) {
+            const double d1 = beta * (lsp[i + 1] - lsp[i]);
+            const double d2 = beta * (lsp[i] - lsp[i - 1]);
+            buf[i] = lsp[i - 1] + d2 + (d2 * d2 * ((lsp[i + 1] - lsp[i - 1]) - (d1 + d2))) / ((d2 * d2) + (d1 * d1));
+        } else {
+            buf[i] = lsp[i];
+        }
+    }
+    memcpy(lsp, buf, sizeof(double) * n);
+    free(buf);
+    const double en2 = lsp2en(lsp, n, alpha, use_log_gain, stage, gamma);
+    if (en1 != en2) {
+        if (use_log_gain)
+            lsp[0] += 0.5 * log(en1 / en2);
+        else
+            lsp[0] *= sqrt(en1 / en2);
+    }
+}
+
+/* LineSpectralPairs::check_lsp_stability (lsp.rs:141-165), in place */
+void jbo_check_lsp_stability(double *lsp, size_t n)
+{
+    const double PI = 3.14159265358979323846;
+    const double min = 0.25 * PI / (double)n;
+    const size_t last = n - 1;
+    for (int it = 0; it < 4; it++) {
+        int find = 0;
+        for (size_t j = 1; j < last; j++) {
+            const double tmp = lsp[j + 1] - lsp[j];
+            if (tmp < min) {
+                lsp[j] -= 0.5 * (min - tmp);
+                lsp[j + 1] += 0.5 * (min - tmp);
+                find = 1;
+            }
+        }
+        if (lsp[1] < min) {
+            lsp[1] = min;
+            find = 1;
+        }
+        if (lsp[last] > PI - min) {
+            lsp[last] = PI - min;
+            find = 1;
+        }
+        if (!find)
+            break;
+    }
+}
+
+/* the coefficients of one frame (mod.rs:92-106 first frame: filtered = 0; mod.rs:148-156: filtered = 1) */
+void jbo_stage_coefficients(const double *spectrum, size_t n, double alpha, double beta, int use_log_gain,
+                            size_t stage, int filtered, double *cc)
+{
+    const double gamma = -1.0 / (double)stage; /* stage.rs:31 */
+    double *lsp = (double *)malloc(sizeof(double) * n), *mgc = (double *)malloc(sizeof(double) * n);
+    memcpy(lsp, spectrum, sizeof(double) * n);
+    if (filtered) {
+        jbo_postfilter_lsp(lsp, n, alpha, use_log_gain, stage, gamma, beta);
+        jbo_check_lsp_stability(lsp, n);
+    }
+    jbo_lsp2mgc(lsp, n, alpha, use_log_gain, stage, gamma, mgc);
+    mc2b(mgc, cc, n, alpha);
+    jbo_gnorm(cc, n, gamma);
+    for (size_t i = 1; i < n; i++)
+        cc[i] *= gamma;
+    free(lsp);
+    free(mgc);
+}
+
+/* MelGeneralizedLogSpectrumApproximation::df / dff (mglsa.rs:15-41): d[stage][n], one sample */
+void jbo_mglsa_df(double *d, size_t stage, size_t n, double *x, double alpha, const double *c)
+{
+    const double aa = 1.0 - alpha * alpha;
+    for (size_t s = 0; s < stage; s++) {
+        double *ds = d + s * n;
+        double y = ds[0] * c[1];
+        for (size_t i = 1; i < n - 1; i++) {
+            ds[i] += alpha * (ds[i + 1] - ds[i - 1]);
+            y += ds[i] * c[i + 1];
+        }
+        *x -= y;
+        for (size_t i = n - 1; i >= 1; i--)
+            ds[i] = ds[i - 1];
+        ds[0] = alpha * ds[0] + aa * *x;
+    }
+}
+
+/* Vocoder::synthesize, Stage::NonZero branch (mod.rs:90-107,142-176), looped over the frames */
+int jbo_vocoder_stage(int fs, int fperiod_i, double alpha, double beta, double volume, int stage_i, int use_log_gain,
+                      int nmcp_i, int nlpf_i, size_t T, const double *lf0, const double *mcp, const double *lpf,
+                      double *pcm, double *excd)
+{
+    const double MAX_LF0 = 9.903487552536127, MIN_LF0 = 2.995732273553991; /* constants.rs:4-6 */
+    const size_t fperiod = (size_t)fperiod_i, nmcp = (size_t)nmcp_i, nlpf = (size_t)nlpf_i, stage = (size_t)stage_i;
+    if (nmcp < 3 || stage == 0)
+        return -1;
+    double *d = (double *)calloc(stage * nmcp, sizeof(double));
+    exc_t e;
+    memset(&e, 0, sizeof e);
+    e.nring = nlpf;
+    e.ring = (double *)calloc(nlpf ? nlpf : 1, sizeof(double));
+    e.random.used = 64;
+    e.random.next = 1;
+    double *c = (double *)calloc(nmcp, sizeof(double)), *cc = (double *)calloc(nmcp, sizeof(double));
+    double *cinc = (double *)calloc(nmcp, sizeof(double));
+    int is_first = 1;
+    for (size_t t = 0; t < T; t++) {
+        const double l = lf0[t];
+        double p;
+        if (l == JBO_NODATA) {
+            p = 0.0;
+        } else {
+            const double cl = l < MIN_LF0 ? MIN_LF0 : (l > MAX_LF0 ? MAX_LF0 : l);
+            p = (double)fs / exp(cl);
+        }
+        const double *spec = mcp + t * nmcp;
+        if (is_first) {
+            is_first = 0;
+            jbo_stage_coefficients(spec, nmcp, alpha, beta, use_log_gain, stage, 0, c);
+        }
+        jbo_stage_coefficients(spec, nmcp, alpha, beta, use_log_gain, stage, 1, cc);
+        for (size_t k = 0; k < nmcp; k++)
+            cinc[k] = (cc[k] - c[k]) / (double)fperiod;
+        exc_start(&e, p, fperiod);
+        const double *lp = lpf ? lpf + t * nlpf : NULL;
+        double *raw = pcm + t * fperiod;
+        for (size_t i = 0; i < fperiod; i++) {
+            double pu;
+            double x = exc_get(&e, lp, &pu);
+            if (excd)
+                excd[t * fperiod + i] = x;
+            x *= c[0];
+            jbo_mglsa_df(d, stage, nmcp, &x, alpha, c);
+            for (size_t k = 0; k < nmcp; k++)
+                c[k] += cinc[k];
+            raw[i] = x * volume;
+        }
+        e.pitch_of_curr_point = p; /* Excitation::end (excitation.rs:102-104) */
+        memcpy(c, cc, sizeof(double) * nmcp);
+    }
+    free(d);
+    free(e.ring);
+    free(c);
+    free(cc);
+    free(cinc);
+    return 0;
+}
+
 /* V2,V5,V8,V9: Vocoder::synthesize Stage::Zero (src/vocoder/mod.rs:72-141) looped
  * as SpeechGenerator::generate_all does (src/speech.rs:87-96). */
 int jbo_vocoder(int fs, int fperiod_i, double alpha, double volume, int nmcp_i, int nlpf_i,

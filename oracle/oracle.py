@@ -127,6 +127,20 @@ def lib():
         L.jbo_b2en.argtypes = [C.c_void_p, C.c_size_t, C.c_double]
         L.jbo_postfilter_mcp.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double]
         L.jbo_noise.argtypes = [C.c_void_p, C.c_size_t]
+        vp, sz, db = C.c_void_p, C.c_size_t, C.c_double
+        L.jbo_lsp2lpc.argtypes = [vp, sz, vp]
+        L.jbo_gnorm.argtypes = [vp, sz, db]
+        L.jbo_ignorm.argtypes = [vp, sz, db]
+        L.jbo_gc2gc.argtypes = [vp, sz, db, vp, sz, db]
+        L.jbo_mgc2mgc.argtypes = [vp, sz, db, db, vp, sz, db, db]
+        L.jbo_lsp2mgc.argtypes = [vp, sz, db, C.c_int, sz, db, vp]
+        L.jbo_postfilter_lsp.argtypes = [vp, sz, db, C.c_int, sz, db, db]
+        L.jbo_check_lsp_stability.argtypes = [vp, sz]
+        L.jbo_stage_coefficients.argtypes = [vp, sz, db, db, C.c_int, sz, C.c_int, vp]
+        L.jbo_mglsa_df.argtypes = [vp, sz, sz, vp, db, vp]
+        L.jbo_vocoder_stage.restype = C.c_int
+        L.jbo_vocoder_stage.argtypes = [C.c_int, C.c_int, db, db, db, C.c_int, C.c_int, C.c_int, C.c_int, sz,
+                                        vp, vp, vp, vp, vp]
         L.jbo_synthesize_ex.restype = C.c_int
         L.jbo_synthesize_ex.argtypes = [C.c_void_p, C.POINTER(Cond), C.POINTER(C.c_char_p), C.c_int,
                                         C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t),
@@ -380,7 +394,9 @@ def postfilter_mcp(mc, alpha, beta):
     return out
 
 
-def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False, beta=0.0):
+def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False, beta=0.0, stage=0, use_log_gain=False):
+    """Vocoder::synthesize over all frames.  stage > 0: the Stage::NonZero branch (spectrum = [gain, LSP...],
+    MGLSA filter; vocoder/mod.rs:90-107,142-176) -- parity unpinned."""
     lf0 = np.ascontiguousarray(lf0, dtype=np.float64).reshape(-1)
     T = len(lf0)
     mcp = np.ascontiguousarray(mcp, dtype=np.float64).reshape(T, -1)
@@ -392,12 +408,93 @@ def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False, beta=0.0):
     pcm = np.zeros(T * fperiod)
     exc = np.zeros(T * fperiod) if dumps else None
     pul = np.zeros(T * fperiod) if dumps else None
+    if stage:
+        r = lib().jbo_vocoder_stage(fs, fperiod, alpha, beta, volume, int(stage), int(bool(use_log_gain)), nmcp, nlpf,
+                                    T, lf0.ctypes.data, mcp.ctypes.data, lpf.ctypes.data if nlpf else None,
+                                    pcm.ctypes.data, exc.ctypes.data if dumps else None)
+        if r:
+            raise RuntimeError("vocoder_stage")
+        return (pcm, exc, None) if dumps else pcm
     r = lib().jbo_vocoder_beta(fs, fperiod, alpha, beta, volume, nmcp, nlpf, T, lf0.ctypes.data, mcp.ctypes.data,
                           lpf.ctypes.data if nlpf else None, pcm.ctypes.data,
                           exc.ctypes.data if dumps else None, pul.ctypes.data if dumps else None)
     if r:
         raise RuntimeError("vocoder")
     return (pcm, exc, pul) if dumps else pcm
+
+
+# ---- X2 pieces (Stage::NonZero; parity unpinned, held by tests/test_oracle_stage.py) ----
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def lsp2lpc(lsp):
+    lsp = _f64(lsp)
+    out = np.zeros(len(lsp) + 1)
+    lib().jbo_lsp2lpc(lsp.ctypes.data, len(lsp), out.ctypes.data)
+    return out
+
+
+def gnorm(c, gamma):
+    c = _f64(c).copy()
+    lib().jbo_gnorm(c.ctypes.data, len(c), gamma)
+    return c
+
+
+def ignorm(c, gamma):
+    c = _f64(c).copy()
+    lib().jbo_ignorm(c.ctypes.data, len(c), gamma)
+    return c
+
+
+def gc2gc(c1, g1, m2, g2):
+    c1 = _f64(c1)
+    out = np.zeros(m2 + 1)
+    lib().jbo_gc2gc(c1.ctypes.data, len(c1), g1, out.ctypes.data, m2, g2)
+    return out
+
+
+def mgc2mgc(c1, a1, g1, m2, a2, g2):
+    c1 = _f64(c1)
+    out = np.zeros(m2 + 1)
+    lib().jbo_mgc2mgc(c1.ctypes.data, len(c1), a1, g1, out.ctypes.data, m2, a2, g2)
+    return out
+
+
+def lsp2mgc(lsp, alpha, use_log_gain, stage):
+    lsp = _f64(lsp)
+    out = np.zeros(len(lsp))
+    lib().jbo_lsp2mgc(lsp.ctypes.data, len(lsp), alpha, int(bool(use_log_gain)), stage, -1.0 / stage, out.ctypes.data)
+    return out
+
+
+def postfilter_lsp(lsp, alpha, use_log_gain, stage, beta):
+    lsp = _f64(lsp).copy()
+    lib().jbo_postfilter_lsp(lsp.ctypes.data, len(lsp), alpha, int(bool(use_log_gain)), stage, -1.0 / stage, beta)
+    return lsp
+
+
+def check_lsp_stability(lsp):
+    lsp = _f64(lsp).copy()
+    lib().jbo_check_lsp_stability(lsp.ctypes.data, len(lsp))
+    return lsp
+
+
+def stage_coefficients(spectrum, alpha, beta, use_log_gain, stage, filtered=True):
+    sp = _f64(spectrum)
+    out = np.zeros(len(sp))
+    lib().jbo_stage_coefficients(sp.ctypes.data, len(sp), alpha, beta, int(bool(use_log_gain)), stage,
+                                 int(bool(filtered)), out.ctypes.data)
+    return out
+
+
+def mglsa_df(d, x, alpha, c):
+    """one sample through the MGLSA cascade; d [stage, n] is updated in place; returns the output"""
+    assert d.dtype == np.float64 and d.flags["C_CONTIGUOUS"]
+    c = _f64(c)
+    xv = np.array([x], dtype=np.float64)
+    lib().jbo_mglsa_df(d.ctypes.data, d.shape[0], d.shape[1], xv.ctypes.data, alpha, c.ctypes.data)
+    return float(xv[0])
 
 
 def noise(n):
