@@ -39,7 +39,7 @@ extern "C" {
 typedef enum jb_status {
     JB_OK = 0,
     JB_ERR_INVALID = -1,     /* bad argument / shape (reference: panics in src/speech.rs:32-40) */
-    JB_ERR_UNSUPPORTED = -2, /* Stage::NonZero (GAMMA!=0), nlpf==0: not on any BASELINE config */
+    JB_ERR_UNSUPPORTED = -2, /* nlpf==0, stages above 8, frame periods without a block divisor: off every BASELINE config */
     JB_ERR_DEVICE = -3,      /* HIP error or no gfx950 device: the product never falls back to CPU */
     JB_ERR_MODEL = -4,       /* ModelError (src/model/mod.rs:31-46) */
     JB_ERR_LABEL = -5,       /* LabelError (src/label.rs:8-23) */
@@ -68,9 +68,10 @@ typedef struct jb_voice_desc {
     uint32_t sampling_frequency;  /* rate */
     uint32_t fperiod;
     uint32_t nstream;             /* 3: MCP, LF0, LPF (src/engine.rs:303-313 needs stream 2) */
-    uint32_t stage;               /* 0 only */
+    uint32_t stage;               /* 0: MLSA (mel-cepstra); 1..8: Stage::NonZero, gamma = -1/stage, spectrum = [gain, LSP...],
+                                     MGLSA filter (vocoder/mod.rs:90-107,142-176; parity unpinned: no reference test reaches it) */
     uint32_t use_log_gain;        /* ignored when stage==0 */
-    double alpha, beta, volume;   /* beta > 0: mel-cepstral post-filter per frame (cepstrum.rs:23-37) */
+    double alpha, beta, volume;   /* beta > 0: post-filter per frame (stage 0: cepstrum.rs:23-37; stage > 0: lsp.rs:113-139) */
     jb_stream_desc stream[JB_MAX_STREAM];
 } jb_voice_desc;
 
@@ -212,6 +213,9 @@ int jb_release_cached_memory(void);
 /* Parity tap: the MLSA filter coefficients the vocoder interpolates between, [T][nmcp] =
  * mc2b(postfilter_mcp(spectrum)) per frame (src/vocoder/mod.rs:116-118). */
 int jb_batch_read_coefficients(jb_batch *b, size_t utt, double *dst, size_t cap);
+/* The coefficients frame 0 STARTS from, [nmcp]: equal to frame 0's row above unless a post-filter or
+ * Stage::NonZero is on (then: of the un-filtered spectrum, vocoder/mod.rs:80-106). */
+int jb_batch_read_first_coefficients(jb_batch *b, size_t utt, double *dst, size_t cap);
 /* Debug/parity taps: excitation before gain [N]; needs KEEP_TRACKS. */
 int jb_batch_read_excitation(jb_batch *b, size_t utt, double *dst, size_t cap);
 /* Device pointer + sample count of the batch's contiguous PCM slab (for an RCCL gather

@@ -119,7 +119,7 @@ class BatchOpts(C.Structure):
 SYMBOLS = [
     "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_last_timing", "jb_batch_size",
     "jb_batch_num_frames", "jb_batch_num_samples", "jb_batch_total_samples", "jb_batch_read_pcm",
-    "jb_batch_read_pcm_i16", "jb_batch_read_pcm_all", "jb_batch_read_pcm_i16_all", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_batch_read_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
+    "jb_batch_read_pcm_i16", "jb_batch_read_pcm_all", "jb_batch_read_pcm_i16_all", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_batch_read_coefficients", "jb_batch_read_first_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
     "jb_batch_info", "jb_batch_redo_stats", "jb_batch_free", "jb_paramgen_vocode_batch",
     "jb_engine_load", "jb_engine_load_from_bytes", "jb_engine_free",
     "jb_engine_set_sampling_frequency", "jb_engine_get_sampling_frequency",
@@ -191,6 +191,7 @@ def lib():
     L.jb_batch_read_pcm_i16_all.argtypes = [vp, C.POINTER(vp)]
     L.jb_batch_read_track.argtypes = [vp, sz, C.c_uint32, vp, sz]
     L.jb_batch_read_coefficients.argtypes = [vp, sz, vp, sz]
+    L.jb_batch_read_first_coefficients.argtypes = [vp, sz, vp, sz]
     L.jb_batch_read_pcm_i16.argtypes = [vp, sz, vp, sz]
     L.jb_batch_read_excitation.argtypes = [vp, sz, vp, sz]
     L.jb_batch_device_pcm.restype = vp

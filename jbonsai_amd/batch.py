@@ -278,6 +278,13 @@ class Batch:
         F.check(self._L.jb_batch_read_coefficients(self._h, i, out.ctypes.data, out.size))
         return out
 
+    def first_coefficients(self, i) -> np.ndarray:
+        """The coefficients frame 0 starts from (un-filtered spectrum when a post-filter / stage is on)."""
+        Lv = self.voice.streams[0].vector_length
+        out = np.zeros(Lv, dtype=np.float64)
+        F.check(self._L.jb_batch_read_first_coefficients(self._h, i, out.ctypes.data, out.size))
+        return out
+
     def excitation(self, i) -> np.ndarray:
         n = self.num_samples(i)
         out = np.empty(n, dtype=np.float64)

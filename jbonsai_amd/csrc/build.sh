@@ -9,7 +9,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-result -Wno-unused-value"
 mkdir -p build
 objs=()
-for f in jb_mlpg.hip jb_gv_gang.hip jb_vocoder.hip jb_postfilter.hip jb_batch.cpp jb_voice.cpp jb_engine.cpp jb_multi.cpp; do
+for f in jb_mlpg.hip jb_gv_gang.hip jb_vocoder.hip jb_mglsa.hip jb_postfilter.hip jb_batch.cpp jb_voice.cpp jb_engine.cpp jb_multi.cpp; do
   [ -f "$f" ] || continue
   o=build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ jb_device.h -nt "$o" ] || [ jb_host.h -nt "$o" ] \

@@ -501,8 +501,8 @@ static int check_voice(const jb_voice_desc *v)
 {
     if (!v)
         return JB_ERR_INVALID;
-    if (v->stage != 0) {
-        set_error("Stage::NonZero (GAMMA != 0, LSP/MGLSA) is not supported");
+    if (v->stage > 8) {
+        set_error("Stage::NonZero: stages above 8 are not supported");
         return JB_ERR_UNSUPPORTED;
     }
     if (!(v->beta >= 0.0)) {
@@ -538,6 +538,10 @@ static int check_voice(const jb_voice_desc *v)
     if (m.vector_length < 2 || m.vector_length - 1 > (uint32_t)(kGroups * kMaxTPL)) {
         set_error("nmcp must be in [2, 61]");
         return JB_ERR_UNSUPPORTED;
+    }
+    if (v->stage != 0 && m.vector_length < 3) {
+        set_error("Stage::NonZero needs at least a gain and two line spectral frequencies");
+        return JB_ERR_INVALID;
     }
     for (uint32_t i = 0; i < v->nstream; i++) {
         const jb_stream_desc &s = v->stream[i];
@@ -762,7 +766,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         sd.serial_gv = (b->flags & JB_BATCH_SERIAL_GV) ? 1 : 0;
         sd.mt = (sd.BW == 3 && !sd.generic_solver && sd.L > 2 && sd.L <= mlpg_mt_max_dim()) ? 1 : 0;
         // MCP, non-MSD, [dim][frame]: its transpose is fused with mc2b (enqueue_paramgen)
-        sd.defer_out = (si == 0 && sd.mt && !sd.is_msd) ? 1 : 0;
+        // (Stage::NonZero reads the [frame][dim] track itself: k_stage_coef)
+        sd.defer_out = (si == 0 && sd.mt && !sd.is_msd && voice->stage == 0) ? 1 : 0;
         const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L, nst = (size_t)sumS;
         if ((rc = b->dalloc(&sd.s_start, nst, false)) || (rc = b->dalloc(&sd.s_vpre, nst, false)) ||
             (rc = b->dalloc(&sd.s_rstart, nst, false)) || (rc = b->dalloc(&sd.s_rend, nst, false)) ||
@@ -828,7 +833,10 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.alpha = voice->alpha;
     vd.volume = voice->volume;
     // postfilter_mcp acts only for beta > 0 and more than two coefficients (cepstrum.rs:24)
-    vd.beta = (voice->beta > 0.0 && vd.nmcp > 2) ? voice->beta : 0.0;
+    vd.beta = (voice->beta > 0.0 && vd.nmcp > 2 && voice->stage == 0) ? voice->beta : 0.0;
+    vd.stage = (int)voice->stage;
+    vd.use_log_gain = voice->use_log_gain ? 1 : 0;
+    vd.beta_stage = voice->stage ? voice->beta : 0.0; // postfilter_lsp (lsp.rs:113-139)
     vd.voiced = b->sd[1].voiced;
     vd.run_list = b->sd[1].run_list;
     vd.nruns = b->sd[1].nruns;
@@ -844,6 +852,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         (rc = b->dalloc(&vd.pinc, nf, false)) || (rc = b->dalloc(&vd.counter_start, nf, false)) ||
         (rc = b->dalloc(&vd.pmask, nf * (size_t)vd.nblk, false)) ||
         (rc = b->dalloc(&vd.xin, b->total_samples, false)))
+        return rc;
+    if (vd.stage > 0 && (rc = b->dalloc(&vd.bfirst, (size_t)std::max<size_t>(n, 1) * (size_t)vd.nmcp, true)))
         return rc;
     if (vd.beta > 0.0) {
         if ((rc = b->dalloc(&vd.bfirst, (size_t)std::max<size_t>(n, 1) * (size_t)vd.nmcp, true)) ||
@@ -863,7 +873,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     if (b->flags & JB_BATCH_KEEP_TRACKS)
         if ((rc = b->dalloc(&vd.exc, b->total_samples, false)))
             return rc;
-    vd.state_stride = vocoder_state_doubles(vd.nmcp);
+    vd.state_stride = vd.stage > 0 ? mglsa_state_doubles(vd.stage) : vocoder_state_doubles(vd.nmcp);
     if ((rc = b->dalloc(&vd.state, (size_t)vd.state_stride * n, true)))
         return rc;
     if ((rc = noise_table(dev, (size_t)maxT * (size_t)vd.fperiod, &b->noise)))
@@ -906,7 +916,7 @@ int Batch::build_work(const jb_batch_opts *opts)
     uint64_t lp_min = 190000;
     if (const char *e = getenv("JB_LP_MIN_FRAMES"))
         lp_min = strtoull(e, nullptr, 10);
-    lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vocoder_ls_supported(vd.nmcp) &&
+    lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vd.stage == 0 && vocoder_ls_supported(vd.nmcp) &&
               (sumT >= lp_min || (flags & JB_BATCH_PAIR_KERNEL));
     if (serial) {
         ch = 0;
@@ -1115,7 +1125,9 @@ int Batch::enqueue_paramgen()
         return hip_fail(e, "k_prep(mcp)");
     if ((e = launch_mlpg(bd, sd[0], 0, stream, ev_mcpbuild, excite_noise_hook, this)) != hipSuccess)
         return hip_fail(e, "k_mlpg(mcp) / k_excite(noise)");
-    if (sd[0].defer_out)
+    if (vd.stage > 0)
+        e = launch_stage_coef(bd, vd, stream); // Stage::NonZero: LSP track -> MGLSA coefficients
+    else if (sd[0].defer_out)
         e = launch_mc2b_mt(bd, sd[0], vd, (flags & JB_BATCH_KEEP_TRACKS) != 0, stream);
     else
         e = launch_mc2b(bd, vd, stream);
@@ -1155,7 +1167,7 @@ int Batch::run(bool timed)
         hipEventRecord(ev2, stream_voc);
     if (chunk_frames != 0 && n_items > 0) {
         hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
-        if ((e = launch_voc_verify(work_dev, n_items, vd.state_stride, vd.nmcp - 1, verify_tol, bad_dev,
+        if ((e = launch_voc_verify(work_dev, n_items, vd.state_stride, vd.stage > 0 ? -1 : vd.nmcp - 1, verify_tol, bad_dev,
                                    nbad_dev, stream_voc)) != hipSuccess)
             return hip_fail(e, "k_voc_verify");
         verify_pending = true;
@@ -1254,7 +1266,7 @@ int Batch::finish_verify()
             }
             hipMemcpy(pairs_dev, pairs.data(), sizeof(double *) * pairs.size(), hipMemcpyHostToDevice);
             hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
-            if ((e = launch_voc_verify_pairs(pairs_dev, (uint32_t)part.size(), vd.state_stride, vd.nmcp - 1, verify_tol, bad_dev,
+            if ((e = launch_voc_verify_pairs(pairs_dev, (uint32_t)part.size(), vd.state_stride, vd.stage > 0 ? -1 : vd.nmcp - 1, verify_tol, bad_dev,
                                              nbad_dev, stream_voc)) != hipSuccess)
                 return hip_fail(e, "k_voc_verify_pairs");
             std::vector<uint8_t> bad2(part.size());
@@ -1305,7 +1317,7 @@ int Batch::finish_verify()
             }
             hipMemcpy(pairs_dev, pairs.data(), sizeof(double *) * pairs.size(), hipMemcpyHostToDevice);
             hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
-            if ((e = launch_voc_verify_pairs(pairs_dev, (uint32_t)succ.size(), vd.state_stride, vd.nmcp - 1, verify_tol,
+            if ((e = launch_voc_verify_pairs(pairs_dev, (uint32_t)succ.size(), vd.state_stride, vd.stage > 0 ? -1 : vd.nmcp - 1, verify_tol,
                                              bad_dev, nbad_dev, stream_voc)) != hipSuccess)
                 return hip_fail(e, "k_voc_verify_pairs(successors)");
             std::vector<uint8_t> bad3(succ.size());
@@ -1762,6 +1774,21 @@ int jb_batch_read_coefficients(jb_batch *hb, size_t i, double *dst, size_t cap)
     if (ne == 0)
         return JB_OK;
     return b->read(b->vd.bcoef + (size_t)b->frame_off[i] * L, dst, ne * sizeof(double));
+}
+
+int jb_batch_read_first_coefficients(jb_batch *hb, size_t i, double *dst, size_t cap)
+{
+    Batch *b = (Batch *)hb;
+    if (!b || i >= (size_t)b->B)
+        return JB_ERR_INVALID;
+    const size_t L = (size_t)b->vd.nmcp;
+    if (cap < L)
+        return JB_ERR_BUFFER;
+    if (b->T[i] == 0)
+        return JB_OK;
+    if (b->vd.bfirst)
+        return b->read(b->vd.bfirst + i * L, dst, L * sizeof(double));
+    return b->read(b->vd.bcoef + (size_t)b->frame_off[i] * L, dst, L * sizeof(double));
 }
 
 int jb_batch_read_excitation(jb_batch *hb, size_t i, double *dst, size_t cap)

@@ -113,6 +113,10 @@ struct VocDev {
     const double *lpf;    // [sumT][nlpf]
     double *bcoef;        // [sumT][nmcp]  mc2b(mcp)  (src/vocoder/cepstrum.rs:139-149)
     double beta;          // post-filter coefficient (cepstrum.rs:23-37); 0 = off
+    // Stage::NonZero (GAMMA != 0, stage.rs:24-39; jb_mglsa.hip): stage > 0 selects it; its post-filter
+    // coefficient (postfilter_lsp, lsp.rs:113-139) is beta_stage, `beta` above stays 0 then
+    int stage, use_log_gain;
+    double beta_stage;
     double *bfirst;       // [B][nmcp] un-filtered bcoef of each utterance's first frame, or nullptr (beta == 0)
     double *pf_table;     // [nmcp][576] freqt(575, -alpha) as a linear operator (k_pf_table), or nullptr
     double *pf_rcp;       // [576] 1/n
@@ -221,6 +225,12 @@ hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork
 hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int state_doubles, int ntaps, double tol,
                              uint8_t *bad, uint32_t *n_bad, hipStream_t stream);
 int vocoder_state_doubles(int nmcp);
+// Stage::NonZero: per-frame coefficients (bcoef, bfirst) from the [frame][dim] LSP track; the filter
+// (dispatched by launch_vocoder when vd.stage > 0); doubles of its state dump
+hipError_t launch_stage_coef(const BatchDev &bd, const VocDev &vd, hipStream_t stream);
+hipError_t launch_vocoder_mglsa(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
+                                hipStream_t stream);
+int mglsa_state_doubles(int stage);
 // bad[j] = 1 (and ++*n_bad) when states pairs[2j] and pairs[2j+1] differ by more than tol * max|state|
 hipError_t launch_voc_verify_pairs(const double *const *pairs_dev, uint32_t n_pairs, int state_doubles, int ntaps,
                                    double tol, uint8_t *bad, uint32_t *n_bad, hipStream_t stream);

@@ -1488,7 +1488,9 @@ __device__ __forceinline__ bool voc_state_differs(const double *__restrict__ a, 
     const int urow = nfilt - 76; // 64*TPL: start of the u row (layout: d[TPL][64] | u[64] | e11[6] | e12[6])
     const int tpl = urow / 64;
     for (int k = lane; k < nfilt; k += 64) {
-        if (k < urow) {
+        if (ntaps < 0) {
+            // Stage::NonZero dumps (d[stage][64]): every slot is carried state
+        } else if (k < urow) {
             const int ln = k & 63, kk = k >> 6;
             if (ln >= kGroups * kPade || (ln % kGroups) * tpl + kk >= ntaps)
                 continue;
@@ -1661,7 +1663,7 @@ hipError_t launch_voc_verify(const VocWork *work_dev, uint32_t n_items, int stat
     if (n_items == 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_voc_verify, dim3(n_items), dim3(64), 0, stream, work_dev, n_items,
-                       state_doubles - 4, ntaps, tol, bad, n_bad);
+                       ntaps < 0 ? state_doubles : state_doubles - 4, ntaps, tol, bad, n_bad);
     return hipGetLastError();
 }
 
@@ -1671,7 +1673,7 @@ hipError_t launch_voc_verify_pairs(const double *const *pairs_dev, uint32_t n_pa
     if (n_pairs == 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_voc_verify_pairs, dim3(n_pairs), dim3(64), 0, stream, pairs_dev, n_pairs,
-                       state_doubles - 4, ntaps, tol, bad, n_bad);
+                       ntaps < 0 ? state_doubles : state_doubles - 4, ntaps, tol, bad, n_bad);
     return hipGetLastError();
 }
 
@@ -1721,6 +1723,8 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
 {
     if (n_items == 0)
         return hipSuccess;
+    if (vd.stage > 0) // Stage::NonZero: the MGLSA cascade (jb_mglsa.hip)
+        return launch_vocoder_mglsa(bd, vd, work_dev, n_items, stream);
     dim3 grid((n_items + 3) / 4), block(256);
     switch (tpl_for(vd.nmcp)) {
     case 1:

@@ -149,6 +149,10 @@ void jbo_mglsa_df(double *d /*[stage][n]*/, size_t stage, size_t n, double *x, d
 int jbo_vocoder_stage(int fs, int fperiod, double alpha, double beta, double volume, int stage, int use_log_gain,
                       int nmcp, int nlpf, size_t T, const double *lf0, const double *mcp, const double *lpf,
                       double *pcm, double *exc);
+/* same loop on GIVEN coefficients coef[T][nmcp] / cfirst[nmcp] (the conversion is ill-conditioned) */
+int jbo_vocoder_stage_coef(int fs, int fperiod, double alpha, double beta, double volume, int stage, int use_log_gain,
+                           int nmcp, int nlpf, size_t T, const double *lf0, const double *mcp, const double *lpf,
+                           const double *coef, const double *cfirst, double *pcm, double *exc);
 /* Random::nrandom stream (src/vocoder/excitation.rs:177-237), seed next=1. */
 void jbo_noise(double *out, size_t n);
 

@@ -908,10 +908,23 @@ void jbo_mglsa_df(double *d, size_t stage, size_t n, double *x, double alpha, co
     }
 }
 
-/* Vocoder::synthesize, Stage::NonZero branch (mod.rs:90-107,142-176), looped over the frames */
+/* Vocoder::synthesize, Stage::NonZero branch (mod.rs:90-107,142-176), looped over the frames.
+ * coef != NULL: the per-frame coefficients cc are TAKEN from coef[T][nmcp] (and the first frame's start
+ * from cfirst[nmcp]) instead of computed from the spectrum -- the LSP -> coefficient conversion is
+ * ill-conditioned (tests/test_oracle_stage.py), so the filter loop is checked on given coefficients. */
+int jbo_vocoder_stage_coef(int fs, int fperiod_i, double alpha, double beta, double volume, int stage_i,
+                           int use_log_gain, int nmcp_i, int nlpf_i, size_t T, const double *lf0, const double *mcp,
+                           const double *lpf, const double *coef, const double *cfirst, double *pcm, double *excd);
 int jbo_vocoder_stage(int fs, int fperiod_i, double alpha, double beta, double volume, int stage_i, int use_log_gain,
                       int nmcp_i, int nlpf_i, size_t T, const double *lf0, const double *mcp, const double *lpf,
                       double *pcm, double *excd)
+{
+    return jbo_vocoder_stage_coef(fs, fperiod_i, alpha, beta, volume, stage_i, use_log_gain, nmcp_i, nlpf_i, T, lf0,
+                                  mcp, lpf, NULL, NULL, pcm, excd);
+}
+int jbo_vocoder_stage_coef(int fs, int fperiod_i, double alpha, double beta, double volume, int stage_i,
+                           int use_log_gain, int nmcp_i, int nlpf_i, size_t T, const double *lf0, const double *mcp,
+                           const double *lpf, const double *coef, const double *cfirst, double *pcm, double *excd)
 {
     const double MAX_LF0 = 9.903487552536127, MIN_LF0 = 2.995732273553991; /* constants.rs:4-6 */
     const size_t fperiod = (size_t)fperiod_i, nmcp = (size_t)nmcp_i, nlpf = (size_t)nlpf_i, stage = (size_t)stage_i;
@@ -939,9 +952,15 @@ int jbo_vocoder_stage(int fs, int fperiod_i, double alpha, double beta, double v
         const double *spec = mcp + t * nmcp;
         if (is_first) {
             is_first = 0;
-            jbo_stage_coefficients(spec, nmcp, alpha, beta, use_log_gain, stage, 0, c);
+            if (coef)
+                memcpy(c, cfirst, sizeof(double) * nmcp);
+            else
+                jbo_stage_coefficients(spec, nmcp, alpha, beta, use_log_gain, stage, 0, c);
         }
-        jbo_stage_coefficients(spec, nmcp, alpha, beta, use_log_gain, stage, 1, cc);
+        if (coef)
+            memcpy(cc, coef + t * nmcp, sizeof(double) * nmcp);
+        else
+            jbo_stage_coefficients(spec, nmcp, alpha, beta, use_log_gain, stage, 1, cc);
         for (size_t k = 0; k < nmcp; k++)
             cinc[k] = (cc[k] - c[k]) / (double)fperiod;
         exc_start(&e, p, fperiod);

@@ -141,6 +141,9 @@ def lib():
         L.jbo_vocoder_stage.restype = C.c_int
         L.jbo_vocoder_stage.argtypes = [C.c_int, C.c_int, db, db, db, C.c_int, C.c_int, C.c_int, C.c_int, sz,
                                         vp, vp, vp, vp, vp]
+        L.jbo_vocoder_stage_coef.restype = C.c_int
+        L.jbo_vocoder_stage_coef.argtypes = [C.c_int, C.c_int, db, db, db, C.c_int, C.c_int, C.c_int, C.c_int, sz,
+                                             vp, vp, vp, vp, vp, vp, vp]
         L.jbo_synthesize_ex.restype = C.c_int
         L.jbo_synthesize_ex.argtypes = [C.c_void_p, C.POINTER(Cond), C.POINTER(C.c_char_p), C.c_int,
                                         C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t),
@@ -394,7 +397,8 @@ def postfilter_mcp(mc, alpha, beta):
     return out
 
 
-def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False, beta=0.0, stage=0, use_log_gain=False):
+def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False, beta=0.0, stage=0, use_log_gain=False,
+            coef=None, cfirst=None):
     """Vocoder::synthesize over all frames.  stage > 0: the Stage::NonZero branch (spectrum = [gain, LSP...],
     MGLSA filter; vocoder/mod.rs:90-107,142-176) -- parity unpinned."""
     lf0 = np.ascontiguousarray(lf0, dtype=np.float64).reshape(-1)
@@ -409,9 +413,14 @@ def vocoder(fs, fperiod, alpha, volume, lf0, mcp, lpf, dumps=False, beta=0.0, st
     exc = np.zeros(T * fperiod) if dumps else None
     pul = np.zeros(T * fperiod) if dumps else None
     if stage:
-        r = lib().jbo_vocoder_stage(fs, fperiod, alpha, beta, volume, int(stage), int(bool(use_log_gain)), nmcp, nlpf,
-                                    T, lf0.ctypes.data, mcp.ctypes.data, lpf.ctypes.data if nlpf else None,
-                                    pcm.ctypes.data, exc.ctypes.data if dumps else None)
+        if coef is not None:
+            coef = np.ascontiguousarray(coef, dtype=np.float64).reshape(T, nmcp)
+            cfirst = np.ascontiguousarray(cfirst, dtype=np.float64).reshape(nmcp)
+        r = lib().jbo_vocoder_stage_coef(fs, fperiod, alpha, beta, volume, int(stage), int(bool(use_log_gain)), nmcp,
+                                         nlpf, T, lf0.ctypes.data, mcp.ctypes.data, lpf.ctypes.data if nlpf else None,
+                                         coef.ctypes.data if coef is not None else None,
+                                         cfirst.ctypes.data if coef is not None else None,
+                                         pcm.ctypes.data, exc.ctypes.data if dumps else None)
         if r:
             raise RuntimeError("vocoder_stage")
         return (pcm, exc, None) if dumps else pcm

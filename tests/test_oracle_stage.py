@@ -137,3 +137,24 @@ def test_vocoder_stage_runs_and_is_linear_in_volume():
     c1 = O.stage_coefficients(mcp[0], 0.55, 0.4, False, 2, filtered=True)
     c2 = O.stage_coefficients(mcp[0], 0.55, 0.0, False, 2, filtered=False)
     assert np.array_equal(c0, c2) and not np.array_equal(c0, c1)
+
+
+def test_lsp_conversion_is_ill_conditioned():
+    """Why the GPU tests of this stage compare coefficients at 1e-6 and audio at 1e-4: the reference's
+    lsp2lpc (lsp.rs:58-86) expands the product of its second-order sections as a cascade whose partial
+    products (all low-frequency roots first) reach ~1e10 before the high-frequency sections cancel them,
+    so ONE ulp of relative change in the input moves the LPC by ~1e-9 and the filter coefficients by
+    ~1e-8 -- a property of the algorithm as written (two libm's cosines differ by that much)."""
+    L = 35
+    h = np.pi / L
+    lsp = np.concatenate([[0.05], h * np.arange(1, L)])
+    a = O.lsp2lpc(lsp)
+    c = O.stage_coefficients(lsp, 0.55, 0.0, False, 2)
+    rng = np.random.default_rng(0)
+    worst_a = worst_c = 0.0
+    for _ in range(20):
+        l2 = lsp * (1.0 + 2.2e-16 * rng.choice([-1.0, 1.0], L))
+        worst_a = max(worst_a, np.abs(O.lsp2lpc(l2) - a).max())
+        worst_c = max(worst_c, np.abs(O.stage_coefficients(l2, 0.55, 0.0, False, 2) - c).max() / np.abs(c).max())
+    print("one-ulp input change: LPC moves by", worst_a, "coefficients by", worst_c, "(relative)")
+    assert 1e-12 < worst_a < 1e-6 and 1e-11 < worst_c < 1e-6
