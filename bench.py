@@ -394,13 +394,36 @@ def run_config3(R, J, tab, vi, pset, args, steps, warmup):
     except Exception as e:
         err = repr(e)
 
-    def one_pass():
-        for utts in subs:
-            b = J.Batch(vi, utts, device=R.local_rank, pdf_set=pset)
+    def run_passes(n):
+        # n passes over this rank's sub-batches as one sequence.  The next sub-batch (of this pass or the
+        # next one) is created -- index upload, device gather, work list -- on a helper thread while the GPU
+        # runs the current one: two sub-batches resident at most, every creation inside the timed region
+        seq = [k for _ in range(n) for k in range(len(subs))]
+        nxt = {}
+
+        def make(i):
+            try:
+                nxt[i] = J.Batch(vi, subs[seq[i]], device=R.local_rank, pdf_set=pset)
+            except Exception as e:  # surfaces in the consuming iteration
+                nxt[i] = e
+
+        th = None
+        if seq:
+            make(0)
+        for i in range(len(seq)):
+            b = nxt.pop(i)
+            if isinstance(b, Exception):
+                raise b
             try:
                 b.run()
+                if i + 1 < len(seq):
+                    th = threading.Thread(target=make, args=(i + 1,))
+                    th.start()
                 b.sync()
             finally:
+                if th is not None:
+                    th.join()
+                    th = None
                 b.close()
 
     def passes(n):
@@ -408,8 +431,7 @@ def run_config3(R, J, tab, vi, pset, args, steps, warmup):
         if err is not None or R.dry:
             return
         try:
-            for _ in range(n):
-                one_pass()
+            run_passes(n)
         except Exception as e:
             err = repr(e)
 
@@ -531,6 +553,9 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
 
 
 def run_rank(args):
+    # the config-3 job keeps two sub-batches alive (one running, the next being created): let the
+    # library's device-memory pool hold both sets of blocks between passes (default cap 64 GB)
+    os.environ.setdefault("JB_DEVICE_POOL_MB", "160000")
     import torch  # first: so that this process uses ONE HIP runtime (same SONAME as ours)
 
     R = Ranks()

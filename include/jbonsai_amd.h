@@ -39,7 +39,7 @@ extern "C" {
 typedef enum jb_status {
     JB_OK = 0,
     JB_ERR_INVALID = -1,     /* bad argument / shape (reference: panics in src/speech.rs:32-40) */
-    JB_ERR_UNSUPPORTED = -2, /* nlpf==0, stages above 8, frame periods without a block divisor: off every BASELINE config */
+    JB_ERR_UNSUPPORTED = -2, /* stages above 8, nlpf > 63, frame periods without a block divisor: off every BASELINE config */
     JB_ERR_DEVICE = -3,      /* HIP error or no gfx950 device: the product never falls back to CPU */
     JB_ERR_MODEL = -4,       /* ModelError (src/model/mod.rs:31-46) */
     JB_ERR_LABEL = -5,       /* LabelError (src/label.rs:8-23) */

@@ -268,9 +268,13 @@ Batch::~Batch()
     if (device >= 0)
         hipSetDevice(device);
     // everything this batch enqueued has to be finished before another batch may get the memory
-    // or the streams
-    if (!allocs.empty() || stream)
-        hipDeviceSynchronize();
+    // or the streams: its own streams (and the legacy stream its memsets ran on), not the whole device --
+    // another batch of the process may be in the middle of a step
+    for (hipStream_t st : {stream, stream_lf0, stream_lpf, stream_voc})
+        if (st)
+            hipStreamSynchronize(st);
+    if (!allocs.empty())
+        hipStreamSynchronize(nullptr);
     for (auto &a : allocs)
         pool_free(device, a.first, a.second);
     if (ev0)
@@ -523,10 +527,9 @@ static int check_voice(const jb_voice_desc *v)
         set_error("The size of lf0 static vector must be 1."); // src/speech.rs:35-37
         return JB_ERR_INVALID;
     }
-    if (p.vector_length == 0) {
-        set_error("nlpf == 0 is not supported");
-        return JB_ERR_UNSUPPORTED;
-    }
+    // SpeechGenerator::new panics on an even LPF length, 0 included (speech.rs:38-40): the ring-buffer-less
+    // branch of Excitation::get (excitation.rs:87-100) can be reached through Vocoder::synthesize alone,
+    // never through Engine / SpeechGenerator, which is the boundary this library mirrors
     if (p.vector_length % 2 == 0) {
         set_error("The number of low-pass filter coefficient must be odd numbers."); // speech.rs:38-40
         return JB_ERR_INVALID;
@@ -888,7 +891,11 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         return rc;
     for (auto &c : b->up_chunks)
         c.host.reset(); // staging copies are not needed any more
-    e = hipDeviceSynchronize();
+    // uploads and memsets ran on the legacy stream, the gather and the constant tables on the batch's
+    // own: wait for those two, not for the device (another batch may be running a step)
+    e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess)
         return hip_fail(e, "upload");
     *out = b.release();
