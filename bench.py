@@ -554,8 +554,11 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
 
 def run_rank(args):
     # the config-3 job keeps two sub-batches alive (one running, the next being created): let the
-    # library's device-memory pool hold both sets of blocks between passes (default cap 64 GB)
-    os.environ.setdefault("JB_DEVICE_POOL_MB", "160000")
+    # library's device-memory pool hold both sets of blocks between passes (default cap 64 GB).  Not for
+    # the single-GPU default run: its secondary measurements create differently shaped batches, and a
+    # pool that fills the device turns their allocations into out-of-memory retries
+    if args.job == "config3" or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("JB_DEVICE_POOL_MB", "160000")
     import torch  # first: so that this process uses ONE HIP runtime (same SONAME as ours)
 
     R = Ranks()
