@@ -530,6 +530,26 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
         bd.close()
     except Exception as e:
         ex["distinct_64"] = {"error": repr(e)}
+    # (2b) two batches in flight (--pipeline 2): one batch's parameter generation beside the other's vocoder
+    try:
+        b2 = J.Batch(vi, batch_utts, device=R.local_rank)
+        pair = [batch, b2]
+        for b_ in pair:
+            b_.run()
+        for b_ in pair:
+            b_.sync()
+        t0 = time.perf_counter()
+        nst = 8
+        for k in range(nst):
+            if k >= 2:
+                pair[k % 2].sync()
+            pair[k % 2].run()
+        for b_ in pair:
+            b_.sync()
+        ex["two_batches_in_flight"] = {"ms_per_step": (time.perf_counter() - t0) / nst * 1e3}
+        b2.close()
+    except Exception as e:
+        ex["two_batches_in_flight"] = {"error": repr(e)}
     # (3) labels -> PCM on the host through the engine entry (front half on host threads, device gather,
     #     GPU hot path, staged D2H): 64 utterances of 75 x SAMPLE_SENTENCE_2
     try:

@@ -876,6 +876,10 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     if (b->flags & JB_BATCH_KEEP_TRACKS)
         if ((rc = b->dalloc(&vd.exc, b->total_samples, false)))
             return rc;
+    // frames whose excitation is the noise stream itself are not stored (not with the debug tap, which
+    // wants every sample, nor with the one-pass kernel for other tap counts / frame periods)
+    static const bool skip_off = getenv("JB_EXCITE_SKIP") && atoi(getenv("JB_EXCITE_SKIP")) == 0;
+    vd.skip_unvoiced = (!skip_off && !vd.exc && excite_is_split(vd)) ? 1 : 0;
     vd.state_stride = vd.stage > 0 ? mglsa_state_doubles(vd.stage) : vocoder_state_doubles(vd.nmcp);
     if ((rc = b->dalloc(&vd.state, (size_t)vd.state_stride * n, true)))
         return rc;

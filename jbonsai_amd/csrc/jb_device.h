@@ -132,7 +132,11 @@ struct VocDev {
     uint32_t *run_counter;     // [1] next run to hand out
     const double *noise;  // [noise_len] shared Gaussian stream
     uint64_t noise_len;
-    double *xin;          // [sumT*fperiod] excitation after the LPF mix and gain (k_excite)
+    double *xin;          // [sumT*fperiod] excitation after the LPF mix (k_excite*), gain not yet applied
+    // 1: frames that are unvoiced and follow an unvoiced frame (never the first of an utterance) have no
+    // entry in xin: their excitation IS the shared noise stream, x[n] = noise[n - (nlpf-1)/2]
+    // (excitation.rs:43-45,83-86), and the vocoder kernels read it there (exc_frame_ptr)
+    int skip_unvoiced;
     double *pcm;          // [sumT*fperiod] f64 PCM, or nullptr when the i16 sink is selected
     int16_t *pcm16;       // [sumT*fperiod] clamped i16 PCM (JB_BATCH_PCM_I16), or nullptr
     double *exc;          // optional [sumT*fperiod] excitation before gain, or nullptr
@@ -140,6 +144,16 @@ struct VocDev {
     int state_stride;     // doubles per utterance
     uint32_t ckpt_frames; // checkpoint position inside a chunk (frames past t_out); 0 = no checkpoints
 };
+
+// Where the vocoder finds the excitation of frame t of an utterance (base = its first frame in the
+// concatenated arrays): the stored row of xin, or -- for a frame the excitation kernels skipped -- the
+// shared noise stream at the frame's first sample minus the ring buffer's delay.
+__device__ __forceinline__ const double *exc_frame_ptr(const VocDev &vd, uint64_t base, uint32_t t)
+{
+    if (vd.skip_unvoiced && t >= 1 && !vd.voiced[base + t] && !vd.voiced[base + t - 1])
+        return vd.noise + ((uint64_t)t * (uint64_t)vd.fperiod - (uint64_t)((vd.nlpf - 1) / 2));
+    return vd.xin + (base + t) * (uint64_t)vd.fperiod;
+}
 
 // One unit of vocoder work: output frames [t_out, t_end) of utterance `utt`, with the
 // recursion started at t_start <= t_out (frames [t_start, t_out) are warm-up: computed,

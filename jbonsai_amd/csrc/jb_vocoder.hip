@@ -369,6 +369,10 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
     // needs the MSD voiced flags only, not the pitch track.  k_excite_fix repairs the rest.
     const bool vcur = NOISE_ONLY ? vd.voiced[f] != 0 : vd.pitch[f] != 0.0;
     const bool vprev = fr > 0 && (NOISE_ONLY ? vd.voiced[f - 1] != 0 : vd.pitch[f - 1] != 0.0);
+    // an unvoiced frame behind an unvoiced frame is the noise stream itself, delayed: nothing to store,
+    // the vocoder reads the noise table (VocDev::skip_unvoiced; 37 % of the frames of config 2)
+    if (vd.skip_unvoiced && fr >= 1 && !vcur && !vprev)
+        return;
     // ---- stage noise and e for samples m = -32 .. fp-1 of this frame ----
     // (all noise loads of the wave are issued before the first one is consumed: the wave is
     // latency-bound otherwise, one memory round trip per 64 samples)
@@ -784,7 +788,7 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
             const int i0 = q * bs; // first sample of block within frame
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)i0; // within utterance
             // excitation (gain applied) of this block, lane = sample (k_excite)
-            const double xin = lane < bs ? vd.xin[base * (uint64_t)fp + n0 + (uint64_t)lane] : 0.0;
+            const double xin = lane < bs ? exc_frame_ptr(vd, base, t)[i0 + lane] : 0.0;
             // =========== Phase B: bs serial filter steps ===========
             double ob = 0.0;
             for (int i = 0; i < bs; i++) {
@@ -1012,7 +1016,7 @@ __global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, Voc
                 f1s[0][pair] = exp((bcur[0] - bprev[0]) / (double)fp);
         }
         __syncthreads();
-        const double *xp = vd.xin + (base + t) * (uint64_t)fp;
+        const double *xp = exc_frame_ptr(vd, base, t);
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
         const double gq = f1s[0][pair];
@@ -1298,7 +1302,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 gqs[ci] = exp((bcur[0] - bprev[0]) / (double)fp);
         }
         __syncthreads();
-        const double *xp = vd.xin + (base + t) * (uint64_t)fp;
+        const double *xp = exc_frame_ptr(vd, base, t);
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
         const double gq = gqs[ci];
