@@ -317,6 +317,7 @@ __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 #define JB_BUILD_TF 32
 #endif
 constexpr int kBuildTF = JB_BUILD_TF;
+#define JB_MAX_WIN_BUILD 3 // windows served by the sliding-window build (static, delta, acceleration)
 constexpr int kMtMaxDim = 60; // (BW+1) * L * (kBuildTF+1) * 8 B <= 64 KiB of LDS for BW = 3
 template <int BW>
 __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd, int si)
@@ -420,6 +421,160 @@ __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd
         for (int j = 0; j < BW; j++)
             tile[j * plane + m * pitch + kl] = wuw[j];
         tile[BW * plane + m * pitch + kl] = wum;
+    }
+    __syncthreads();
+    const uint64_t row0 = base * (uint64_t)L, Tu = up->T;
+    for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
+        const int m = e / kBuildTF, kl = e % kBuildTF;
+        const uint32_t k = k0 + (uint32_t)kl;
+        if (k < Tv) {
+            const uint64_t o = row0 + (uint64_t)m * Tu + k;
+#pragma unroll
+            for (int j = 0; j < BW; j++)
+                sd.A[j][o] = tile[j * plane + m * pitch + kl];
+            sd.bvec[o] = tile[BW * plane + m * pitch + kl];
+        }
+    }
+}
+
+// Same kernel with the table loads of neighbouring frames SHARED.  k_mlpg_build_mt loads, for every
+// (frame, dim), mean and 1/var of up to three source frames of every window -- 18 loads per element,
+// 34 GB through the texture addressers for config 2, which is what its 4.8 ms are (10 % VALU busy,
+// 61 % of the wave cycles parked on memory).  Here a thread owns kBuildRun CONSECUTIVE frames of one
+// dim and slides a three-frame window over the table: 6 loads per element (2 for a one-tap window).
+// The arithmetic per element is the reference's loop nest, unchanged and in the same order
+// (test_fused_mlpg_equals_generic_bitwise holds it to the un-fused kernels bit for bit).
+constexpr int kBuildRun = 4;
+template <int BW>
+__global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
+{
+    extern __shared__ double tile[]; // [BW+1][L][kBuildTF+1]
+    constexpr int HW = BW / 2;       // frames a window can reach to either side
+    static_assert(BW == 3 && HW == 1, "written for three-tap windows");
+    __shared__ uint32_t f_state[kBuildTF + 2 * HW];
+    __shared__ uint8_t f_l[kBuildTF + 2 * HW], f_r[kBuildTF + 2 * HW];
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    const uint32_t Tv = sd.Tv[b];
+    const uint32_t k0 = blockIdx.x * (uint32_t)kBuildTF;
+    if (k0 >= Tv)
+        return;
+    const int L = sd.L, W = sd.W;
+    const StreamStatesDev st = up->st[si];
+    const uint64_t base = up->frame_off;
+    if (threadIdx.x < kBuildTF + 2 * HW) {
+        const long k = (long)k0 - HW + (long)threadIdx.x;
+        uint32_t s = 0;
+        uint8_t dl = 0, dr = 0;
+        if (k >= 0 && k < (long)Tv) {
+            const uint32_t f = sd.vidx[base + k];
+            s = sd.fstate[base + f];
+            dl = sd.fl[base + f];
+            dr = sd.fr[base + f];
+        }
+        f_state[threadIdx.x] = s;
+        f_l[threadIdx.x] = dl;
+        f_r[threadIdx.x] = dr;
+    }
+    __syncthreads();
+    const double *ivt = sd.ivar + up->state_off * (uint64_t)(W * L);
+    const double *mnt = st.mean;
+    const int pitch = kBuildTF + 1, plane = L * pitch;
+    const int WL = W * L;
+    constexpr int G = kBuildTF / kBuildRun; // runs per block
+    const int tid = threadIdx.x;
+    if (tid < G * L) {
+        const int g = tid / L, m = tid - g * L;
+        const int kl0 = g * kBuildRun;
+        // window state: per window w, (mean, masked 1/var) of the frames fi - 1, fi, fi + 1 of the block's
+        // frame window (fi = kl + HW is the frame itself); slot [w][0] = older, [w][2] = newer
+        double mvw[JB_MAX_WIN_BUILD][3], ivw[JB_MAX_WIN_BUILD][3];
+        auto fetch = [&](int w, int fi, double &mv, double &iv) {
+            const int ww = sd.win_width[w];
+            const int lw = ww / 2, rw = ww - lw - 1;
+            const uint64_t pi = (uint64_t)(f_state[fi] * (uint32_t)WL + (uint32_t)(L * w + m));
+            mv = mnt[pi];
+            double ivar = ivt[pi];
+            // dynamic windows touching an MSD boundary get ivar = 0 (mod.rs:69-80)
+            if (w != 0 && ((int)f_l[fi] < lw || (int)f_r[fi] < rw))
+                ivar = 0.0;
+            iv = ivar;
+        };
+#pragma unroll
+        for (int w = 0; w < JB_MAX_WIN_BUILD; w++) {
+            mvw[w][0] = mvw[w][1] = mvw[w][2] = 0.0;
+            ivw[w][0] = ivw[w][1] = ivw[w][2] = 0.0;
+            if (w < W) {
+                fetch(w, kl0 + HW, mvw[w][1], ivw[w][1]);
+                if (sd.win_width[w] > 1)
+                    fetch(w, kl0 + HW - 1, mvw[w][0], ivw[w][0]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kBuildRun; r++) {
+            const int kl = kl0 + r;
+            const uint32_t k = k0 + (uint32_t)kl;
+            // the newer neighbour of this frame (all windows' loads before any arithmetic)
+#pragma unroll
+            for (int w = 0; w < JB_MAX_WIN_BUILD; w++)
+                if (w < W) // (a one-tap window only ever uses it one frame later, as "itself")
+                    fetch(w, kl + HW + 1, mvw[w][2], ivw[w][2]);
+            if (k < Tv) {
+                double wuw[BW], wum = 0.0;
+#pragma unroll
+                for (int j = 0; j < BW; j++)
+                    wuw[j] = 0.0;
+                // the reference's loop nest (mlpg.rs:25-70), as in k_mlpg_build_mt
+#pragma unroll
+                for (int w = 0; w < JB_MAX_WIN_BUILD; w++) {
+                    if (w >= W)
+                        continue;
+                    const int ww = sd.win_width[w];
+                    const double *coef = sd.win_coef + sd.win_off[w];
+                    const int lw = ww / 2;
+                    double cf[3];
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+                        cf[i] = i < ww ? coef[i] : 0.0;
+#pragma unroll
+                    for (int index = 2; index >= 0; index--) {
+                        const int d = index - lw; // source frame k - d: d = +1 older, 0 itself, -1 newer
+                        const long idx = (long)k - (long)d;
+                        const bool ok = index < ww && idx >= 0 && idx < (long)Tv;
+                        // slot of the source frame in the sliding window (a one-tap window only has d = 0)
+                        const int slot = 1 - d;
+                        const double ivs = slot == 0 ? ivw[w][0] : (slot == 1 ? ivw[w][1] : ivw[w][2]);
+                        const double mvs = slot == 0 ? mvw[w][0] : (slot == 1 ? mvw[w][1] : mvw[w][2]);
+                        const double wu = ok ? cf[index] * ivs : 0.0;
+                        wum += wu * mvs;
+                        bool live = true; // the reference leaves the inner loop at the first tap past the end
+#pragma unroll
+                        for (int inner = 2; inner >= 0; inner--) {
+                            if (inner < index)
+                                continue;
+                            const int j = inner - index;
+                            // (a zero coefficient is skipped BEFORE the end test in the reference)
+                            if (cf[inner] != 0.0 && inner < ww && (uint64_t)k + (uint64_t)j >= Tv)
+                                live = false;
+                            if (live)
+                                wuw[j] += wu * cf[inner];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < BW; j++)
+                    tile[j * plane + m * pitch + kl] = wuw[j];
+                tile[BW * plane + m * pitch + kl] = wum;
+            }
+            // slide
+#pragma unroll
+            for (int w = 0; w < JB_MAX_WIN_BUILD; w++) {
+                mvw[w][0] = mvw[w][1];
+                ivw[w][0] = ivw[w][1];
+                mvw[w][1] = mvw[w][2];
+                ivw[w][1] = ivw[w][2];
+            }
+        }
     }
     __syncthreads();
     const uint64_t row0 = base * (uint64_t)L, Tu = up->T;
@@ -2184,7 +2339,16 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
         {
             dim3 grid((bd.maxT + kBuildTF - 1) / kBuildTF, bd.B), block(256);
             const size_t lds = sizeof(double) * (size_t)(BW + 1) * sd.L * (kBuildTF + 1);
-            hipLaunchKernelGGL(k_mlpg_build_mt<BW>, grid, block, lds, stream, bd, sd, si);
+            // sliding-window loads (k_mlpg_build_mt2) for up to three windows; JB_BUILD_V2=0: the
+            // element-per-thread kernel (same bits)
+            static const bool v2_off = getenv("JB_BUILD_V2") && atoi(getenv("JB_BUILD_V2")) == 0;
+            const int nthr = ((kBuildTF / kBuildRun) * sd.L + 63) / 64 * 64;
+            if (!v2_off && sd.W <= JB_MAX_WIN_BUILD && nthr <= 1024) {
+                dim3 b2((unsigned)(nthr < 64 ? 64 : nthr));
+                hipLaunchKernelGGL(k_mlpg_build_mt2<BW>, grid, b2, lds, stream, bd, sd, si);
+            } else {
+                hipLaunchKernelGGL(k_mlpg_build_mt<BW>, grid, block, lds, stream, bd, sd, si);
+            }
         }
         if (after_build)
             (void)hipEventRecord(after_build, stream);
