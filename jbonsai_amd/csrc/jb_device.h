@@ -90,7 +90,7 @@ struct StreamDev {
 };
 
 // Control block of one launch of k_mlpg_gv_gang (zeroed before the launch) and per-gang records.
-constexpr int kGvGangMaxTiles = 32; // workgroups per gang: rows of up to 32 x 3,904 frames
+constexpr int kGvGangMaxTiles = 64; // workgroups per gang (one poller lane each): rows of up to 64 tiles
 struct GvGangCtl {
     uint32_t tickets;  // next workgroup to start -> (gang, tile)
     uint32_t next_row; // row queue: (utterance, dim) rows in launch order

@@ -87,7 +87,10 @@ constexpr int kGgFPT = JB_GG_FPT;                    // frames per thread (conti
 constexpr int kGgWin = 64 * kGgFPT;                  // frames per wave window: 512
 constexpr int kGgHalo = 12;                          // >= 2 frames per ascent iteration x 5, rounded to 4
 constexpr int kGgOwn = kGgWin - 2 * kGgHalo;         // frames a wave owns: 488
-constexpr int kGgWaves = 8;
+#ifndef JB_GG_WAVES
+#define JB_GG_WAVES 8
+#endif
+constexpr int kGgWaves = JB_GG_WAVES;
 constexpr int kGgNT = 64 * kGgWaves;                 // threads per workgroup
 constexpr int kGgBlockOwn = kGgWaves * kGgOwn;       // frames a workgroup owns: 3,904
 constexpr uint32_t kGgPoison = 1u << 24;             // added to a gang counter that will never complete

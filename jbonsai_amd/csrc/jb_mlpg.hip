@@ -1486,10 +1486,14 @@ __global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd
     // ---- pass F: ldl_factorization + forward substitution (mlpg.rs:79-105) ----
     {
         const double *const in[4] = {sd.A[0] + row0, sd.A[1] + row0, sd.A[2] + row0, sd.bvec + row0};
-        double *const out[4] = {sd.F[0] + row0, sd.F[1] + row0, sd.F[2] + row0, sd.g + row0};
+        // what the backward pass needs of a frame: L1, L2 and g/D.  The quotient is formed HERE, off the
+        // recurrence's dependency chain and with the reciprocal of D_t that the factors already use (the
+        // same two operations on the same operands as mlpg.rs:108's division, so the same bits); the
+        // backward chain loses its division and D_t itself never goes to memory (-3.6 GB per step).
+        double *const out[3] = {sd.F[1] + row0, sd.F[2] + row0, sd.g + row0};
         double p1_0 = 0, p1_1 = 0, p1_2 = 0, p2_0 = 0, p2_2 = 0, g1 = 0, g2 = 0;
-        fl_pass<LMAX, 4, 4, false>(lds, in, out, n, L, rs,
-                                   [&](auto interior, uint32_t t, const double (&iv)[4], double (&ov)[4]) {
+        fl_pass<LMAX, 4, 3, false>(lds, in, out, n, L, rs,
+                                   [&](auto interior, uint32_t t, const double (&iv)[4], double (&ov)[3]) {
             constexpr bool IN = decltype(interior)::value;
             double r0 = iv[0], r1 = iv[1], r2 = iv[2], g = iv[3];
             if (IN || t >= 1)
@@ -1506,10 +1510,9 @@ __global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd
                 g -= p1_1 * g1;
             if (IN || t >= 2)
                 g -= p2_2 * g2;
-            ov[0] = r0;
-            ov[1] = r1;
-            ov[2] = r2;
-            ov[3] = g;
+            ov[0] = r1;
+            ov[1] = r2;
+            ov[2] = fb_div(g, r0, rr);
             p2_0 = p1_0;
             p2_2 = p1_2;
             g2 = g1;
@@ -1525,17 +1528,17 @@ __global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd
     __syncthreads();
     // ---- pass B: backward substitution (mlpg.rs:106-113), t descending ----
     {
-        const double *const in[4] = {sd.F[0] + row0, sd.F[1] + row0, sd.F[2] + row0, sd.g + row0};
+        const double *const in[3] = {sd.F[1] + row0, sd.F[2] + row0, sd.g + row0};
         double *const out[1] = {sd.par + row0};
         double q1 = 0, q2 = 0;
-        fl_pass<LMAX, 4, 1, true>(lds, in, out, n, L, rs,
-                                  [&](auto interior, uint32_t t, const double (&iv)[4], double (&ov)[1]) {
+        fl_pass<LMAX, 3, 1, true>(lds, in, out, n, L, rs,
+                                  [&](auto interior, uint32_t t, const double (&iv)[3], double (&ov)[1]) {
             constexpr bool IN = decltype(interior)::value;
-            double p = fb_div(iv[3], iv[0], fb_rcp(iv[0]));
+            double p = iv[2]; // g_t / D_t, from the forward pass
             if (IN || t + 1 < n)
-                p -= iv[1] * q1;
+                p -= iv[0] * q1;
             if (IN || t + 2 < n)
-                p -= iv[2] * q2;
+                p -= iv[1] * q2;
             ov[0] = p;
             q2 = q1;
             q1 = p;
