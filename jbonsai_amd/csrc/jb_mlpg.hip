@@ -313,6 +313,9 @@ __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 // kBuildTF contiguous frames per dim.  What depends on the frame alone (state index, MSD
 // boundary distances of the frame and its +-1 neighbours) is looked up once per block.
 // Same arithmetic, in the same order, as build_elem.
+#ifndef JB_FL_PROFILE
+#define JB_FL_PROFILE 0 // 1: block 3 prints the work / barrier-wait ticks of its solver and first mover per pass
+#endif
 #ifndef JB_BUILD_TF
 #define JB_BUILD_TF 32
 #endif
@@ -1362,16 +1365,21 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
             }
         }
     }
-    double regs[KI];
+    double regs_even[KI], regs_odd[KI];
 #pragma unroll
     for (int k = 0; k < KI; k++)
-        regs[k] = 0.0;
-    // Phase p: the solver works on chunk p.  A mover (1) parks chunk p+2 -- loaded during the
-    // previous phase, so its latency is already paid -- in its LDS slot, (2) issues the loads of
-    // chunk p+3 into the same registers, (3) drains the results of chunk p-1 to HBM.  The phase
+        regs_even[k] = regs_odd[k] = 0.0;
+    // Phase p: the solver works on chunk p.  A mover (1) parks chunk p+2 -- loaded TWO phases ago,
+    // so its latency is already paid -- in its LDS slot, (2) issues the loads of chunk p+4 into the
+    // same registers, (3) drains the results of chunk p-1 to HBM.  Two register sets alternate
+    // between the phases: with one (loads a single phase ahead) a phase lasted as long as a load
+    // under traffic, 1.7 us for 16 frames, about twice what the solver's chain needs.  The phase
     // barrier is a raw s_barrier behind lgkmcnt(0) only: __syncthreads() would also wait for the
     // stores of (3) (vmcnt(0)) and with them for the loads of (2).
-    for (int p = -3; p <= nch; p++) {
+#if JB_FL_PROFILE
+    long long t_work = 0, t_wait = 0, t0 = clock64();
+#endif
+    auto phase = [&](const int p, double (&regs)[KI]) {
         if (!solver) {
             const int cw = p + 2;
             if (cw >= 0 && cw < nch) {
@@ -1381,8 +1389,8 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
                     if (mt + kFlMovers * k < nei)
                         ib[e_l[k]] = regs[k];
             }
-            const int cl = p + 3;
-            if (cl < nch) {
+            const int cl = p + 4;
+            if (cl >= 0 && cl < nch) {
                 const long l0 = lo(cl);
                 if (l0 >= 0 && l0 + kFlCT <= (long)n) { // interior chunk: no per-frame checks
 #pragma unroll
@@ -1458,8 +1466,29 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if JB_FL_PROFILE
+        const long long t1 = clock64();
+        t_work += t1 - t0;
+#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+#if JB_FL_PROFILE
+        t0 = clock64();
+        t_wait += t0 - t1;
+#endif
+    };
+#if JB_FL_PROFILE
+    struct Report {
+        long long &w, &b; int nch; bool back;
+        __device__ ~Report() {
+            if (blockIdx.x == 3 && (threadIdx.x == 0 || threadIdx.x == 64))
+                printf("fl_pass %s thread %d: chunks %d work %lld wait %lld ticks\n", back ? "B" : "F", (int)threadIdx.x, nch, w, b);
+        }
+    } report{t_work, t_wait, nch, BACKWARD};
+#endif
+    for (int p = -4; p <= nch; p += 2) { // (an extra last phase finds nothing to do)
+        phase(p, regs_even);
+        phase(p + 1, regs_odd);
     }
 }
 

@@ -367,12 +367,23 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
     double(*nz)[kExwQ] = nz_s[wv];
     // NOISE_ONLY: every sample as if no pulse fell into its window (e = -noise in voiced frames);
     // needs the MSD voiced flags only, not the pitch track.  k_excite_fix repairs the rest.
-    const bool vcur = NOISE_ONLY ? vd.voiced[f] != 0 : vd.pitch[f] != 0.0;
-    const bool vprev = fr > 0 && (NOISE_ONLY ? vd.voiced[f - 1] != 0 : vd.pitch[f - 1] != 0.0);
-    // an unvoiced frame behind an unvoiced frame is the noise stream itself, delayed: nothing to store,
-    // the vocoder reads the noise table (VocDev::skip_unvoiced; 37 % of the frames of config 2)
-    if (vd.skip_unvoiced && fr >= 1 && !vcur && !vprev)
-        return;
+    // A wave is a chain of memory round trips (7 waves per SIMD hide only so many: the kernel ran 47 %
+    // VALU-busy at 2.1 TB/s of stores), so everything it will read from memory is requested HERE, in one
+    // go behind the utterance descriptor: both voiced flags, the noise, and the taps of this frame and of
+    // the previous one as one value per lane (the tap loops take them out with v_readlane: as scalar
+    // loads they were issued after the staging barrier, those of pass 2 in five dependent pieces).
+    const uint64_t fprev = fr > 0 ? f - 1 : f;
+    uint32_t vflag_c, vflag_p;
+    if (NOISE_ONLY) {
+        vflag_c = vd.voiced[f];
+        vflag_p = vd.voiced[fprev];
+    } else {
+        vflag_c = vd.pitch[f] != 0.0;
+        vflag_p = vd.pitch[fprev] != 0.0;
+    }
+    const double *tc = vd.lpf + f * (uint64_t)nlpf;
+    const double tcv = lane < NLPF ? tc[lane] : 0.0;
+    const double tpv = lane < NLPF ? vd.lpf[fprev * (uint64_t)nlpf + (uint64_t)lane] : 0.0;
     // ---- stage noise and e for samples m = -32 .. fp-1 of this frame ----
     // (all noise loads of the wave are issued before the first one is consumed: the wave is
     // latency-bound otherwise, one memory round trip per 64 samples)
@@ -384,6 +395,17 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
         const long g = (long)n0 + idx - kExwHalo;
         nvr[it] = (idx < fp + kExwHalo && g >= 0) ? vd.noise[g] : 0.0;
     }
+    const bool vcur = __builtin_amdgcn_readfirstlane((int)vflag_c) != 0;
+    const bool vprev = fr > 0 && __builtin_amdgcn_readfirstlane((int)vflag_p) != 0;
+    // an unvoiced frame behind an unvoiced frame is the noise stream itself, delayed: nothing to store,
+    // the vocoder reads the noise table (VocDev::skip_unvoiced; 37 % of the frames of config 2)
+    if (vd.skip_unvoiced && fr >= 1 && !vcur && !vprev)
+        return;
+    auto tap = [](double v, int k) { // value of lane k, wave-uniform (k is a constant after unrolling)
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
+        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+        return __hiloint2double(hi, lo);
+    };
 #pragma unroll
     for (int it = 0; it < kIt; it++) {
         const int idx = lane + 64 * it;
@@ -432,12 +454,11 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
         const int o = i0 + r - anti + kExwHalo;
         x[r] = ((long)n0 + i0 + r - anti >= 0) ? nz[o & (kExw - 1)][o >> 2] : 0.0;
     }
-    const double *tc = vd.lpf + f * (uint64_t)nlpf;
     if (vcur && own) {
         double ck[NLPF];
 #pragma unroll
         for (int k = 0; k < NLPF; k++)
-            ck[k] = tc[k];
+            ck[k] = tap(tcv, k);
         double w[kExwWin]; // w[c] = e[i0 - (NLPF-1) + c]
 #pragma unroll
         for (int c = 0; c < kExwWin; c++) {
@@ -457,7 +478,6 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
         // pass costs NLPF-1 FMAs per wave instead of 4*(NLPF-1) on eight busy lanes.  ep[] continues
         // with zeros where this frame starts: x + 0*c == x, the order of the remaining terms is the
         // tap order.
-        const double *tp = tc - nlpf;
         if (own && i0 < kExwHalo) {
 #pragma unroll
             for (int r = 0; r < kExw; r++)
@@ -466,12 +486,18 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < NLPF - 1 && lane < fp) {
-            double xv = xs[lane];
+        {
+            double tk[NLPF];
 #pragma unroll
             for (int k = 1; k < NLPF; k++)
-                xv = fma(ep[lane - k + kExwHalo], tp[k], xv);
-            xs[lane] = xv;
+                tk[k] = tap(tpv, k);
+            if (lane < NLPF - 1 && lane < fp) {
+                double xv = xs[lane];
+#pragma unroll
+                for (int k = 1; k < NLPF; k++)
+                    xv = fma(ep[lane - k + kExwHalo], tk[k], xv);
+                xs[lane] = xv;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1610,8 +1636,8 @@ hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t
 {
     if (bd.B == 0 || bd.maxT == 0 || !excite_is_split(vd))
         return hipSuccess;
-    dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
     static const bool no_swap = getenv("JB_EXCITE_UTT_FASTEST") && atoi(getenv("JB_EXCITE_UTT_FASTEST")) == 0;
+    dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
     const int swap = !no_swap && grid.x <= 65535u; // grid.y limit
     if (swap)
         grid = dim3(bd.B, (bd.maxT + 3) / 4);
