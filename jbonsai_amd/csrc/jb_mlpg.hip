@@ -313,11 +313,15 @@ __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 // kBuildTF contiguous frames per dim.  What depends on the frame alone (state index, MSD
 // boundary distances of the frame and its +-1 neighbours) is looked up once per block.
 // Same arithmetic, in the same order, as build_elem.
+#ifndef JB_BUILD_PROFILE
+#define JB_BUILD_PROFILE 0 // 1: a few blocks print the cycles of their sections
+#endif
 #ifndef JB_FL_PROFILE
 #define JB_FL_PROFILE 0 // 1: block 3 prints the work / barrier-wait ticks of its solver and first mover per pass
 #endif
 #ifndef JB_BUILD_TF
-#define JB_BUILD_TF 32
+#define JB_BUILD_TF 16 // 128-byte pieces per row reach the same HBM rate as longer ones (tools/microbench/piece_bw.hip)
+                       // and twice as many workgroups fit a CU: 16 frames 3.6 ms, 32 4.5, 64 4.6, 8 4.6
 #endif
 constexpr int kBuildTF = JB_BUILD_TF;
 #define JB_MAX_WIN_BUILD 3 // windows served by the sliding-window build (static, delta, acceleration)
@@ -447,7 +451,11 @@ __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd
 // dim and slides a three-frame window over the table: 6 loads per element (2 for a one-tap window).
 // The arithmetic per element is the reference's loop nest, unchanged and in the same order
 // (test_fused_mlpg_equals_generic_bitwise holds it to the un-fused kernels bit for bit).
-constexpr int kBuildRun = 4;
+#ifndef JB_BUILD_RUN
+#define JB_BUILD_RUN 4
+#endif
+constexpr int kBuildRun = JB_BUILD_RUN;
+typedef const double __attribute__((address_space(1))) *Gp;
 template <int BW>
 __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
 {
@@ -462,6 +470,9 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
     const uint32_t k0 = blockIdx.x * (uint32_t)kBuildTF;
     if (k0 >= Tv)
         return;
+#if JB_BUILD_PROFILE
+    const long long pt0 = clock64();
+#endif
     const int L = sd.L, W = sd.W;
     const StreamStatesDev st = up->st[si];
     const uint64_t base = up->frame_off;
@@ -470,7 +481,8 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
         uint32_t s = 0;
         uint8_t dl = 0, dr = 0;
         if (k >= 0 && k < (long)Tv) {
-            const uint32_t f = sd.vidx[base + k];
+            // (a stream without MSD keeps every frame: one memory round trip less before the table loads)
+            const uint32_t f = sd.is_msd ? sd.vidx[base + k] : (uint32_t)k;
             s = sd.fstate[base + f];
             dl = sd.fl[base + f];
             dr = sd.fr[base + f];
@@ -480,24 +492,31 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
         f_r[threadIdx.x] = dr;
     }
     __syncthreads();
+#if JB_BUILD_PROFILE
+    const long long pt1 = clock64();
+#endif
     const double *ivt = sd.ivar + up->state_off * (uint64_t)(W * L);
     const double *mnt = st.mean;
     const int pitch = kBuildTF + 1, plane = L * pitch;
     const int WL = W * L;
     constexpr int G = kBuildTF / kBuildRun; // runs per block
     const int tid = threadIdx.x;
+    // interior block: frames k0-1 .. k0+TF+1 all exist (sources k-1..k+1, band columns k..k+2)
+    const bool interior = k0 >= 1 && (uint64_t)k0 + kBuildTF + 2 <= (uint64_t)Tv;
     if (tid < G * L) {
         const int g = tid / L, m = tid - g * L;
         const int kl0 = g * kBuildRun;
-        // window state: per window w, (mean, masked 1/var) of the frames fi - 1, fi, fi + 1 of the block's
-        // frame window (fi = kl + HW is the frame itself); slot [w][0] = older, [w][2] = newer
-        double mvw[JB_MAX_WIN_BUILD][3], ivw[JB_MAX_WIN_BUILD][3];
+        // ALL table values of the run -- (mean, masked 1/var) of frames kl0-1 .. kl0+kBuildRun of every
+        // window -- are requested before the first is used; loaded frame by frame as the window slides,
+        // every frame of the run was its own memory round trip.
+        double mvr[JB_MAX_WIN_BUILD][kBuildRun + 2], ivr[JB_MAX_WIN_BUILD][kBuildRun + 2];
+        const Gp mng = (Gp)mnt, ivg = (Gp)ivt; // global, not generic: the tables come from hipMalloc
         auto fetch = [&](int w, int fi, double &mv, double &iv) {
             const int ww = sd.win_width[w];
             const int lw = ww / 2, rw = ww - lw - 1;
-            const uint64_t pi = (uint64_t)(f_state[fi] * (uint32_t)WL + (uint32_t)(L * w + m));
-            mv = mnt[pi];
-            double ivar = ivt[pi];
+            const uint32_t pi = f_state[fi] * (uint32_t)WL + (uint32_t)(L * w + m);
+            mv = mng[pi];
+            double ivar = ivg[pi];
             // dynamic windows touching an MSD boundary get ivar = 0 (mod.rs:69-80)
             if (w != 0 && ((int)f_l[fi] < lw || (int)f_r[fi] < rw))
                 ivar = 0.0;
@@ -505,81 +524,123 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
         };
 #pragma unroll
         for (int w = 0; w < JB_MAX_WIN_BUILD; w++) {
-            mvw[w][0] = mvw[w][1] = mvw[w][2] = 0.0;
-            ivw[w][0] = ivw[w][1] = ivw[w][2] = 0.0;
-            if (w < W) {
-                fetch(w, kl0 + HW, mvw[w][1], ivw[w][1]);
-                if (sd.win_width[w] > 1)
-                    fetch(w, kl0 + HW - 1, mvw[w][0], ivw[w][0]);
+#pragma unroll
+            for (int q = 0; q < kBuildRun + 2; q++) {
+                mvr[w][q] = ivr[w][q] = 0.0;
+                // a one-tap window never looks at its neighbours
+                if (w < W && (sd.win_width[w] > 1 || (q >= 1 && q <= kBuildRun)))
+                    fetch(w, kl0 + HW - 1 + q, mvr[w][q], ivr[w][q]);
             }
         }
+        // One window's share of one frame (mlpg.rs:25-70).  R (frame of the run), the window and its left
+        // width are compile-time constants, so that every operand is a named register: with a run-time
+        // frame index the compiler kept the run as a loop and picked the operands out of the arrays with
+        // chains of v_cndmask (171 of the ~450 VALU instructions per frame).
+        // INTERIOR: every source frame and band column exists -- the edge tests are constants and what is
+        // left branches on the window shape alone, width and zero coefficients, the same for all lanes.
+        // The reference SKIPS a zero coefficient (mlpg.rs:38,47); the general form multiplies by it and
+        // adds exact zeros instead, which changes no bit (the accumulators start at +0 and are never -0).
+        auto window = [&](auto RC, auto WC, auto LWC, auto INC, const uint32_t k, double (&wuw)[BW], double &wum) {
+            constexpr int R = decltype(RC)::value, Wn = decltype(WC)::value, LW = decltype(LWC)::value;
+            constexpr bool INTERIOR = decltype(INC)::value;
+            const int ww = sd.win_width[Wn];
+            const double *coef = sd.win_coef + sd.win_off[Wn];
+            double cf[3];
 #pragma unroll
-        for (int r = 0; r < kBuildRun; r++) {
-            const int kl = kl0 + r;
-            const uint32_t k = k0 + (uint32_t)kl;
-            // the newer neighbour of this frame (all windows' loads before any arithmetic)
+            for (int i = 0; i < 3; i++)
+                cf[i] = i < ww ? coef[i] : 0.0;
 #pragma unroll
-            for (int w = 0; w < JB_MAX_WIN_BUILD; w++)
-                if (w < W) // (a one-tap window only ever uses it one frame later, as "itself")
-                    fetch(w, kl + HW + 1, mvw[w][2], ivw[w][2]);
-            if (k < Tv) {
-                double wuw[BW], wum = 0.0;
-#pragma unroll
-                for (int j = 0; j < BW; j++)
-                    wuw[j] = 0.0;
-                // the reference's loop nest (mlpg.rs:25-70), as in k_mlpg_build_mt
-#pragma unroll
-                for (int w = 0; w < JB_MAX_WIN_BUILD; w++) {
-                    if (w >= W)
+            for (int index = 2; index >= 0; index--) {
+                // source frame k - d, d = index - LW: slot R + 1 - d of the run's values
+                const int d = index - LW;
+                const int sl = R + 1 - d;
+                const int slc = sl < 0 ? 0 : (sl > kBuildRun + 1 ? kBuildRun + 1 : sl);
+                const double ivs = ivr[Wn][slc], mvs = mvr[Wn][slc];
+                if (INTERIOR) {
+                    if (index >= ww || cf[index] == 0.0)
                         continue;
-                    const int ww = sd.win_width[w];
-                    const double *coef = sd.win_coef + sd.win_off[w];
-                    const int lw = ww / 2;
-                    double cf[3];
+                    const double wu = cf[index] * ivs;
+                    wum += wu * mvs;
 #pragma unroll
-                    for (int i = 0; i < 3; i++)
-                        cf[i] = i < ww ? coef[i] : 0.0;
+                    for (int inner = 2; inner >= 0; inner--) {
+                        if (inner < index || inner >= ww || cf[inner] == 0.0)
+                            continue;
+                        wuw[inner - index] += wu * cf[inner];
+                    }
+                } else {
+                    const long idx = (long)k - (long)d;
+                    const bool ok = index < ww && idx >= 0 && idx < (long)Tv;
+                    const double wu = ok ? cf[index] * ivs : 0.0;
+                    wum += wu * mvs;
+                    bool live = true; // the reference leaves the inner loop at the first tap past the end
 #pragma unroll
-                    for (int index = 2; index >= 0; index--) {
-                        const int d = index - lw; // source frame k - d: d = +1 older, 0 itself, -1 newer
-                        const long idx = (long)k - (long)d;
-                        const bool ok = index < ww && idx >= 0 && idx < (long)Tv;
-                        // slot of the source frame in the sliding window (a one-tap window only has d = 0)
-                        const int slot = 1 - d;
-                        const double ivs = slot == 0 ? ivw[w][0] : (slot == 1 ? ivw[w][1] : ivw[w][2]);
-                        const double mvs = slot == 0 ? mvw[w][0] : (slot == 1 ? mvw[w][1] : mvw[w][2]);
-                        const double wu = ok ? cf[index] * ivs : 0.0;
-                        wum += wu * mvs;
-                        bool live = true; // the reference leaves the inner loop at the first tap past the end
-#pragma unroll
-                        for (int inner = 2; inner >= 0; inner--) {
-                            if (inner < index)
-                                continue;
-                            const int j = inner - index;
-                            // (a zero coefficient is skipped BEFORE the end test in the reference)
-                            if (cf[inner] != 0.0 && inner < ww && (uint64_t)k + (uint64_t)j >= Tv)
-                                live = false;
-                            if (live)
-                                wuw[j] += wu * cf[inner];
-                        }
+                    for (int inner = 2; inner >= 0; inner--) {
+                        if (inner < index)
+                            continue;
+                        const int j = inner - index;
+                        // (a zero coefficient is skipped BEFORE the end test in the reference)
+                        if (cf[inner] != 0.0 && inner < ww && (uint64_t)k + (uint64_t)j >= Tv)
+                            live = false;
+                        if (live)
+                            wuw[j] += wu * cf[inner];
                     }
                 }
-#pragma unroll
-                for (int j = 0; j < BW; j++)
-                    tile[j * plane + m * pitch + kl] = wuw[j];
-                tile[BW * plane + m * pitch + kl] = wum;
             }
-            // slide
+        };
+        auto frame = [&](auto RC, auto INC) {
+            constexpr int R = decltype(RC)::value;
+            const int kl = kl0 + R;
+            const uint32_t k = k0 + (uint32_t)kl;
+            if (!decltype(INC)::value && k >= Tv)
+                return;
+            double wuw[BW], wum = 0.0;
 #pragma unroll
-            for (int w = 0; w < JB_MAX_WIN_BUILD; w++) {
-                mvw[w][0] = mvw[w][1];
-                ivw[w][0] = ivw[w][1];
-                mvw[w][1] = mvw[w][2];
-                ivw[w][1] = ivw[w][2];
+            for (int j = 0; j < BW; j++)
+                wuw[j] = 0.0;
+            auto one = [&](auto WC) {
+                constexpr int Wn = decltype(WC)::value;
+                if (Wn >= W)
+                    return;
+                if (sd.win_width[Wn] / 2 == 0)
+                    window(RC, WC, std::integral_constant<int, 0>{}, INC, k, wuw, wum);
+                else
+                    window(RC, WC, std::integral_constant<int, 1>{}, INC, k, wuw, wum);
+            };
+            one(std::integral_constant<int, 0>{});
+            one(std::integral_constant<int, 1>{});
+            one(std::integral_constant<int, 2>{});
+#pragma unroll
+            for (int j = 0; j < BW; j++)
+                tile[j * plane + m * pitch + kl] = wuw[j];
+            tile[BW * plane + m * pitch + kl] = wum;
+        };
+        auto run = [&](auto INC) {
+            static_assert(kBuildRun == 2 || kBuildRun == 4 || kBuildRun == 8, "frames of a run, written out");
+            frame(std::integral_constant<int, 0>{}, INC);
+            frame(std::integral_constant<int, 1>{}, INC);
+            if constexpr (kBuildRun > 2) {
+                frame(std::integral_constant<int, 2>{}, INC);
+                frame(std::integral_constant<int, 3>{}, INC);
             }
-        }
+            if constexpr (kBuildRun > 4) {
+                frame(std::integral_constant<int, 4>{}, INC);
+                frame(std::integral_constant<int, 5>{}, INC);
+                frame(std::integral_constant<int, 6>{}, INC);
+                frame(std::integral_constant<int, 7>{}, INC);
+            }
+        };
+        if (interior)
+            run(std::true_type{});
+        else
+            run(std::false_type{});
     }
+#if JB_BUILD_PROFILE
+    const long long pt2 = clock64();
+#endif
     __syncthreads();
+#if JB_BUILD_PROFILE
+    const long long pt3 = clock64();
+#endif
     const uint64_t row0 = base * (uint64_t)L, Tu = up->T;
     for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
         const int m = e / kBuildTF, kl = e % kBuildTF;
@@ -592,6 +653,13 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
             sd.bvec[o] = tile[BW * plane + m * pitch + kl];
         }
     }
+#if JB_BUILD_PROFILE
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long pt4 = clock64();
+    if (blockIdx.y == 3 && blockIdx.x % 200 == 100 && (threadIdx.x == 0 || threadIdx.x == 256))
+        printf("build_mt2 block %d thread %d: desc %lld compute %lld barrier %lld store %lld cycles\n", (int)blockIdx.x,
+               (int)threadIdx.x, pt1 - pt0, pt2 - pt1, pt3 - pt2, pt4 - pt3);
+#endif
 }
 
 // --------------------------------------------------------------------------
