@@ -1096,7 +1096,9 @@ static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
     // LPF chain (width-1 static window: one bandwidth-bound kernel): held back until the MCP
     // build is done (ev_mcpbuild), so that it runs under the latency-bound band solve instead of
     // beside the equally bandwidth-bound ivar/build kernels at the head of the step
-    hipStreamWaitEvent(b->stream_lpf, b->ev_mcpbuild, 0);
+    static const bool lpf_early = getenv("JB_LPF_EARLY") && atoi(getenv("JB_LPF_EARLY")) != 0; // A/B aid
+    if (!lpf_early)
+        hipStreamWaitEvent(b->stream_lpf, b->ev_mcpbuild, 0);
     if (b->voice.nstream > 2) {
         if ((e = launch_prep(b->bd, b->sd[2], 2, b->stream_lpf)) != hipSuccess)
             return e;

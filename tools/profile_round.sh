@@ -8,13 +8,15 @@ R=${1:-r02}
 out=gpurun_out/prof_$R
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
+# counters first: the bench line quotes them (profiles/${R}_traffic.json, profiles/${R}_pmc_sq_k_vocoder_lt.txt)
+bash tools/pmc_voc.sh > $out/${R}_pmc_sq_k_vocoder_lt.txt 2>&1 && cp $out/${R}_pmc_sq_k_vocoder_lt.txt profiles/
+bash tools/traffic.sh > $out/traffic.log 2>&1 && cp profiles/traffic.json $out/${R}_traffic.json && cp profiles/traffic.json profiles/${R}_traffic.json
 python bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 STEPS=4 bash tools/kstats.sh > $out/${R}_kernel_ms_per_step.txt 2>&1
 cp gpurun_out/kstats/k_kernel_stats.csv $out/${R}_kernel_stats.csv
 python tools/timeline.py > $out/${R}_timeline_one_step.txt
 JB_ONE_STREAM=1 STEPS=4 bash tools/kstats.sh > $out/${R}_kernel_ms_per_step_one_stream.txt 2>&1
-bash tools/pmc_voc.sh > $out/${R}_pmc_sq_k_vocoder_lt.txt 2>&1
 KERNEL=k_mlpg_gv_gang bash tools/pmc_voc.sh > $out/${R}_pmc_sq_k_mlpg_gv_gang.txt 2>&1
-bash tools/traffic.sh > $out/traffic.log 2>&1 && cp profiles/traffic.json $out/${R}_traffic.json
 bash tools/gg_prof.sh > $out/${R}_gv_gang_sections.txt 2>&1
+bash tools/shapes.sh > $out/${R}_shapes.txt 2>&1
 ls -la $out
