@@ -537,91 +537,137 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     const uint32_t T = u->T;
     const uint64_t base = u->frame_off;
     const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
-    // a wave walks kFixFrames frames (most leave at once): 8x fewer workgroups for the dispatcher,
-    // which otherwise spends the launch slots of concurrently running kernels on empty blocks
-    for (int jf = 0; jf < kFixFrames; jf++) {
-    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
-    if (fr >= T)
-        break;
-    const uint64_t f = base + fr;
-    if (!vd.voiced[f])
-        continue;
-    unsigned long long any = 0ull;
-    for (int q = 0; q < nblk; q++)
-        any |= vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
-    if (any == 0ull)
-        continue;
     constexpr int H = NLPF - 1;
     static_assert(2 * H + 1 <= 64, "window must fit one wave");
     const int anti = H / 2;
-    const long n0 = (long)fr * (long)fp;
     const long N = (long)T * (long)fp;
     __shared__ double es_s[4][2 * H + 1]; // e[p-H .. p+H] of the current pulse
     __shared__ double tp_s[4][3][NLPF];   // taps of frames fr-1, fr, fr+1
     double *es = es_s[wv];
     double(*tp3)[NLPF] = tp_s[wv];
-    if (lane < NLPF) {
+    // A wave walks kFixFrames frames, frame index = (block * kFixFrames + jf) * 4 + wave (most leave at
+    // once: 8x fewer workgroups for the dispatcher).  What decides whether a frame has work -- its pulse
+    // mask words -- is fetched for all of them in ONE request (lane = frame x word), where the loop used to
+    // pay a round trip for the voiced flag and another for the mask of every frame: the kernel's time is
+    // (waves in flight) x (round trips per wave), beside the resident GV kernel with a quarter of the waves.
+    unsigned long long mword = 0ull;
+    uint32_t vfl = 0; // voiced flag of frame jf in lane jf (the masks of unvoiced frames are never written)
+    {
+        const uint32_t frv = (blockIdx.x * (uint32_t)kFixFrames + (uint32_t)lane) * 4u + (uint32_t)wv;
+        if (lane < kFixFrames && frv < T)
+            vfl = vd.voiced[base + frv];
+    }
+    {
+        const int jf = lane / 4, q = lane & 3; // up to four mask words per frame (kFixFrames * 4 <= 64)
+        const uint32_t frl = (blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv;
+        if (jf < kFixFrames && q < nblk && frl < T)
+            mword = vd.pmask[(base + frl) * (uint64_t)nblk + (uint64_t)q];
+    }
+    static_assert(kFixFrames * 4 <= 64, "one lane per (frame, mask word)");
+    const bool wide = nblk > 4; // (fperiod > 4 * bs: the words beyond the fourth are fetched in the loop)
+    for (int jf = 0; jf < kFixFrames; jf++) {
+        const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
+            (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
+        if (fr >= T)
+            break;
+        const uint64_t f = base + fr;
+        if (__builtin_amdgcn_readlane((int)vfl, jf) == 0)
+            continue;
+        unsigned long long any = 0ull;
+        for (int q = 0; q < 4; q++) {
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, jf * 4 + q);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), jf * 4 + q);
+            any |= ((unsigned long long)hi << 32) | lo;
+        }
+        if (wide)
+            for (int q = 4; q < nblk; q++)
+                any |= vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
+        if (any == 0ull)
+            continue;
+        const long n0 = (long)fr * (long)fp;
+        // taps of the three frames a window can touch: requested here, needed after the window is staged
+        double tpv[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const long ff = (long)fr - 1 + j;
-            tp3[j][lane] = (ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
+            tpv[j] = (lane < NLPF && ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
         }
-    }
-    for (int q = 0; q < nblk; q++) {
-        unsigned long long word = vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
-        // wave-uniform by construction; tell the compiler
-        word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(word >> 32)) << 32) |
-               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
-        while (word) {
-            const int j = __builtin_ctzll(word);
-            word &= word - 1ull;
-            const int p = q * bs + j;
-            // ---- e over the window m = p-H+lane (frame-relative), lanes 0..2H ----
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane <= 2 * H) {
-                const int m = p - H + lane;
-                const long g = n0 + m;
-                const bool in = g >= 0 && g < N;
-                // unconditional loads at clamped positions, selected afterwards (loads nested in
-                // the edge / voicing tests would be waited for one after the other)
-                const long gc = in ? g : n0;
-                const int df = !in ? 0 : (m < 0 ? -1 : (m >= fp ? 1 : 0));
-                const uint64_t ff = (uint64_t)((long)f + df);
-                const int i = in ? m - df * fp : 0;
-                const bool vo = vd.voiced[ff] != 0;
-                const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
-                const double pinc = vd.pinc[ff], cur = vd.cur_start[ff], nv = vd.noise[gc];
+        bool taps_parked = false;
+        for (int q = 0; q < nblk; q++) {
+            unsigned long long word;
+            if (q < 4) {
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, jf * 4 + q);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), jf * 4 + q);
+                word = ((unsigned long long)hi << 32) | lo;
+            } else {
+                word = vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
+                // wave-uniform by construction; tell the compiler
+                word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(word >> 32)) << 32) |
+                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
+            }
+            while (word) {
+                const int j = __builtin_ctzll(word);
+                word &= word - 1ull;
+                const int p = q * bs + j;
+                // ---- e over the window m = p-H+lane (frame-relative), lanes 0..2H; the start value of
+                // the targets n = n0 + p + lane, lanes 0..H, in the same request ----
+                const long n = n0 + p + lane;
+                const bool tgt = lane <= H && n < N;
+                const double x0 = (tgt && n >= anti) ? vd.noise[n - anti] : 0.0;
                 double ev = 0.0;
-                if (in && vo) {
-                    double pulse = 0.0;
-                    if ((pm >> (i % bs)) & 1ull)
-                        pulse = sqrt(fma((double)i, pinc, cur));
-                    ev = pulse - nv;
+                if (lane <= 2 * H) {
+                    const int m = p - H + lane;
+                    const long g = n0 + m;
+                    const bool in = g >= 0 && g < N;
+                    // unconditional loads at clamped positions, selected afterwards (loads nested in
+                    // the edge / voicing tests would be waited for one after the other)
+                    const long gc = in ? g : n0;
+                    const int df = !in ? 0 : (m < 0 ? -1 : (m >= fp ? 1 : 0));
+                    const uint64_t ff = (uint64_t)((long)f + df);
+                    const int i = in ? m - df * fp : 0;
+                    const bool vo = vd.voiced[ff] != 0;
+                    const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
+                    const double pinc = vd.pinc[ff], cur = vd.cur_start[ff], nv = vd.noise[gc];
+                    if (in && vo) {
+                        double pulse = 0.0;
+                        if ((pm >> (i % bs)) & 1ull)
+                            pulse = sqrt(fma((double)i, pinc, cur));
+                        ev = pulse - nv;
+                    }
                 }
-                es[lane] = ev;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // ---- targets n = n0 + p + lane, lanes 0..H ----
-            const long n = n0 + p + lane;
-            if (lane <= H && n < N) {
-                double x = n >= anti ? vd.noise[n - anti] : 0.0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier(); // the previous pulse's reads of es[] are done
+                if (lane <= 2 * H)
+                    es[lane] = ev;
+                if (!taps_parked) {
+                    if (lane < NLPF) {
 #pragma unroll
-                for (int k = 0; k < NLPF; k++) {
-                    const int ms = p + lane - k; // frame-relative source sample
-                    const int sel = ms < 0 ? 0 : (ms >= fp ? 2 : 1);
-                    x = fma(es[lane + H - k], tp3[sel][k], x);
+                        for (int t3 = 0; t3 < 3; t3++)
+                            tp3[t3][lane] = tpv[t3];
+                    }
+                    taps_parked = true;
                 }
-                const uint64_t o = base * (uint64_t)fp + (uint64_t)n;
-                vd.xin[o] = x;
-                if (vd.exc)
-                    vd.exc[o] = x;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (tgt) {
+                    double x = x0;
+#pragma unroll
+                    for (int k = 0; k < NLPF; k++) {
+                        const int ms = p + lane - k; // frame-relative source sample
+                        const int sel = ms < 0 ? 0 : (ms >= fp ? 2 : 1);
+                        x = fma(es[lane + H - k], tp3[sel][k], x);
+                    }
+                    const uint64_t o = base * (uint64_t)fp + (uint64_t)n;
+                    vd.xin[o] = x;
+                    if (vd.exc)
+                        vd.exc[o] = x;
+                }
             }
         }
-    }
+        // the next frame with pulses overwrites tp3: this frame's reads of it are done
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     } // frames of this wave
 }
 
