@@ -316,6 +316,18 @@ __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 #ifndef JB_BUILD_PROFILE
 #define JB_BUILD_PROFILE 0 // 1: a few blocks print the cycles of their sections
 #endif
+#ifndef JB_VT_FUSE2
+#define JB_VT_FUSE2 1
+#endif
+#ifndef JB_FL_SPLIT
+#define JB_FL_SPLIT 1
+#endif
+#ifndef JB_FL_SCHED
+#define JB_FL_SCHED 0
+#endif
+#ifndef JB_FL_LP_CONST
+#define JB_FL_LP_CONST 1
+#endif
 #ifndef JB_FL_PROFILE
 #define JB_FL_PROFILE 0 // 1: block 3 prints the work / barrier-wait ticks of its solver and first mover per pass
 #endif
@@ -1362,9 +1374,11 @@ __global__ __launch_bounds__(64) void k_mlpg_fb_mt(BatchDev bd, StreamDev sd, in
 // chain (two f64 divisions per frame in the factorisation) and the kernel as a whole by HBM.
 constexpr int kFlCT = 16;  // frames per chunk
 constexpr int kFlIn = 3;   // input slots (chunk p being solved, p+1 parked, p+2 arriving)
-constexpr int kFlOut = 2;  // output slots (chunk p being written, p-1 draining)
-constexpr int kFlNT = 256; // threads per block
+constexpr int kFlOut = 3;  // output slots (chunk p being written, p-1 waiting, p-2 draining)
+constexpr int kFlNT = 256; // threads per block: the solver wave and three mover waves (a wave per SIMD: with a
+                           // fifth wave two share a SIMD's registers, 256 each, and the solver's spill to scratch)
 constexpr int kFlMovers = kFlNT - 64;
+constexpr int kFlGroups = kFlMovers / 64; // mover groups (one wave each)
 
 // IEEE-754 double division as the compiler expands it (v_rcp_f64, two Newton steps, quotient,
 // residual correction) minus v_div_scale / v_div_fixup, with the refined reciprocal shared between
@@ -1398,100 +1412,115 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
     const int tid = threadIdx.x, lane = tid & 63;
     const bool solver = tid < 64;
     const int mt = tid - 64;
+    // the tile pitch of the MCP instantiation is a constant, not the stream's L: LDS addresses are then base +
+    // immediate offset (with a run-time pitch the solver spent 4 of its 42 instructions per frame forming them)
+    // (the pitch must stay odd: the movers walk a tile frame-fastest, and with 36 doubles between frames
+    // their LDS accesses collide eight ways -- the kernel took 11.9 ms instead of 5.6)
+#if JB_FL_LP_CONST
+    const int LP = LMAX == 36 ? 37 : L;
+#else
     const int LP = L;
+#endif
     const int nch = (int)((n + kFlCT - 1) / kFlCT);
     double *inb = lds;                                // [kFlIn][NIN][kFlCT][LP]
     double *outb = lds + kFlIn * 4 * kFlCT * LP;      // [kFlOut][NOUT][kFlCT][LP]
     auto lo = [&](int c) { return BACKWARD ? (long)n - (long)(c + 1) * kFlCT : (long)c * kFlCT; };
-    // mover element list, fixed per thread for the whole pass: element e = mt + 192k ->
-    // (array a, dim m, frame-in-chunk tt); the same decomposition serves inputs (e < NIN*L*CT)
-    // and outputs (e < NOUT*L*CT).  Pointers to frame tt of the row are formed once.
-    constexpr int KI = (NIN * LMAX * kFlCT + kFlMovers - 1) / kFlMovers;
-    constexpr int KO = (NOUT * LMAX * kFlCT + kFlMovers - 1) / kFlMovers;
-    const int nei = NIN * L * kFlCT, neo = NOUT * L * kFlCT;
-    const double *pin[KI];
-    double *pout[KO];
-    uint32_t e_l[KI], e_tt[KI];
-    if (!solver) {
+    // MOVERS: kFlGroups waves; wave g owns the chunks c = g (mod kFlGroups) from HBM to HBM -- it loads chunk
+    // c during phase c-2-kFlGroups, parks it in LDS during phase c-2 (and loads its next chunk), drains its
+    // results during phase c+2 and idles otherwise.  A thread so holds ONE set of prefetch registers, filled
+    // kFlGroups phases before it is read, and a CU keeps kFlGroups chunks (54 KB for MCP) in flight: with two
+    // (loads two phases ahead) the kernel moved 36 KB per ~3 us of loaded-HBM latency and CU, 2.9 TB/s.
+    // (The first form had every mover do all three jobs every phase with two register sets alternating;
+    // whether the compiler kept the sets apart, or funnelled both through the same registers and waited for
+    // every load where it was issued, changed with unrelated edits to this function: 5.6 or 11.5 ms.)
+    // Element list of a thread, the same for every array: j = mtl + GT*kk -> (dim m, frame-in-chunk tt).
+    constexpr int GT = 64, NG = kFlGroups;
+    constexpr int KPA = (LMAX * kFlCT + GT - 1) / GT; // 9 for MCP, 1 for LF0
+    const int grp = mt >> 6, mtl = mt & 63;
+    uint64_t goff[KPA]; // m*rs + tt: the element in a [dim][frame] array
+    uint32_t loff[KPA]; // tt*LP + m: the element in one array's tile
+    uint32_t ett[KPA];
+    bool val[KPA];
 #pragma unroll
-        for (int k = 0; k < KI; k++) {
-            const int e = mt + kFlMovers * k;
-            const int tt = e % kFlCT, am = e / kFlCT, m = am % L, a = am / L;
-            e_l[k] = (uint32_t)((a * kFlCT + tt) * LP + m);
-            e_tt[k] = (uint32_t)tt;
-            const double *src = in[0];
-#pragma unroll
-            for (int q = 1; q < NIN; q++)
-                src = a == q ? in[q] : src;
-            pin[k] = src + (uint64_t)m * rs + (uint64_t)tt;
-            if (k < KO) {
-                double *dst = out[0];
-#pragma unroll
-                for (int q = 1; q < NOUT; q++)
-                    dst = a == q ? out[q] : dst;
-                pout[k] = dst + (uint64_t)m * rs + (uint64_t)tt;
-            }
-        }
+    for (int kk = 0; kk < KPA; kk++) {
+        const int j = mtl + GT * kk;
+        const int tt = j % kFlCT, m = j / kFlCT;
+        val[kk] = !solver && m < L;
+        const int mc = m < L ? m : 0; // (an element past the tile: a valid address, never parked or stored)
+        goff[kk] = (uint64_t)mc * rs + (uint64_t)tt;
+        loff[kk] = (uint32_t)(tt * LP + mc);
+        ett[kk] = (uint32_t)tt;
     }
-    double regs_even[KI], regs_odd[KI];
+    double regs[NIN][KPA];
 #pragma unroll
-    for (int k = 0; k < KI; k++)
-        regs_even[k] = regs_odd[k] = 0.0;
-    // Phase p: the solver works on chunk p.  A mover (1) parks chunk p+2 -- loaded TWO phases ago,
-    // so its latency is already paid -- in its LDS slot, (2) issues the loads of chunk p+4 into the
-    // same registers, (3) drains the results of chunk p-1 to HBM.  Two register sets alternate
-    // between the phases: with one (loads a single phase ahead) a phase lasted as long as a load
-    // under traffic, 1.7 us for 16 frames, about twice what the solver's chain needs.  The phase
-    // barrier is a raw s_barrier behind lgkmcnt(0) only: __syncthreads() would also wait for the
-    // stores of (3) (vmcnt(0)) and with them for the loads of (2).
+    for (int a2 = 0; a2 < NIN; a2++)
+#pragma unroll
+        for (int kk = 0; kk < KPA; kk++)
+            regs[a2][kk] = 0.0;
+    // Phase p: the solver works on chunk p.  The phase barrier is a raw s_barrier behind lgkmcnt(0) only:
+    // __syncthreads() would also wait for the movers' stores and loads in flight (vmcnt(0)).
 #if JB_FL_PROFILE
     long long t_work = 0, t_wait = 0, t0 = clock64();
 #endif
-    auto phase = [&](const int p, double (&regs)[KI]) {
-        if (!solver) {
-            const int cw = p + 2;
+    auto mover_phase = [&](const int p) {
+        if ((((p + 2) % NG) + NG) % NG == grp) {
+            const int cw = p + 2; // loaded NG phases ago
             if (cw >= 0 && cw < nch) {
                 double *ib = inb + (cw % kFlIn) * NIN * kFlCT * LP;
 #pragma unroll
-                for (int k = 0; k < KI; k++)
-                    if (mt + kFlMovers * k < nei)
-                        ib[e_l[k]] = regs[k];
+                for (int a2 = 0; a2 < NIN; a2++)
+#pragma unroll
+                    for (int kk = 0; kk < KPA; kk++)
+                        if (val[kk])
+                            ib[a2 * kFlCT * LP + loff[kk]] = regs[a2][kk];
             }
-            const int cl = p + 4;
+            const int cl = p + 2 + NG;
             if (cl >= 0 && cl < nch) {
                 const long l0 = lo(cl);
-                if (l0 >= 0 && l0 + kFlCT <= (long)n) { // interior chunk: no per-frame checks
+                if (l0 >= 0 && l0 + kFlCT <= (long)n) { // interior chunk: no per-frame checks, and
+                                                        // UNCONDITIONAL loads (no branch per load)
 #pragma unroll
-                    for (int k = 0; k < KI; k++)
-                        if (mt + kFlMovers * k < nei)
-                            regs[k] = pin[k][l0];
+                    for (int a2 = 0; a2 < NIN; a2++)
+#pragma unroll
+                        for (int kk = 0; kk < KPA; kk++)
+                            regs[a2][kk] = in[a2][goff[kk] + (uint64_t)l0];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < KI; k++) {
-                        const long t = l0 + (long)e_tt[k];
-                        regs[k] = (mt + kFlMovers * k < nei && t >= 0 && t < (long)n) ? pin[k][l0] : 0.0;
-                    }
+                    for (int a2 = 0; a2 < NIN; a2++)
+#pragma unroll
+                        for (int kk = 0; kk < KPA; kk++) {
+                            const long t = l0 + (long)ett[kk];
+                            regs[a2][kk] = (val[kk] && t >= 0 && t < (long)n) ? in[a2][(long)goff[kk] + l0] : 0.0;
+                        }
                 }
             }
-            const int cs = p - 1;
+        } else if ((((p - 2) % NG) + NG) % NG == grp) {
+            const int cs = p - 2; // solved two phases ago (with three groups p-1 is the parking group's class)
             if (cs >= 0 && cs < nch) {
                 const long l0 = lo(cs);
                 const double *ob = outb + (cs % kFlOut) * NOUT * kFlCT * LP;
                 if (l0 >= 0 && l0 + kFlCT <= (long)n) {
 #pragma unroll
-                    for (int k = 0; k < KO; k++)
-                        if (mt + kFlMovers * k < neo)
-                            pout[k][l0] = ob[e_l[k]];
+                    for (int a2 = 0; a2 < NOUT; a2++)
+#pragma unroll
+                        for (int kk = 0; kk < KPA; kk++)
+                            if (val[kk])
+                                out[a2][goff[kk] + (uint64_t)l0] = ob[a2 * kFlCT * LP + loff[kk]];
                 } else {
 #pragma unroll
-                    for (int k = 0; k < KO; k++) {
-                        const long t = l0 + (long)e_tt[k];
-                        if (mt + kFlMovers * k < neo && t >= 0 && t < (long)n)
-                            pout[k][l0] = ob[e_l[k]];
-                    }
+                    for (int a2 = 0; a2 < NOUT; a2++)
+#pragma unroll
+                        for (int kk = 0; kk < KPA; kk++) {
+                            const long t = l0 + (long)ett[kk];
+                            if (val[kk] && t >= 0 && t < (long)n)
+                                out[a2][(long)goff[kk] + l0] = ob[a2 * kFlCT * LP + loff[kk]];
+                        }
                 }
             }
-        } else if (p >= 0 && p < nch && lane < L) {
+        }
+    };
+    auto solver_phase = [&](const int p) {
+        if (p >= 0 && p < nch && lane < L) {
             const long l0 = lo(p);
             const double *ib = inb + (p % kFlIn) * NIN * kFlCT * LP;
             double *ob = outb + (p % kFlOut) * NOUT * kFlCT * LP;
@@ -1506,6 +1535,11 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
                 for (int a = 0; a < NIN; a++)
                     ivs[u][a] = ib[(a * kFlCT + tt) * LP + lane];
             }
+            // (with a compile-time tile pitch the compiler CAN tell them apart and sinks every read next
+            // to its use again: the kernel took 11.5 ms instead of 5.5)
+#if JB_FL_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             if (l0 >= 2 && l0 + kFlCT + 2 <= (long)n) {
                 // interior chunk: every frame exists and has both neighbours on either side, so
                 // the recurrences run without their edge guards (same operations, same order)
@@ -1533,6 +1567,8 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
                 }
             }
         }
+    };
+    auto phase_end = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #if JB_FL_PROFILE
         const long long t1 = clock64();
@@ -1554,9 +1590,13 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
         }
     } report{t_work, t_wait, nch, BACKWARD};
 #endif
-    for (int p = -4; p <= nch; p += 2) { // (an extra last phase finds nothing to do)
-        phase(p, regs_even);
-        phase(p + 1, regs_odd);
+    static_assert(kFlGroups == 3 && kFlOut == 3, "roles: park c-2 / drain c+2 fall on different groups for 3");
+    for (int p = -2 - kFlGroups; p <= nch + 1; p++) {
+        if (solver)
+            solver_phase(p);
+        else
+            mover_phase(p);
+        phase_end();
     }
 }
 
@@ -1756,9 +1796,9 @@ __device__ __forceinline__ double serial_add64(double acc, double v)
 }
 
 // Loads of kVtNB blocks of 64 frames are issued together before their serial sums run, so a
-// lone wave pays one memory latency per 256 frames instead of one per 64.
+// lone wave pays one memory latency per 512 frames instead of one per 64.
 #ifndef JB_VT_NB
-#define JB_VT_NB 4
+#define JB_VT_NB 8 // 4: 3.08 ms, 8: 2.85, 16: 2.90 (LF0 of config 2, alone)
 #endif
 constexpr int kVtNB = JB_VT_NB;
 
@@ -1792,6 +1832,38 @@ __device__ __forceinline__ double serial_add_lds(double acc, const double *buf)
         __builtin_amdgcn_sched_barrier(0);
     }
     return acc;
+}
+
+// Two independent in-order sums side by side (variance and HMM objective of an ascent iteration): each is
+// a chain of dependent v_add_f64, and two chains fill the slots that one leaves empty.
+__device__ __forceinline__ void serial_add2_lds(double &acc_a, const double *buf_a, double &acc_b, const double *buf_b)
+{
+    const double2 *a2 = reinterpret_cast<const double2 *>(buf_a), *b2 = reinterpret_cast<const double2 *>(buf_b);
+    double2 x[2][4], y[2][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        x[0][u] = a2[u];
+        y[0][u] = b2[u];
+    }
+#pragma unroll
+    for (int g = 0; g < 8; g++) {
+        if (g < 7) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                x[(g + 1) & 1][u] = a2[4 * (g + 1) + u];
+                y[(g + 1) & 1][u] = b2[4 * (g + 1) + u];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            acc_a += x[g & 1][u].x;
+            acc_b += y[g & 1][u].x;
+            acc_a += x[g & 1][u].y;
+            acc_b += y[g & 1][u].y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 template <bool NONMSD>
@@ -1956,9 +2028,13 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
 #pragma unroll
             for (int q = 0; q < kVtNB; q++)
                 if (tb + 64u * q < n) {
-                    vsum = serial_add_lds(vsum, sbuf[0][q]);
                     // hmmobj has no switch: frames beyond n contribute nothing (exact: + 0.0)
+#if JB_VT_FUSE2
+                    serial_add2_lds(vsum, sbuf[0][q], hmmobj, sbuf[1][q]);
+#else
+                    vsum = serial_add_lds(vsum, sbuf[0][q]);
                     hmmobj = serial_add_lds(hmmobj, sbuf[1][q]);
+#endif
                 }
         }
         vari = vsum / glen;
@@ -2408,14 +2484,15 @@ static void launch_fb_lds(const BatchDev &bd, const StreamDev &sd, int si, size_
 static void launch_fb(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
 {
     static const bool use_lds = !(getenv("JB_FB_LDS") && atoi(getenv("JB_FB_LDS")) == 0);
-    const size_t lds = sizeof(double) * (size_t)(kFlIn * 4 + kFlOut * 4) * kFlCT * (size_t)sd.L;
-    if (use_lds && sd.L <= 64 && lds <= 160 * 1024) {
+    // per dim of the tile pitch: input slots of four arrays, output slots of at most three (L1, L2, g/D)
+    const size_t lds1 = sizeof(double) * (size_t)(kFlIn * 4 + kFlOut * 3) * kFlCT;
+    if (use_lds && sd.L <= 64 && lds1 * (size_t)sd.L <= 160 * 1024) {
         if (sd.L == 1)
-            launch_fb_lds<1>(bd, sd, si, lds, stream);
+            launch_fb_lds<1>(bd, sd, si, lds1, stream);
         else if (sd.L <= 36)
-            launch_fb_lds<36>(bd, sd, si, lds, stream);
+            launch_fb_lds<36>(bd, sd, si, lds1 * (JB_FL_LP_CONST ? 37 : (size_t)sd.L), stream); // tile pitch (fl_pass)
         else
-            launch_fb_lds<64>(bd, sd, si, lds, stream);
+            launch_fb_lds<64>(bd, sd, si, lds1 * (size_t)sd.L, stream); // up to 160 KB: the whole LDS of a CU
     } else {
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         hipLaunchKernelGGL(k_mlpg_fb_mt, grid, block, 0, stream, bd, sd, si);
