@@ -1085,18 +1085,21 @@ int Batch::enqueue_vocoder()
 // main stream, LF0 -> pitch -> pulse schedule and LPF on side streams, forked after
 // whatever the main stream was doing (a previous run may still read the tracks) and
 // joined before the vocoder.
-// Hook of the MCP chain, called between its band solve and its GV sweeps: the pulse-free
-// excitation pass goes onto the main stream there.  Run beside the band solve or the GV sweeps it
-// stretched both by more than its own 7 ms (memory-heavy kernels do not overlap well here);
-// the LF0 / LPF chains it depends on are long done at that point.
+// Hook of the MCP chain, called between its band solve and its GV sweeps: enqueues the LPF chain and
+// the pulse-free excitation pass (side stream by default; on the main stream, at this point of the MCP
+// chain, with JB_EXCITE_SIDE=0).
 static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
 {
     Batch *b = (Batch *)ctx;
     hipError_t e;
-    // LPF chain (width-1 static window: one bandwidth-bound kernel): held back until the MCP
-    // build is done (ev_mcpbuild), so that it runs under the latency-bound band solve instead of
-    // beside the equally bandwidth-bound ivar/build kernels at the head of the step
-    static const bool lpf_early = getenv("JB_LPF_EARLY") && atoi(getenv("JB_LPF_EARLY")) != 0; // A/B aid
+    // LPF chain (width-1 static window: one bandwidth-bound kernel) and, behind it on the same side stream,
+    // the pulse-free excitation pass: both start with the step, beside the MCP build and band solve.
+    // (Until the band solve shed a third of its traffic and its movers their stalls, beside it the
+    // excitation pass stretched both by more than its own time, and it ran on the main stream between band
+    // solve and GV instead, with the LPF chain held back until the MCP build was done: step 98.8 ms that
+    // way now, 97.8 this way -- the pulse repair pass, which needs this one, then starts ~4 ms earlier.
+    // JB_EXCITE_SIDE=0 / JB_LPF_EARLY=0 restore the old order, A/B aids.)
+    static const bool lpf_early = !(getenv("JB_LPF_EARLY") && atoi(getenv("JB_LPF_EARLY")) == 0);
     if (!lpf_early)
         hipStreamWaitEvent(b->stream_lpf, b->ev_mcpbuild, 0);
     if (b->voice.nstream > 2) {
@@ -1106,11 +1109,7 @@ static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
             return e;
     }
     hipEventRecord(b->ev_lpf, b->stream_lpf);
-    // The pulse-free excitation pass goes onto the main stream between band solve and GV.  Beside
-    // either it stretches both by more than its own time -- the phase is throughput bound as a whole:
-    // with the resident GV kernel, 12.9 + 16.3 ms side by side against 6.2 + 9.1 ms one after the
-    // other, step 103.3 against 101.5 ms (JB_EXCITE_SIDE=1 puts it on the LPF stream, A/B aid).
-    static const bool side_env = getenv("JB_EXCITE_SIDE") && atoi(getenv("JB_EXCITE_SIDE")) != 0;
+    static const bool side_env = !(getenv("JB_EXCITE_SIDE") && atoi(getenv("JB_EXCITE_SIDE")) == 0);
     const bool side = side_env && b->stream_lpf != stream;
     hipStream_t es = side ? b->stream_lpf : stream;
     hipStreamWaitEvent(es, b->ev_prep, 0); // voiced flags (LF0 state walk)

@@ -527,6 +527,9 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
 // bit-identical to the one-pass form.  Samples covered by two pulses are written twice with the
 // same value.
 constexpr int kFixFrames = 8;
+#ifndef JB_FIX_UNROLL
+#define JB_FIX_UNROLL 8
+#endif
 
 template <int NLPF>
 __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
@@ -652,7 +655,10 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 if (tgt) {
                     double x = x0;
-#pragma unroll
+                    // (eight taps at a time: fully unrolled, the compiler fetches all operands first and
+                    // the kernel needs 52 VGPRs -- with 48 two of its waves fit a SIMD beside the resident
+                    // GV kernel's two of 208, with 52 one)
+#pragma unroll JB_FIX_UNROLL
                     for (int k = 0; k < NLPF; k++) {
                         const int ms = p + lane - k; // frame-relative source sample
                         const int sel = ms < 0 ? 0 : (ms >= fp ? 2 : 1);
