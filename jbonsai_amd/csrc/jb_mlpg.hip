@@ -2513,6 +2513,10 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             dim3 grid((unsigned)((ne + 255) / 256), bd.B), block(256);
             hipLaunchKernelGGL(k_mlpg_ivar, grid, block, 0, stream, bd, sd, si);
         }
+        // A/B aid: JB_LPF_AFTER_IVAR=1 records the caller's event here instead of behind the build
+        static const bool ev_after_ivar = getenv("JB_LPF_AFTER_IVAR") && atoi(getenv("JB_LPF_AFTER_IVAR")) != 0;
+        if (after_build && ev_after_ivar)
+            (void)hipEventRecord(after_build, stream);
         {
             dim3 grid((bd.maxT + kBuildTF - 1) / kBuildTF, bd.B), block(256);
             const size_t lds = sizeof(double) * (size_t)(BW + 1) * sd.L * (kBuildTF + 1);
@@ -2527,7 +2531,7 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
                 hipLaunchKernelGGL(k_mlpg_build_mt<BW>, grid, block, lds, stream, bd, sd, si);
             }
         }
-        if (after_build)
+        if (after_build && !ev_after_ivar)
             (void)hipEventRecord(after_build, stream);
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         const bool tp = sd.use_gv && !sd.serial_gv && sd.gv_part;
