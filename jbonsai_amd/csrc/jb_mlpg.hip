@@ -294,11 +294,17 @@ __global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
     sd.bvec[o] = wum;
 }
 
+#ifndef JB_CHAIN_PRIO
+#define JB_CHAIN_PRIO 0 // s_setprio level of the MCP chain's throughput kernels (A/B aid; 0 = default)
+#endif
 // MeanVari::with_ivar per (state, window, dim), once per batch: a frame's inverse variance is
 // its state's, and each is used by up to three neighbouring frames of every window, so the
 // table replaces ~6 f64 divisions per (frame, dim) in the build by loads.
 __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 {
+#if JB_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(JB_CHAIN_PRIO);
+#endif
     const int b = blockIdx.y;
     const UttDev *up = bd.utt + b;
     const uint32_t WL = (uint32_t)(sd.W * sd.L);
@@ -474,6 +480,9 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
     extern __shared__ double tile[]; // [BW+1][L][kBuildTF+1]
     constexpr int HW = BW / 2;       // frames a window can reach to either side
     static_assert(BW == 3 && HW == 1, "written for three-tap windows");
+#if JB_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(JB_CHAIN_PRIO); // MCP chain = critical path of the step: ahead of side-stream waves
+#endif
     __shared__ uint32_t f_state[kBuildTF + 2 * HW];
     __shared__ uint8_t f_l[kBuildTF + 2 * HW], f_r[kBuildTF + 2 * HW];
     const int b = blockIdx.y;
