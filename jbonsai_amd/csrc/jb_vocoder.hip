@@ -1231,6 +1231,9 @@ constexpr int DPP_WAVE_SHL1 = 0x130;
 #define JB_LT_CHUNKS 21
 #endif
 constexpr int kLtChunks = JB_LT_CHUNKS;
+#ifndef JB_LT_XASM
+#define JB_LT_XASM 1 // excitation load outside the compiler's vmcnt bookkeeping, counted wait (0: plain load)
+#endif
 #ifndef JB_LT_PF
 #define JB_LT_PF 4
 #endif
@@ -1385,14 +1388,49 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
         const double gq = gqs[ci];
+#if !JB_LT_XASM
         // PCM leaves the lead lane 32 bytes at a time (8-byte stores cost a sector each)
         double o0 = 0.0, o1 = 0.0, o2 = 0.0;
         const bool quad = (fp & 3) == 0;
+#endif
+#if JB_LT_XASM
+        // The next sample's excitation is requested at the top of a sample and used at the top of the next
+        // one, a whole sample (~1.5 us) later.  Two things made that load cost 3.7 of the kernel's 66 ms
+        // (measured by removing it): it sat behind a per-lane test (`act ? ... : 0`), which splits the
+        // sample's straight-line code at the top, and the wait in front of its use is vmcnt(0), which every
+        // fourth sample also waited for the PCM stores the sample before had just issued.  So: the load is
+        // unconditional (a lane without work reads the noise table: a valid address, finite values it
+        // never uses) and an asm statement with its own wait; and the PCM leaves the lead lane in PAIRS,
+        // one sample late -- at the top of a sample, before the load is issued, so that what the wait
+        // covers is a whole sample old.  (Moving the excitation through an LDS ring filled by LDS-DMA, and
+        // a wait that counts the stores, both cost more than they saved: tools/experiments/.)
+        const double *xq = act ? xp : vd.noise;
+        const bool pairm = (fp & 1) == 0;
+        double oA = 0.0, oB = 0.0;
+        auto put_pair = [&](int at) { // samples at, at+1 of this frame
+            if (vd.pcm16)
+                *reinterpret_cast<uint32_t *>(vd.pcm16 + (base + t) * (uint64_t)fp + at) = pcm_i16x2(oA, oB);
+            else
+                *reinterpret_cast<double2 *>(op + at) = make_double2(oA, oB);
+        };
+#endif
         for (int i = 0; i < fp; i++) {
+#if JB_LT_XASM
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory");
+            double x = xn * gain;
+            gain *= gq;
+            if (pairm && (i & 1) == 0 && i > 0 && emit)
+                put_pair(i - 2);
+            {
+                const int nx = i + 1 < fp ? i + 1 : i; // (the last sample re-reads itself: nothing past the row)
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn) : "v"(xq + nx) : "memory");
+            }
+#else
             double x = xn * gain;
             gain *= gq;
             if (i + 1 < fp)
                 xn = act ? xp[i + 1] : 0.0;
+#endif
             const double fi = (double)i;
             // ---- V6 df1 (mlsa.rs:54-66): every lane runs it, the lead lane's copy is kept ----
             {
@@ -1519,6 +1557,19 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             u[1] = y[0];
             u[0] = pos == 0 ? xmid : yprev;
             const double pv = x * vol;
+#if JB_LT_XASM
+            if (pairm) {
+                if ((i & 1) == 0)
+                    oA = pv;
+                else
+                    oB = pv;
+            } else if (emit) {
+                if (vd.pcm16)
+                    vd.pcm16[(base + t) * (uint64_t)fp + i] = (int16_t)pcm_i16(pv);
+                else
+                    op[i] = pv;
+            }
+#else
             if (quad) {
                 const int ph = i & 3;
                 if (ph == 0)
@@ -1542,7 +1593,13 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 else
                     op[i] = pv;
             }
+#endif
         }
+#if JB_LT_XASM
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory"); // the last sample's (unused) request
+        if (pairm && emit)
+            put_pair(fp - 2);
+#endif
         if (act && tl + 1 == nfr) {
             double *se_ = work[item].save_end;
             if (se_)
