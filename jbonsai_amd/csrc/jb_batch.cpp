@@ -927,7 +927,9 @@ int Batch::build_work(const jb_batch_opts *opts)
     uint64_t lp_min = 190000;
     if (const char *e = getenv("JB_LP_MIN_FRAMES"))
         lp_min = strtoull(e, nullptr, 10);
+    // (the lane-triple kernel walks the samples of a frame two at a time)
     lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vd.stage == 0 && vocoder_ls_supported(vd.nmcp) &&
+              (vd.fperiod & 1) == 0 &&
               (sumT >= lp_min || (flags & JB_BATCH_PAIR_KERNEL));
     if (serial) {
         ch = 0;

@@ -1232,7 +1232,8 @@ constexpr int DPP_WAVE_SHL1 = 0x130;
 #endif
 constexpr int kLtChunks = JB_LT_CHUNKS;
 #ifndef JB_LT_XASM
-#define JB_LT_XASM 1 // excitation load outside the compiler's vmcnt bookkeeping, counted wait (0: plain load)
+#define JB_LT_XASM 2 // excitation load outside the compiler's vmcnt bookkeeping: 2 = two samples ahead (needs an
+                     // even frame period), 1 = one sample ahead, 0 = plain load behind the per-lane test
 #endif
 #ifndef JB_LT_PF
 #define JB_LT_PF 4
@@ -1414,8 +1415,40 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 *reinterpret_cast<double2 *>(op + at) = make_double2(oA, oB);
         };
 #endif
+#if JB_LT_XASM == 2
+        // TWO samples ahead, the sample loop unrolled by two: x of even samples lives in xn, of odd ones in
+        // xo.  An even sample waits with vmcnt(1): everything but the youngest operation, the odd sample's
+        // request, is then done -- its own request and the older pair store.  An odd sample waits with
+        // vmcnt(0): what is younger than its request, the even sample's store and request, is a whole
+        // sample old.  (Counting that store as well, vmcnt(2), is wrong: stores are not retired in order
+        // with loads -- the hand-off check caught it, every chunk was redone.)
+        double xo;
+        {
+            const int n1 = fp > 1 ? 1 : 0;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xo) : "v"(xq + n1) : "memory");
+        }
+        auto sample = [&](const int i, auto ODDC) {
+            constexpr bool ODD = decltype(ODDC)::value;
+            double x;
+            if (ODD) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(xo)::"memory");
+                x = xo * gain;
+            } else {
+                asm volatile("s_waitcnt vmcnt(1)" : "+v"(xn)::"memory");
+                x = xn * gain;
+            }
+            gain *= gq;
+            if (!ODD && i > 0 && emit)
+                put_pair(i - 2);
+            {
+                const int nx = i + 2 < fp ? i + 2 : fp - 1; // (the last samples re-read the last: nothing past the row)
+                if (ODD)
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xo) : "v"(xq + nx) : "memory");
+                else
+                    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn) : "v"(xq + nx) : "memory");
+            }
+#elif JB_LT_XASM
         for (int i = 0; i < fp; i++) {
-#if JB_LT_XASM
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory");
             double x = xn * gain;
             gain *= gq;
@@ -1426,6 +1459,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn) : "v"(xq + nx) : "memory");
             }
 #else
+        for (int i = 0; i < fp; i++) {
             double x = xn * gain;
             gain *= gq;
             if (i + 1 < fp)
@@ -1557,7 +1591,22 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             u[1] = y[0];
             u[0] = pos == 0 ? xmid : yprev;
             const double pv = x * vol;
-#if JB_LT_XASM
+#if JB_LT_XASM == 2
+            if (ODD)
+                oB = pv;
+            else
+                oA = pv;
+        };
+        // (this form needs an even frame period: checked on the host, which otherwise builds chunks for
+        // the wave kernel)
+        for (int i2 = 0; i2 < fp; i2 += 2) {
+            sample(i2, std::false_type{});
+            sample(i2 + 1, std::true_type{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xo)::"memory"); // the last samples' (unused) requests
+        if (emit)
+            put_pair(fp - 2);
+#elif JB_LT_XASM
             if (pairm) {
                 if ((i & 1) == 0)
                     oA = pv;
@@ -1594,8 +1643,10 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                     op[i] = pv;
             }
 #endif
+#if JB_LT_XASM != 2
         }
-#if JB_LT_XASM
+#endif
+#if JB_LT_XASM == 1
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory"); // the last sample's (unused) request
         if (pairm && emit)
             put_pair(fp - 2);
