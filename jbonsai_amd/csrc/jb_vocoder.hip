@@ -1231,6 +1231,9 @@ constexpr int DPP_WAVE_SHL1 = 0x130;
 #define JB_LT_CHUNKS 21
 #endif
 constexpr int kLtChunks = JB_LT_CHUNKS;
+#ifndef JB_LT_PROFILE
+#define JB_LT_PROFILE 0 // 1: one wave prints the cycles of its frame set-ups and of its sample loops
+#endif
 #ifndef JB_LT_XASM
 #define JB_LT_XASM 2 // excitation load outside the compiler's vmcnt bookkeeping: 2 = two samples ahead (needs an
                      // even frame period), 1 = one sample ahead, 0 = plain load behind the per-lane test
@@ -1354,7 +1357,13 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         }
     };
 
+#if JB_LT_PROFILE
+    long long pt_setup = 0, pt_samples = 0;
+#endif
     for (uint32_t tl = 0; tl < maxfr; tl++) {
+#if JB_LT_PROFILE
+        const long long pt0 = clock64();
+#endif
         const bool act = tl < nfr;
         const uint32_t t = wk.t_start + (act ? tl : 0);
         const uint64_t f = base + t;
@@ -1389,6 +1398,10 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
         const double gq = gqs[ci];
+#if JB_LT_PROFILE
+        const long long pt1 = clock64();
+        pt_setup += pt1 - pt0;
+#endif
 #if !JB_LT_XASM
         // PCM leaves the lead lane 32 bytes at a time (8-byte stores cost a sector each)
         double o0 = 0.0, o1 = 0.0, o2 = 0.0;
@@ -1651,12 +1664,19 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         if (pairm && emit)
             put_pair(fp - 2);
 #endif
+#if JB_LT_PROFILE
+        pt_samples += clock64() - pt1;
+#endif
         if (act && tl + 1 == nfr) {
             double *se_ = work[item].save_end;
             if (se_)
                 save_state(se_);
         }
     }
+#if JB_LT_PROFILE
+    if (blockIdx.x == 777 && lane == 0)
+        printf("k_vocoder_lt wave 777: %u frames, setup %lld cycles, samples %lld cycles\n", maxfr, pt_setup, pt_samples);
+#endif
 }
 
 // --------------------------------------------------------------------------
