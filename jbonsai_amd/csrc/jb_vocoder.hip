@@ -520,6 +520,167 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
     }
 }
 
+// The pulse-free pass once more, trimmed for instruction count: k_excite_w4<NLPF, true> spends two thirds of
+// its VALU instructions outside its FMAs (1.72e9 wave instructions per launch for 0.63e9 of FMAs: five passes
+// of index arithmetic to stage 272 samples through three LDS images, two v_readlane per tap and pass), and
+// with 7 waves per SIMD the VALU pipe is what it fills first (3.5 of its 5.6 ms).  Here a lane loads the four
+// noise values of its own samples as one 32-byte piece and keeps them (the only LDS image is this frame's e,
+// for the 30-sample history of a lane's window), the start values noise[n - 15] come straight from memory
+// (the L1 has the lines), the previous frame's tail is loaded by the eight lanes that need it, and the taps
+// of the frame are scalar loads issued WITH everything else at the top (written before the staging fences,
+// which is where the compiler leaves them).  Same terms in the same order: the same bits.
+template <int NLPF>
+__global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, int utt_fastest)
+{
+    static_assert(NLPF - 1 <= kExwHalo - 2, "history window too short");
+    constexpr int kExwWin = NLPF - 1 + kExw;
+    constexpr int anti = (NLPF - 1) / 2;
+    constexpr int HQ = kExwHalo / kExw; // history columns of the image
+    const int b = utt_fastest ? blockIdx.x : blockIdx.y;
+    const uint32_t bx = utt_fastest ? blockIdx.y : blockIdx.x;
+    const UttDev *u = bd.utt + b;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx * 4u + (uint32_t)wv));
+    if (fr >= u->T)
+        return;
+    const int fp = vd.fperiod;
+    const uint64_t base = u->frame_off;
+    const uint64_t f = base + fr;
+    const long n0 = (long)fr * (long)fp;
+    __shared__ double ec_s[4][kExw][kExwQ];
+    __shared__ double ep_s[4][2 * kExwHalo];
+    __shared__ double xs_s[4][kExwHalo];
+    double(*ec)[kExwQ] = ec_s[wv];
+    double *ep = ep_s[wv];
+    double *xs = xs_s[wv];
+    const int i0 = lane * kExw;
+    const bool own = i0 < fp;
+    // ---- every request of the wave ----
+    const uint64_t fprev = fr > 0 ? f - 1 : f;
+    const uint32_t vflag_c = vd.voiced[f], vflag_p = vd.voiced[fprev];
+    const double *tc = vd.lpf + f * (uint64_t)NLPF;
+    double ck[NLPF]; // wave-uniform: scalar loads
+#pragma unroll
+    for (int k = 0; k < NLPF; k++)
+        ck[k] = tc[k];
+    const double tpv = lane < NLPF ? vd.lpf[fprev * (uint64_t)NLPF + (uint64_t)lane] : 0.0;
+    const long nl = own ? n0 + i0 : n0; // (a lane past the frame reads the frame's first samples and keeps nothing)
+    const double2 nva = *reinterpret_cast<const double2 *>(vd.noise + nl);
+    const double2 nvb = *reinterpret_cast<const double2 *>(vd.noise + nl + 2);
+    double xi[kExw];
+#pragma unroll
+    for (int r = 0; r < kExw; r++) {
+        const long q = nl + r - anti;
+        const double v = vd.noise[q < 0 ? 0 : q];
+        xi[r] = q < 0 ? 0.0 : v;
+    }
+    // the previous frame's last 32 samples, four per lane on lanes 0..7 (zero before the utterance starts)
+    const long nt = n0 - kExwHalo + i0;
+    const bool has_tail = lane < HQ && nt >= 0;
+    const long ntc = has_tail ? nt : n0;
+    const double2 tla = *reinterpret_cast<const double2 *>(vd.noise + ntc);
+    const double2 tlb = *reinterpret_cast<const double2 *>(vd.noise + ntc + 2);
+    const bool vcur = __builtin_amdgcn_readfirstlane((int)vflag_c) != 0;
+    const bool vprev = fr > 0 && __builtin_amdgcn_readfirstlane((int)vflag_p) != 0;
+    if (vd.skip_unvoiced && fr >= 1 && !vcur && !vprev)
+        return;
+    const double nv[kExw] = {nva.x, nva.y, nvb.x, nvb.y};
+    double x[kExw];
+#pragma unroll
+    for (int r = 0; r < kExw; r++)
+        x[r] = xi[r];
+    if (vcur) {
+        // image of this frame's e = -noise: own samples at column HQ + lane, history columns zero
+        if (lane < HQ) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                ec[r][lane] = 0.0;
+        }
+        if (own) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                ec[r][HQ + lane] = 0.0 - nv[r];
+        }
+    }
+    if (vprev) {
+        // previous frame's e tail, then zeros where this frame starts
+        if (lane < HQ) {
+            const double tl[kExw] = {tla.x, tla.y, tlb.x, tlb.y};
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                ep[i0 + r] = has_tail ? 0.0 - tl[r] : 0.0;
+        } else if (lane < 2 * HQ) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                ep[i0 + r] = 0.0;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (vcur && own) {
+        double w[kExwWin]; // w[c] = e[i0 - (NLPF-1) + c]
+#pragma unroll
+        for (int c = 0; c < NLPF - 1; c++) {
+            const int o = c + kExwHalo - (NLPF - 1);
+            w[c] = ec[o & (kExw - 1)][lane + (o >> 2)];
+        }
+#pragma unroll
+        for (int r = 0; r < kExw; r++)
+            w[NLPF - 1 + r] = 0.0 - nv[r];
+#pragma unroll
+        for (int k = 0; k < NLPF; k++) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
+        }
+    }
+    if (vprev) {
+        // pass 2 (previous frame's sources and taps), one sample per lane: as in k_excite_w4
+        if (own && i0 < kExwHalo) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                xs[i0 + r] = x[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        {
+            double tk[NLPF];
+#pragma unroll
+            for (int k = 1; k < NLPF; k++) {
+                const int lo = __builtin_amdgcn_readlane(__double2loint(tpv), k);
+                const int hi = __builtin_amdgcn_readlane(__double2hiint(tpv), k);
+                tk[k] = __hiloint2double(hi, lo);
+            }
+            if (lane < NLPF - 1 && lane < fp) {
+                double xv = xs[lane];
+#pragma unroll
+                for (int k = 1; k < NLPF; k++)
+                    xv = fma(ep[lane - k + kExwHalo], tk[k], xv);
+                xs[lane] = xv;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (own && i0 < kExwHalo) {
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                x[r] = xs[i0 + r];
+        }
+    }
+    if (!own)
+        return;
+    const uint64_t o = base * (uint64_t)fp + (uint64_t)n0 + (uint64_t)i0;
+    *reinterpret_cast<double2 *>(vd.xin + o) = make_double2(x[0], x[1]);
+    *reinterpret_cast<double2 *>(vd.xin + o + 2) = make_double2(x[2], x[3]);
+    if (vd.exc) {
+        *reinterpret_cast<double2 *>(vd.exc + o) = make_double2(x[0], x[1]);
+        *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[2], x[3]);
+    }
+}
+
 // Second half of the split excitation: one wave per frame; frames without a pulse leave at
 // once.  For every pulse (sample p of the frame) lanes 0..NLPF-1 recompute the NLPF samples
 // p .. p+NLPF-1 that see it, from the complete e[] (all pulses, both neighbouring frames) in tap
@@ -1822,6 +1983,15 @@ hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t
     const int swap = !no_swap && grid.x <= 65535u; // grid.y limit
     if (swap)
         grid = dim3(bd.B, (bd.maxT + 3) / 4);
+    // k_excite_noise4: the same pass with fewer instructions (JB_EXCITE_NOISE4=0: k_excite_w4<NLPF, true>, same bits)
+    static const bool old_w4 = getenv("JB_EXCITE_NOISE4") && atoi(getenv("JB_EXCITE_NOISE4")) == 0;
+    if (!old_w4) {
+        if (vd.nlpf == 31)
+            hipLaunchKernelGGL(k_excite_noise4<31>, grid, block, 0, stream, bd, vd, swap);
+        else
+            hipLaunchKernelGGL(k_excite_noise4<15>, grid, block, 0, stream, bd, vd, swap);
+        return hipGetLastError();
+    }
     if (vd.nlpf == 31)
         hipLaunchKernelGGL((k_excite_w4<31, true>), grid, block, 0, stream, bd, vd, swap);
     else
