@@ -539,11 +539,20 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
             a2m = gg_dpp<GG_WAVE_SHR1>(a2[kGgFPT - 1]);
             a2mm = gg_dpp<GG_WAVE_SHR1>(a2[kGgFPT - 2]);
             const int own_hi = own_lo + kGgOwn < n_i ? own_lo + kGgOwn : n_i;
+            // the eight GV switches of the lane's frames: unconditional loads at clamped positions, all in
+            // flight together (behind the bounds test each was a basic block of its own and waited for
+            // alone -- eight memory round trips per row and wave)
+            uint8_t swb[kGgFPT];
+#pragma unroll
+            for (int f = 0; f < kGgFPT; f++) {
+                const int t = t0 + f;
+                swb[f] = sw[t < 0 ? 0 : (t >= n_i ? n_i - 1 : t)];
+            }
 #pragma unroll
             for (int f = 0; f < kGgFPT; f++) {
                 const int t = t0 + f;
                 const bool in = t >= 0 && t < n_i;
-                if (in && sw[t] != 0)
+                if (in && swb[f] != 0)
                     onbits |= 1u << f;
                 if (t >= own_lo && t < own_hi)
                     ownbits |= 1u << f;
