@@ -1379,8 +1379,11 @@ int Batch::sync()
                 GvGangCtl c;
                 hipMemcpy(&c, sd[si].gv_gang_ctl, sizeof c, hipMemcpyDeviceToHost);
                 const double nb = (double)sd[si].gv_gang_n * sd[si].gv_gang_tiles;
-                fprintf(stderr, "k_mlpg_gv_gang ticks per workgroup: load %.0f stats %.0f blocksum %.0f exchange %.0f step %.0f store %.0f\n",
-                        c.prof[0] / nb, c.prof[1] / nb, c.prof[2] / nb, c.prof[3] / nb, c.prof[4] / nb, c.prof[5] / nb);
+                fprintf(stderr,
+                        "k_mlpg_gv_gang ticks per workgroup: load %.0f stats %.0f blocksum %.0f exchange %.0f (hand-off alone "
+                        "%.0f) step %.0f store %.0f\n",
+                        c.prof[0] / nb, c.prof[1] / nb, c.prof[2] / nb, c.prof[3] / nb, c.prof[6] / nb, c.prof[4] / nb,
+                        c.prof[5] / nb);
             }
         }
     return finish_verify();

@@ -316,6 +316,9 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
     // from_red: the first three values are the workgroup sums of block_sum (added up here, waves in order)
     auto exchange = [&](bool from_red, double v0, double v1, double v2, double v3) {
         __syncthreads(); // every thread is done with the records of the previous exchange; red[] is written
+#if JB_GG_PROFILE
+        const long long tx0_ = clock64();
+#endif
         if (wv == 0) {
             typedef unsigned long long u64;
             unsigned long long *slot = &G->rec[kbar & 1][0][0];
@@ -387,6 +390,9 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
             if (lane == 0)
                 sh_i[0] = all_ok ? 1 : 0;
         }
+#if JB_GG_PROFILE
+        prof_[6] += clock64() - tx0_; // the hand-off itself (wave 0), without the wait for the workgroup's other waves
+#endif
         __syncthreads();
         dead = sh_i[0] == 0;
         kbar++;
