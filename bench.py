@@ -52,8 +52,8 @@ SUB_BATCH_FRAMES = 7_000_000  # frames per sub-batch of the config-3 job (config
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--job", choices=("config2", "config3"), default="config2",
                     help="config2: the headline (per-GPU batch of copies, weak scaling); config3: the 4096 "
                          "mixed-length utterances as one LPT-sharded job (strong scaling)")
