@@ -76,7 +76,7 @@ def test_config2_at_batch_256(ctx):
         info = b.info()
         picks = {i: b.pcm(i) for i in (0, 1, 100, 255)}
     # two waves per SIMD of the lane-triple kernel: 64 x 32 x 21 = 43,008 chunk slots
-    assert 40000 <= info["n_items"] <= 43008 and info["chunk_frames"] in (152, 156, 160), info
+    assert 40000 <= info["n_items"] <= 43008 and 152 <= info["chunk_frames"] <= 160, info
     for i in (1, 100, 255):
         assert np.array_equal(picks[0], picks[i]), i
     ref, _ = oracle_pcm(vi, u)
