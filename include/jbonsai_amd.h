@@ -98,7 +98,7 @@ typedef struct jb_batch_opts {
     int32_t device;         /* HIP device ordinal; -1 = current */
     uint32_t flags;         /* JB_BATCH_* */
     uint32_t chunk_frames;  /* vocoder time-chunk length in frames; 0 = auto */
-    uint32_t warmup_frames; /* frames each chunk starts early from zero state; 0 = default (20) */
+    uint32_t warmup_frames; /* frames each chunk starts early from zero state; 0 = default (18) */
     double verify_tol;      /* chunk hand-off check: max|state diff| <= tol*max|state|; 0 = default (1e-9) */
     uint32_t mlpg_cus_per_xcd; /* CU partition for batches in flight (below); 0 = none */
     uint32_t reserved;

@@ -911,11 +911,13 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
 int Batch::build_work(const jb_batch_opts *opts)
 {
     const bool serial = (flags & JB_BATCH_SERIAL) != 0;
-    // 20 frames: on config 2 the vocoder kernel takes 66.3 instead of 67.8 ms (24 frames); with 64 distinct
-    // utterances 220 instead of 136 hand-offs fail per step, all settle at their checkpoint, and the step
-    // still comes out ahead (104.6 against 105.5 ms; 16 frames: 524 fail, 102.6 -- but one hand-off of
-    // config 2's own utterance then fails in all 256 copies, 102.3 against 100.9)
-    warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 20;
+    // 18 frames.  Every frame of warm-up is 0.6 % of the vocoder kernel (0.35 ms on config 2); a failing
+    // hand-off costs a redo round (~2.5 ms whatever their number).  Same box, config 2 (copies of one utterance
+    // / 64 distinct utterances), ms per step: 20 frames 92.2 / 94.1, 19: 91.2 / 93.3, 18: 90.5 / 93.6,
+    // 17: 93.0 / 92.6 (at 17 a hand-off of config 2's own utterance fails in all 256 copies; with distinct
+    // utterances a few hundred fail at every length and settle at their checkpoint).  24 -> 20 earlier in the
+    // round: vocoder 67.8 -> 66.3 ms, 136 -> 220 failing hand-offs with distinct utterances.
+    warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 18;
     if (!(opts && opts->warmup_frames) && getenv("JB_WARMUP_FRAMES")) // tuning aid
         warmup_frames = (uint32_t)std::max(1, atoi(getenv("JB_WARMUP_FRAMES")));
     verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
