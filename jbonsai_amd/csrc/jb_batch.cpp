@@ -985,7 +985,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
-    vd.ckpt_frames = ch >= 2 * kVocCkptFrames ? kVocCkptFrames : (ch >= kVocCkptFramesShort + 16 ? kVocCkptFramesShort : 0);
+    vd.ckpt_frames = ch >= 2 * kVocCkptFrames ? kVocCkptFrames : (ch >= kVocCkptFramesShort + 12 ? kVocCkptFramesShort : 0);
     if (const char *e = getenv("JB_CKPT_FRAMES")) { // tuning aid: checkpoint position of long chunks
         const uint32_t v = (uint32_t)std::max(8, atoi(e));
         if (ch >= 2 * v)
@@ -1036,7 +1036,7 @@ int Batch::build_work(const jb_batch_opts *opts)
             w.save_end = end_state + (size_t)k * stride;
             w.save_warm = first ? nullptr : warm_state + (size_t)k * stride;
             // checkpoint for the partial redo: only where it saves at least half the chunk
-            const uint32_t need = vd.ckpt_frames >= kVocCkptFrames ? 2 * vd.ckpt_frames : vd.ckpt_frames + 16;
+            const uint32_t need = vd.ckpt_frames >= kVocCkptFrames ? 2 * vd.ckpt_frames : vd.ckpt_frames + 12;
             w.save_ckpt = (!first && vd.ckpt_frames && w.t_end - w.t_out >= need) ? ckpt_state + (size_t)k * stride
                                                                                    : nullptr;
         }
