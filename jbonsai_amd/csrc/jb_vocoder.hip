@@ -687,6 +687,9 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
 // order -- the same chain of FMAs as k_excite_w4's two passes, so the two kernels together are
 // bit-identical to the one-pass form.  Samples covered by two pulses are written twice with the
 // same value.
+#ifndef JB_FIX_PARK_EARLY
+#define JB_FIX_PARK_EARLY 1
+#endif
 constexpr int kFixFrames = 8;
 #ifndef JB_FIX_UNROLL
 #define JB_FIX_UNROLL 8
@@ -749,6 +752,21 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
         if (any == 0ull)
             continue;
         const long n0 = (long)fr * (long)fp;
+#if JB_FIX_PARK_EARLY
+        // taps of the three frames a window can touch, parked at once: held in registers until the first window
+        // is staged they cost six VGPRs, and at 52 only ONE wave of this kernel fits a SIMD beside the resident
+        // GV kernel's two of 208 (at 48, two)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier(); // the previous frame's reads of tp3 are done
+        if (lane < NLPF) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const long ff = (long)fr - 1 + j;
+                tp3[j][lane] = (ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
+            }
+        }
+        bool taps_parked = true;
+#else
         // taps of the three frames a window can touch: requested here, needed after the window is staged
         double tpv[3];
 #pragma unroll
@@ -757,6 +775,7 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             tpv[j] = (lane < NLPF && ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
         }
         bool taps_parked = false;
+#endif
         for (int q = 0; q < nblk; q++) {
             unsigned long long word;
             if (q < 4) {
@@ -803,6 +822,7 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                 __builtin_amdgcn_wave_barrier(); // the previous pulse's reads of es[] are done
                 if (lane <= 2 * H)
                     es[lane] = ev;
+#if !JB_FIX_PARK_EARLY
                 if (!taps_parked) {
                     if (lane < NLPF) {
 #pragma unroll
@@ -811,6 +831,8 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                     }
                     taps_parked = true;
                 }
+#endif
+                (void)taps_parked;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
