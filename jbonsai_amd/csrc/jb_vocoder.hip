@@ -529,6 +529,9 @@ __global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int u
 // (the L1 has the lines), the previous frame's tail is loaded by the eight lanes that need it, and the taps
 // of the frame are scalar loads issued WITH everything else at the top (written before the staging fences,
 // which is where the compiler leaves them).  Same terms in the same order: the same bits.
+#ifndef JB_N4_GROUP
+#define JB_N4_GROUP 4 // taps per window group of pass 1 (0: the whole window in registers)
+#endif
 template <int NLPF>
 __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, int utt_fastest)
 {
@@ -619,6 +622,39 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (vcur && own) {
+#if JB_N4_GROUP > 0
+        // the window e[i0 - (NLPF-1) .. i0 + 3] a GROUP of taps at a time (taps k0..k1 touch eleven of its 34
+        // values): with the whole window in registers the kernel needs 62 VGPRs and only one of its waves fits
+        // a SIMD beside the resident GV kernel's two of 208, under which its last third runs; same order of the
+        // additions, so the same bits
+        constexpr int G = JB_N4_GROUP;
+#pragma unroll
+        for (int k0 = 0; k0 < NLPF; k0 += G) {
+            const int k1 = k0 + G - 1 < NLPF - 1 ? k0 + G - 1 : NLPF - 1;
+            const int lo = NLPF - 1 - k1; // window index of the oldest value the group touches
+            double wg[G + kExw - 1];
+#pragma unroll
+            for (int c = 0; c < G + kExw - 1; c++) {
+                const int idx = lo + c; // w[idx] = e[i0 - (NLPF-1) + idx]
+                if (idx < kExwWin) {
+                    if (idx >= NLPF - 1) {
+                        wg[c] = 0.0 - nv[idx - (NLPF - 1)];
+                    } else {
+                        const int o = idx + kExwHalo - (NLPF - 1);
+                        wg[c] = ec[o & (kExw - 1)][lane + (o >> 2)];
+                    }
+                } else {
+                    wg[c] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int k = k0; k <= k1; k++) {
+#pragma unroll
+                for (int r = 0; r < kExw; r++)
+                    x[r] = fma(wg[NLPF - 1 + r - k - lo], ck[k], x[r]);
+            }
+        }
+#else
         double w[kExwWin]; // w[c] = e[i0 - (NLPF-1) + c]
 #pragma unroll
         for (int c = 0; c < NLPF - 1; c++) {
@@ -634,6 +670,7 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
             for (int r = 0; r < kExw; r++)
                 x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
         }
+#endif
     }
     if (vprev) {
         // pass 2 (previous frame's sources and taps), one sample per lane: as in k_excite_w4
