@@ -2045,14 +2045,15 @@ hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t
     // k_excite_noise4: the same pass with fewer instructions (JB_EXCITE_NOISE4=0: k_excite_w4<NLPF, true>, same bits)
     static const bool old_w4 = getenv("JB_EXCITE_NOISE4") && atoi(getenv("JB_EXCITE_NOISE4")) == 0;
     if (!old_w4) {
-        // 24 KB of LDS that the kernel does not use ride with every workgroup: they cap the workgroups a CU takes
-        // at four (16 waves instead of up to 32).  This pass runs on a side stream beside the MCP chain's build
+        // 32 KB of LDS that the kernel does not use ride with every workgroup: they cap the workgroups a CU takes
+        // at three (12 waves instead of up to 40).  This pass runs on a side stream beside the MCP chain's build
         // and band solve, which are chains of round trips at low occupancy; with all the wave slots it could get
         // it stretched them by more than it gained (parameter generation 31.4-32.0 ms without the cap, 29.9-30.0
-        // with 20 KB, 29.9-30.6 with 28, 30.1-30.7 with 40, 31.4 with 52, same box; the same cap on the LPF MLPG
-        // or the pulse repair pass loses).  JB_EXCITE_LDS_KB overrides.
+        // with 20 KB, 29.9-30.6 with 28, 30.1-30.7 with 40, 31.4 with 52, same box, when the kernel had 62 VGPRs;
+        // at 48 VGPRs: 31.0-31.4 with 16 KB, 29.1-30.1 with 24, 28.7-29.6 with 32, 29.2-29.4 with 40; the same cap
+        // on the LPF MLPG or the pulse repair pass loses).  JB_EXCITE_LDS_KB overrides.
         static const size_t pad =
-            (size_t)(getenv("JB_EXCITE_LDS_KB") ? std::max(0, atoi(getenv("JB_EXCITE_LDS_KB"))) : 24) * 1024;
+            (size_t)(getenv("JB_EXCITE_LDS_KB") ? std::max(0, atoi(getenv("JB_EXCITE_LDS_KB"))) : 32) * 1024;
         if (vd.nlpf == 31)
             hipLaunchKernelGGL(k_excite_noise4<31>, grid, block, pad, stream, bd, vd, swap);
         else
