@@ -325,6 +325,10 @@ __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 #ifndef JB_VT_FUSE2
 #define JB_VT_FUSE2 1
 #endif
+#ifndef JB_FL_WPE
+#define JB_FL_WPE 1 // register budget of the band solve in waves per SIMD: 2 = 256 registers per wave (it then spills to
+                    // scratch: 5.55 against 5.0 ms alone, and the step gains nothing from fitting beside the LF0 GV kernel)
+#endif
 #ifndef JB_FL_SPLIT
 #define JB_FL_SPLIT 1
 #endif
@@ -1536,47 +1540,54 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
             const long l0 = lo(p);
             const double *ib = inb + (p % kFlIn) * NIN * kFlCT * LP;
             double *ob = outb + (p % kFlOut) * NOUT * kFlCT * LP;
-            // the chunk's operands come out of LDS first: the compiler cannot tell the input
-            // tiles from the output tiles, so reads interleaved with the result writes would each
-            // wait out a full LDS round trip inside the dependency chain
-            double ivs[kFlCT][NIN];
+            // A half chunk's operands come out of LDS before its recurrence starts: reads interleaved with the
+            // result writes would each wait out a full LDS round trip inside the dependency chain.  HALF a
+            // chunk, not the whole: with 16 x 4 operands in flight the kernel needed 256 VGPRs plus ~150
+            // AccVGPRs of spill space per wave (now ~80), which is what a SIMD must have free to take a wave of
+            // this workgroup beside the waves of the other chains.
+            constexpr int kHalf = kFlCT / 2;
+            const bool interior = l0 >= 2 && l0 + kFlCT + 2 <= (long)n;
 #pragma unroll
-            for (int u = 0; u < kFlCT; u++) {
-                const int tt = BACKWARD ? kFlCT - 1 - u : u;
+            for (int h = 0; h < 2; h++) {
+                double ivs[kHalf][NIN];
 #pragma unroll
-                for (int a = 0; a < NIN; a++)
-                    ivs[u][a] = ib[(a * kFlCT + tt) * LP + lane];
-            }
-            // (with a compile-time tile pitch the compiler CAN tell them apart and sinks every read next
-            // to its use again: the kernel took 11.5 ms instead of 5.5)
-#if JB_FL_SCHED
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            if (l0 >= 2 && l0 + kFlCT + 2 <= (long)n) {
-                // interior chunk: every frame exists and has both neighbours on either side, so
-                // the recurrences run without their edge guards (same operations, same order)
-#pragma unroll
-                for (int u = 0; u < kFlCT; u++) {
+                for (int uu = 0; uu < kHalf; uu++) {
+                    const int u = h * kHalf + uu;
                     const int tt = BACKWARD ? kFlCT - 1 - u : u;
-                    double ov[NOUT];
-                    step(std::true_type{}, (uint32_t)(l0 + tt), ivs[u], ov);
 #pragma unroll
-                    for (int a = 0; a < NOUT; a++)
-                        ob[(a * kFlCT + tt) * LP + lane] = ov[a];
+                    for (int a = 0; a < NIN; a++)
+                        ivs[uu][a] = ib[(a * kFlCT + tt) * LP + lane];
                 }
-            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                if (interior) {
+                    // interior chunk: every frame exists and has both neighbours on either side, so
+                    // the recurrences run without their edge guards (same operations, same order)
 #pragma unroll
-                for (int u = 0; u < kFlCT; u++) {
-                    const int tt = BACKWARD ? kFlCT - 1 - u : u;
-                    const long t = l0 + tt;
-                    if (t >= 0 && t < (long)n) {
+                    for (int uu = 0; uu < kHalf; uu++) {
+                        const int u = h * kHalf + uu;
+                        const int tt = BACKWARD ? kFlCT - 1 - u : u;
                         double ov[NOUT];
-                        step(std::false_type{}, (uint32_t)t, ivs[u], ov);
+                        step(std::true_type{}, (uint32_t)(l0 + tt), ivs[uu], ov);
 #pragma unroll
                         for (int a = 0; a < NOUT; a++)
                             ob[(a * kFlCT + tt) * LP + lane] = ov[a];
                     }
+                } else {
+#pragma unroll
+                    for (int uu = 0; uu < kHalf; uu++) {
+                        const int u = h * kHalf + uu;
+                        const int tt = BACKWARD ? kFlCT - 1 - u : u;
+                        const long t = l0 + tt;
+                        if (t >= 0 && t < (long)n) {
+                            double ov[NOUT];
+                            step(std::false_type{}, (uint32_t)t, ivs[uu], ov);
+#pragma unroll
+                            for (int a = 0; a < NOUT; a++)
+                                ob[(a * kFlCT + tt) * LP + lane] = ov[a];
+                        }
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -1613,7 +1624,7 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
 }
 
 template <int LMAX>
-__global__ __launch_bounds__(kFlNT) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd, int si)
+__global__ __launch_bounds__(kFlNT, JB_FL_WPE) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd, int si)
 {
     extern __shared__ double lds[];
     const int b = (int)bd.order[blockIdx.x]; // longest utterance first: the serial sweeps of a ragged
