@@ -63,7 +63,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the secondary measurements appended to the default line (distinct utterances, "
-                         "D2H-inclusive, labels -> PCM, config3_strong at N > 1); none of them enters `value`")
+                         "D2H-inclusive, labels -> PCM, configs 4 and 5 at batch 1024, the config-3 job); none of "
+                         "them enters `value`")
     ap.add_argument("--cu-split", type=int, default=-1,
                     help="CUs per XCD (of 32) given to parameter generation when two batches are in "
                          "flight; the vocoder gets the rest (jb_batch_opts.mlpg_cus_per_xcd); "
@@ -98,16 +99,41 @@ def _free_port():
 
 def spawn_ranks(n: int) -> int:
     """N fresh child processes, one per GPU, started BEFORE this process makes any HIP / torch.cuda
-    call (it never does).  Rank 0 prints the JSON line on the inherited stdout."""
+    call (it never does).  Rank 0 prints the JSON line on the inherited stdout.
+    The launcher never waits for ever and never leaves its ranks behind: JB_BENCH_TIMEOUT_S (default 1500)
+    bounds the whole run, SIGTERM / SIGINT end exactly the children it started (terminate, then kill) and
+    the launcher exits non-zero."""
+    import signal
+
     port = _free_port()
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    deadline = time.monotonic() + float(os.environ.get("JB_BENCH_TIMEOUT_S", "1500"))
+
+    def stop_children(grace=5.0):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + grace
+        for p in procs:
+            while p.poll() is None and time.monotonic() < t_end:
+                time.sleep(0.05)
+            if p.poll() is None:
+                p.kill()
+
+    class _Stop(Exception):
+        pass
+
+    def on_signal(signum, _frame):
+        raise _Stop(signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
     try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
         pending = list(procs)
         while pending:
             for p in list(pending):
@@ -121,23 +147,61 @@ def spawn_ranks(n: int) -> int:
                     # children this launcher started
                     for q in pending:
                         q.terminate()
+            if pending and time.monotonic() > deadline:
+                print(f"bench.py: ranks still running at the deadline (JB_BENCH_TIMEOUT_S); ending them", file=sys.stderr)
+                rc = rc or 124
+                break
             time.sleep(0.05)
+    except _Stop as st:
+        rc = 128 + int(st.args[0])
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
+        stop_children()
+        for sg, h in old.items():
+            signal.signal(sg, h)
     return rc
 
 
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(utt, vi, n_utts_per_thread=2):
-    """The oracle (C restatement of jbonsai's CPU path, kind="port") on the host cores
-    of this box, on a bounded sample of the same workload."""
+def _host_cpu():
+    """CPU model string, nproc, affinity and cgroup quota of this box."""
+    model = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    nproc = os.cpu_count() or 1
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else nproc
+    quota = None
+    try:  # cgroup v2: "max 100000" or "<quota> <period>"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return model, nproc, aff, quota
+
+
+def cpu_baseline(utt, vi, batch_size):
+    """the oracle (C restatement of jbonsai's CPU path, kind="port") built
+    -O3 -march=native ON THIS BOX (oracle/Makefile `native`; no FMA contraction, no fast-math: same bits
+    as the checker build), on the same synthetic utterance as the GPU batch:
+      (a) single thread: one utterance, median of 5 runs after 1 warm-up;
+      (b) all host cores: one utterance per thread at a time until the batch is done or ~12 s have
+          passed (a bounded sample of the batch: the default run must finish within minutes)."""
     import numpy as np
     from oracle import oracle as O
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, int(os.environ.get("JB_CPU_THREADS", "16"))))  # one GPU's CPU share
+    model, nproc, aff, quota = _host_cpu()
+    build = "gcc -O3 -march=native -ffp-contract=off (oracle/Makefile native, built on this box)"
+    try:
+        O.use_library(O.build_native())
+    except Exception as e:  # the checker build still measures something
+        O.use_library(None)
+        build = f"gcc -O2 -ffp-contract=off (native build failed: {e!r})"
+    threads = max(1, int(os.environ.get("JB_CPU_THREADS", "0")) or min(aff, int(quota + 0.5) if quota else aff))
     sts = []
     for i, s in enumerate(utt.streams):
         si = vi.streams[i]
@@ -145,27 +209,52 @@ def cpu_baseline(utt, vi, n_utts_per_thread=2):
         sts.append(O.StreamStates(si.vector_length, len(si.windows), si.is_msd, si.use_gv,
                                   [len(w) for w in si.windows], [c for w in si.windows for c in w],
                                   s.mean, s.var, msd, s.gv_mean, s.gv_var, s.gv_switch))
-    O.lib()
     nsamp = int(utt.durations.sum()) * vi.fperiod
 
-    def work():
-        for _ in range(n_utts_per_thread):
-            tr = [O.mlpg(s, utt.durations) for s in sts]
-            O.vocoder(vi.sampling_frequency, vi.fperiod, vi.alpha, 1.0, tr[1][:, 0], tr[0], tr[2])
+    def one():
+        tr = [O.mlpg(s, utt.durations) for s in sts]
+        O.vocoder(vi.sampling_frequency, vi.fperiod, vi.alpha, 1.0, tr[1][:, 0], tr[0], tr[2])
 
-    th = [threading.Thread(target=work) for _ in range(cores)]
+    one()  # warm-up
+    runs = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        one()
+        runs.append(time.perf_counter() - t0)
+    t_single = sorted(runs)[len(runs) // 2]
+    budget_s = float(os.environ.get("JB_CPU_BASELINE_S", "12"))
+    lock, done = threading.Lock(), [0]
     t0 = time.perf_counter()
+
+    def work():
+        while True:
+            with lock:
+                if done[0] >= batch_size or time.perf_counter() - t0 > budget_s:
+                    return
+                done[0] += 1
+            one()
+
+    th = [threading.Thread(target=work) for _ in range(threads)]
     for t in th:
         t.start()
     for t in th:
         t.join()
     dt = time.perf_counter() - t0
-    total = nsamp * n_utts_per_thread * cores
+    O.use_library(None)
+    all_cores = nsamp * done[0] / dt
     return {
-        "value": total / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-        "sample": f"{n_utts_per_thread * cores} utterances of {nsamp} samples (same synthetic "
-                  f"utterance as the GPU batch), one per thread x {n_utts_per_thread}, "
-                  f"{dt:.2f} s wall; C restatement of jbonsai's CPU path (oracle/), gcc -O2",
+        "value": all_cores, "unit": "samples/s", "cores": threads, "kind": "port",
+        "single_thread": {"value": nsamp / t_single, "unit": "samples/s", "seconds_per_utterance": t_single,
+                          "realtime_factor": nsamp / t_single / vi.sampling_frequency,
+                          "runs": 5, "statistic": "median after 1 warm-up"},
+        "all_cores": {"value": all_cores, "unit": "samples/s", "threads": threads, "utterances": done[0],
+                      "of_batch": batch_size, "wall_s": dt,
+                      "realtime_factor": all_cores / vi.sampling_frequency},
+        "cpu_model": model, "nproc": nproc, "affinity": aff, "cgroup_cpu_quota": quota, "build": build,
+        "sample": f"{done[0]} of the batch's {batch_size} utterances of {nsamp} samples (the same synthetic utterance "
+                  f"as the GPU batch), one per thread at a time on {threads} threads, {dt:.2f} s wall; single thread: "
+                  f"median of 5 runs; C restatement of jbonsai's CPU path (oracle/), never jbonsai itself "
+                  "(no Rust toolchain).  Anchor: jbonsai reaches ~7.6 Msamples/s per i5-13500 core (README.md:84)",
     }
 
 
@@ -279,30 +368,64 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def roofline_block(samples_per_launch, voc_ms, info, traffic):
+PROFILE_ROUND = "r03"  # profiles/<round>_* are what this line may quote
+
+
+def kernel_sources_sha16():
+    """Fingerprint of everything the kernels are built from (there is no .git on the GPU box): the
+    profile files carry the fingerprint they were measured on, and a quote from a profile of other
+    sources is withheld (`profiles_stale`)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    src = ROOT / "jbonsai_amd" / "csrc"
+    for f in sorted(list(src.glob("*.hip")) + list(src.glob("*.h")) + list(src.glob("*.cpp")) + [src / "build.sh"]):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def read_profile(name, batch, frames):
+    """(record, source, reason): a committed profile record of THIS workload on THESE sources, or None and
+    why not.  Counters cannot be read inside an ordinary run; tools/traffic.sh and tools/pmc_voc.sh make the
+    files from separate rocprofv3 --pmc passes of this same command."""
+    f = ROOT / "profiles" / f"{PROFILE_ROUND}_{name}.json"
+    if not f.exists():
+        return None, None, f"profiles/{f.name} missing"
+    try:
+        j = json.loads(f.read_text())
+    except Exception as e:
+        return None, None, f"profiles/{f.name}: {e!r}"
+    if j.get("batch") != batch or j.get("frames") != frames:
+        return None, None, (f"profiles/{f.name} is for batch {j.get('batch')} x {j.get('frames')} frames, "
+                            f"this run is {batch} x {frames}")
+    if j.get("kernel_sources_sha16") != kernel_sources_sha16():
+        return None, None, f"profiles/{f.name} was measured on other kernel sources (stale)"
+    return j, f"profiles/{f.name}", None
+
+
+def roofline_block(samples_per_launch, voc_ms, info, batch, frames):
     """The dominant kernel against the bound that binds it (FP64 VALU issue), with the HBM view the
     metric is defined on as the secondary record."""
     tflops = FLOP_PER_SAMPLE * samples_per_launch / (voc_ms * 1e-3) / 1e12
     gbs = B_ALG * samples_per_launch / (voc_ms * 1e-3) / 1e9
-    sq = None
-    for name in ("r02_pmc_sq_k_vocoder_lt.txt", "r01_v9_pmc_sq_k_vocoder_lt.txt"):
-        f = ROOT / "profiles" / name
-        if f.exists():
-            vals = {}
-            for ln in f.read_text().splitlines():
-                p = ln.split()
-                if len(p) >= 2 and p[0].startswith("SQ_"):
-                    try:
-                        vals[p[0]] = float(p[1])
-                    except ValueError:
-                        pass
-            if "SQ_ACTIVE_INST_VALU" in vals and "SQ_WAVE_CYCLES" in vals:
-                # two waves per SIMD share one VALU: busy = active / (wave cycles / 2)
-                sq = {"source": f"profiles/{name} (rocprofv3 --pmc, separate run of the same command)",
-                      "SQ_ACTIVE_INST_VALU": vals["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": vals["SQ_WAVE_CYCLES"],
-                      "SQ_INSTS_VALU": vals.get("SQ_INSTS_VALU"),
-                      "valu_busy": vals["SQ_ACTIVE_INST_VALU"] / (vals["SQ_WAVE_CYCLES"] / 2.0)}
-            break
+    stale = []
+    sq, sq_src, why = read_profile("pmc_sq_k_vocoder_lt", batch, frames)
+    sqrec = None
+    if sq is not None and "SQ_ACTIVE_INST_VALU" in sq.get("counters", {}) and "SQ_WAVE_CYCLES" in sq["counters"]:
+        c = sq["counters"]
+        # two waves per SIMD share one VALU: busy = active / (wave cycles / 2)
+        sqrec = {"source": f"{sq_src} (rocprofv3 --pmc, separate runs of this command on these sources)",
+                 "SQ_ACTIVE_INST_VALU": c["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": c["SQ_WAVE_CYCLES"],
+                 "SQ_INSTS_VALU": c.get("SQ_INSTS_VALU"),
+                 "valu_busy": c["SQ_ACTIVE_INST_VALU"] / (c["SQ_WAVE_CYCLES"] / 2.0)}
+    elif why:
+        sqrec = {"withheld": why}
+        stale.append(why)
+    tr, tr_src, why = read_profile("traffic", batch, frames)
+    traffic = tr.get("hbm_bytes_per_launch") if tr is not None else None
+    if tr is None and why:
+        stale.append(why)
     lt = bool(info["chunk_frames"]) and info["n_items"] >= 16384
     return {
         "bound": "valu_f64", "kernel": "k_vocoder_lt" if lt else "k_vocoder",
@@ -310,27 +433,14 @@ def roofline_block(samples_per_launch, voc_ms, info, traffic):
         "kernel_ms": voc_ms, "alg_flop_per_sample": FLOP_PER_SAMPLE,
         "note": "recursive IIR: bound by FP64 VALU issue, not by HBM (DESIGN.md section 4); achieved = useful "
                 "f64 flops of the path (SURVEY 8d: 1.39 kflop per output sample) / kernel time",
-        "sq_counters": sq,
-        "traffic": traffic,
+        "sq_counters": sqrec,
+        "traffic": traffic, "traffic_source": tr_src,
+        "whole_step_hbm_bytes": tr.get("whole_step_hbm_bytes") if tr is not None else None,
+        "profiles_stale": bool(stale), "profiles_stale_why": stale or None,
         # the HBM view (SURVEY 8d's per-unit figure x samples per launch / kernel time against 8 TB/s)
         "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                 "alg_bytes_per_sample": B_ALG, "traffic": traffic},
     }
-
-
-def read_traffic(batch, frames):
-    """HBM bytes of the dominant kernel per launch from the committed PMC run of this command
-    (tools/traffic.sh -> profiles/*traffic.json); counters cannot be read inside an ordinary run."""
-    for name in ("r02_traffic.json", "traffic.json"):
-        tf = ROOT / "profiles" / name
-        if tf.exists():
-            try:
-                tj = json.loads(tf.read_text())
-                if tj.get("batch") == batch and tj.get("frames") == frames:
-                    return tj.get("hbm_bytes_per_launch"), f"profiles/{name}"
-            except Exception:
-                pass
-    return None, None
 
 
 # ---------------------------------------------------------------------------------------------
@@ -572,10 +682,102 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
                         "realtime_factor": ns / dt / vi.sampling_frequency}
         rec["workload"] = f"jb_synthesize_batch: 64 utterances x {len(outs[0]) / vi.sampling_frequency:.0f} s (labels in, PCM on the host out)"
         outs = None
+        # the reference tree's only long label sequence: examples/genji/genji.lab, 1,456 distinct labels
+        # (164 s with the nitech voice), 64 copies of it as one request
+        from tests.golden.labels import GENJI
+
+        gl = [list(GENJI)] * 64
+        eng.synthesize_batch(gl[:2])
+        walls = []
+        for _ in range(2):
+            outs = None
+            t0 = time.perf_counter()
+            outs = eng.synthesize_batch(gl)
+            walls.append(time.perf_counter() - t0)
+        ns = sum(len(o) for o in outs)
+        rec["genji_1456_labels"] = {"workload": f"jb_synthesize_batch: 64 x genji.lab (1,456 labels, "
+                                                f"{len(outs[0]) / vi.sampling_frequency:.0f} s each), f64 PCM on the host",
+                                    "wall_ms": walls[1] * 1e3, "first_call_ms": walls[0] * 1e3, "samples": ns,
+                                    "realtime_factor": ns / walls[1] / vi.sampling_frequency}
+        outs = None
         ex["labels_to_pcm"] = rec
     except Exception as e:
         ex["labels_to_pcm"] = {"error": repr(e)}
+    # (4) BASELINE configs 4 and 5 at their stated batch of 1024, resident like the headline: DISTINCT
+    #     synthetic utterances of the same total length as config 2 (1024 x 6,386 frames = 31.9 s each),
+    #     created from pdf row indices.  Config 4's voice (tohoku-f01) is not in the reference tree: the
+    #     documented substitute is nitech with its three streams.  Config 5 blends TWO DIFFERENT
+    #     voices on the device (nitech + the permuted nitech of tests/golden/make_permuted_voice.py, 0.5/0.5).
+    try:
+        ex["config4"] = resident_record(J, vi, R, 1024, [tab], None, 4000,
+                                        "BASELINE config 4 (nitech-LPF substitute for the absent tohoku-f01 voice): "
+                                        "batch=1024 distinct synthetic utterances x 6386 frames, MCP+LF0+LPF streams")
+    except Exception as e:
+        ex["config4"] = {"error": repr(e)}
+    try:
+        import tempfile
+
+        from tests.golden.make_permuted_voice import permuted_voice_path
+
+        with tempfile.TemporaryDirectory() as td:
+            eng2 = J.Engine.load([VOICE, permuted_voice_path(td)])
+        tabs = [synth.VoiceTables(eng2, 0), synth.VoiceTables(eng2, 1)]
+        half = {"duration": [0.5, 0.5], "parameter": [[0.5, 0.5]] * 3, "gv": [[0.5, 0.5]] * 3}
+        ex["config5"] = resident_record(J, eng2.voice_info(), R, 1024, tabs, half, 5000,
+                                        "BASELINE config 5: two-voice interpolation 0.5/0.5 (nitech + permuted nitech: "
+                                        "the tohoku-f01 files are absent), batch=1024 distinct synthetic utterances x "
+                                        "6386 frames, rows of both voices gathered and blended on the device")
+        eng2.close()
+    except Exception as e:
+        ex["config5"] = {"error": repr(e)}
     return ex
+
+
+CONFIG45_FRAMES = 6386  # 1024 x 6386 = 6,539,264 frames: config 2's total (256 x 25,546 = 6,539,776)
+
+
+def resident_record(J, vi, R, n_utts, tabs, weights, id0, workload, steps=3):
+    """One resident batch of n_utts distinct synthetic utterances created from pdf row indices (one voice:
+    tabs = [tab]; several: rows of every voice + weights), timed like the headline: `steps` steps after
+    one warm-up, inputs resident.  Carries its own ms_per_step, redo counts and roofline fraction."""
+    from jbonsai_amd import synth
+
+    pset = synth.voice_set_pdf_set(tabs, R.local_rank)
+    try:
+        if weights is None:
+            utts = [synth.synth_utterance(tabs[0], CONFIG45_FRAMES, id0 + i, indexed=True) for i in range(n_utts)]
+        else:
+            utts = [synth.synth_utterance_voices(tabs, weights, CONFIG45_FRAMES, id0 + i, indexed=True)
+                    for i in range(n_utts)]
+        t0 = time.perf_counter()
+        b = J.Batch(vi, utts, device=R.local_rank, pdf_set=pset)
+        create_ms = (time.perf_counter() - t0) * 1e3
+        try:
+            b.run()
+            b.sync()
+            voc = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                b.run()
+                b.sync()
+                voc.append(b.last_timing()[1])
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            info, redo = b.info(), b.redo_stats()
+            ns = b.total_samples
+        finally:
+            b.close()
+    finally:
+        pset.close()
+    voc_ms = sum(voc) / len(voc)
+    tflops = FLOP_PER_SAMPLE * ns / (voc_ms * 1e-3) / 1e12
+    return {"workload": workload, "batch": n_utts, "frames_per_utterance": CONFIG45_FRAMES, "voices": len(tabs),
+            "ms_per_step": ms, "value": ns / (ms * 1e-3), "unit": "samples/s", "steps": steps,
+            "realtime_factor": ns / (ms * 1e-3) / vi.sampling_frequency, "samples_per_step": ns,
+            "create_ms_from_row_indices": create_ms,
+            "vocoder_chunk_frames": info["chunk_frames"], "vocoder_work_items": info["n_items"],
+            "chunks_redone_last_step": info["n_redo"], "settled_at_checkpoint": redo[0], "redone_to_end": redo[1],
+            "roofline": {"bound": "valu_f64", "kernel_ms": voc_ms, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS}}
 
 
 def run_rank(args):
@@ -583,7 +785,7 @@ def run_rank(args):
     # library's device-memory pool hold both sets of blocks between passes (default cap 64 GB).  Not for
     # the single-GPU default run: its secondary measurements create differently shaped batches, and a
     # pool that fills the device turns their allocations into out-of-memory retries
-    if args.job == "config3" or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if args.job == "config3":
         os.environ.setdefault("JB_DEVICE_POOL_MB", "160000")
     import torch  # first: so that this process uses ONE HIP runtime (same SONAME as ours)
 
@@ -599,6 +801,7 @@ def run_rank(args):
     out = None
 
     if R.dry:
+        time.sleep(float(os.environ.get("JB_BENCH_DRYRUN_SLEEP_S", "0")))  # launcher tests: a rank that hangs
         rec = run_config3(R, J, tab, vi, None, args, 1, 0)
         gms = R.gather_slabs(torch.arange(1000 * (R.rank + 1), dtype=torch.float64))
         if R.rank == 0:
@@ -665,7 +868,6 @@ def run_rank(args):
         total = samples_per_step * R.world * args.steps
         value = total / dt
         voc_avg_ms = sum(voc_ms) / len(voc_ms)
-        traffic, traffic_src = read_traffic(args.batch, frames)
         out = {
             "metric": "48 kHz PCM samples/sec (whole node), batched utterances",
             "value": value, "unit": "samples/s", "n_gpus": R.world, "steps": args.steps,
@@ -689,30 +891,33 @@ def run_rank(args):
             },
             "realtime_factor": value / vi.sampling_frequency,
             **({"gather_ms": gather_ms} if gather_ms is not None else {}),
-            "roofline": roofline_block(samples_per_step, voc_avg_ms, info, traffic),
+            "roofline": roofline_block(samples_per_step, voc_avg_ms, info, args.batch, frames),
+            "kernel_sources_sha16": kernel_sources_sha16(),
         }
-        out["roofline"]["traffic_source"] = traffic_src
     if R.world == 1 and not args.no_extras:
         ex = extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_step, R)
         if out is not None:
             out.update(ex)
     batch.close()
-    if R.world > 1 and not args.no_extras:
-        # the strong-scaling job beside the headline: one warm-up pass and two timed passes of this
-        # rank's share of the 4096-utterance list
+    if not args.no_extras:
+        # BASELINE config 3 as ONE job beside the headline: the 4096-utterance list, this rank's share walked
+        # in sub-batches.  N > 1: one warm-up pass and two timed passes ("config3_strong"); N = 1: one of each
+        # ("config3_job": ~1 s per pass).  The job keeps two sub-batches alive: let the memory pool hold both
         pset = None
         try:
+            J.lib().jb_release_cached_memory()
+            J.lib().jb_set_cached_memory_limit(160000)
             pset = tab.pdf_set(R.local_rank)
         except Exception:
             pass  # run_config3 reports it: creating a batch over a missing set fails on this rank only
-        rec = run_config3(R, J, tab, vi, pset, args, 2, 1)
+        rec = run_config3(R, J, tab, vi, pset, args, 2 if R.world > 1 else 1, 1)
         if pset is not None:
             pset.close()
         if out is not None:
-            out["config3_strong"] = rec
+            out["config3_strong" if R.world > 1 else "config3_job"] = rec
     if R.rank == 0:
         if R.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(utt, vi)
+            out["cpu_baseline"] = cpu_baseline(utt, vi, args.batch)
         print(json.dumps(out), flush=True)
     R.close()
 

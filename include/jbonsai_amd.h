@@ -125,6 +125,10 @@ typedef struct jb_batch_opts {
                                     GV sweeps time-parallel with fixed-shape tree reductions (deterministic;
                                     tracks agree to ~1e-14 relative) */
 
+#define JB_BATCH_MLPG_ONLY 128u  /* MlpgAdjust::create only (src/mlpg_adjust/mod.rs:31-51): the run ends with the
+                                    three parameter tracks (implies KEEP_TRACKS); no excitation, no PCM, and
+                                    no device memory for them.  What jb_mlpg_batch sets */
+
 /* Time-chunked vocoder (default).  The MLSA recursion is time-serial per utterance
  * (src/vocoder/mlsa.rs), but it forgets its initial state within ~16 frames (measured:
  * <=2e-11 relative after 16, rounding floor after 24; tools/warmup_study.py).  Each
@@ -210,6 +214,9 @@ int jb_batch_read_track(jb_batch *b, size_t utt, uint32_t stream, double *dst, s
  * one-sentence synthesis); this hands them back to the driver.  The memory cap is
  * JB_DEVICE_POOL_MB (environment, default 65536; 0 disables the memory pool). */
 int jb_release_cached_memory(void);
+/* Changes the cap of each device's memory pool (megabytes; 0 disables the pool) and trims what is cached
+ * beyond it.  A caller that keeps several large batches alive in turn (bench.py's config-3 job) raises it. */
+int jb_set_cached_memory_limit(size_t megabytes);
 /* Parity tap: the MLSA filter coefficients the vocoder interpolates between, [T][nmcp] =
  * mc2b(postfilter_mcp(spectrum)) per frame (src/vocoder/mod.rs:116-118). */
 int jb_batch_read_coefficients(jb_batch *b, size_t utt, double *dst, size_t cap);
@@ -237,6 +244,38 @@ void jb_batch_free(jb_batch *b);
 int jb_paramgen_vocode_batch(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
                              const jb_batch_opts *opts, double *const *pcm, size_t *n_samples);
 
+/* ---- the two inner seams of the reference -----------------------------------------
+ * MlpgAdjust::new(gv_weight, msd_threshold, model_stream).create(&durations) -> Vec<Vec<f64>>
+ * (src/mlpg_adjust/mod.rs:31-51; called once per stream, src/engine.rs:333-357): for every utterance the
+ * tracks of all streams.  tracks[u * nstream + s] receives T_u x L_s doubles ([frame][dim], JB_NODATA in
+ * unvoiced frames of an MSD stream) or is NULL (that track is not wanted); n_frames[u] = T_u.  Call with
+ * tracks == NULL for the frame counts only. */
+int jb_mlpg_batch(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts, const jb_batch_opts *opts,
+                  double *const *tracks, size_t *n_frames);
+
+/* SpeechGenerator::new(fperiod, vocoder, spectrum, lf0, lpf) (src/speech.rs:25-50) for one utterance: the
+ * three parameter tracks as Vec<Vec<f64>> flattened row-major, with their outer and inner lengths so that
+ * the reference's three panics can be mirrored as JB_ERR_INVALID with the same messages:
+ * outer lengths differ; lf0 inner length != 1; lpf inner length even. */
+typedef struct jb_track_utt {
+    size_t n_spectrum, n_lf0, n_lpf;                /* outer lengths (frames) */
+    uint32_t spectrum_width, lf0_width, lpf_width;  /* inner lengths: nmcp, 1, nlpf (odd) */
+    uint32_t reserved;
+    const double *spectrum; /* [n_spectrum][spectrum_width]: mel-cepstra (stage 0) or [gain, LSP...] */
+    const double *lf0;      /* [n_lf0][1]; JB_NODATA = unvoiced frame (vocoder/mod.rs:73-77) */
+    const double *lpf;      /* [n_lpf][lpf_width] */
+} jb_track_utt;
+/* A batch whose source is parameter tracks: jb_batch_run starts at the frame prologue
+ * (Vocoder::synthesize per frame, src/vocoder/mod.rs:72-178).  Of `voice` the Vocoder::new arguments are
+ * read (sampling_frequency, fperiod, stage, use_log_gain, alpha, beta, volume, and the vector lengths of
+ * streams 0 and 2 = nmcp, nlpf); the window descriptions are not. */
+int jb_batch_create_from_tracks(const jb_voice_desc *voice, const jb_track_utt *utts, size_t n_utts,
+                                const jb_batch_opts *opts, jb_batch **out);
+/* SpeechGenerator::new + generate_all (src/speech.rs:25-50,87-96) for a batch: create + run + read + free.
+ * pcm[i] must hold n_samples[i] = n_lf0 * fperiod doubles; pcm == NULL: n_samples only. */
+int jb_vocode_tracks_batch(const jb_voice_desc *voice, const jb_track_utt *utts, size_t n_utts,
+                           const jb_batch_opts *opts, double *const *pcm, size_t *n_samples);
+
 /* ---- multi-GPU (SURVEY 8b "device_ids[] / n_devices", 8e) ----------------------------------
  * Utterances are independent, so a batch shards over the GPUs of a node with no data-path
  * collective: static LPT partition by length, one host thread per device, results in the caller's
@@ -259,6 +298,10 @@ typedef struct jb_generator jb_generator;
 int jb_engine_load(const char *const *paths, size_t n, jb_engine **out);
 int jb_engine_load_from_bytes(const uint8_t *const *bufs, const size_t *lens, size_t n,
                               jb_engine **out);
+/* Engine::new(VoiceSet, Condition) (src/engine.rs:289-291): an engine over the voices of `voices_of`
+ * (shared, as the reference's Arc<Voice>) with a copy of the Condition of `condition_of`; the same engine
+ * for both = Engine::clone.  JB_ERR_WEIGHT if the condition was made for another number of voices. */
+int jb_engine_new(const jb_engine *voices_of, const jb_engine *condition_of, jb_engine **out);
 void jb_engine_free(jb_engine *e);
 
 /* Condition accessors (src/engine.rs:127-243); setters clamp like the reference. */
@@ -289,6 +332,10 @@ size_t jb_engine_num_states(const jb_engine *e);
  * which: 0 duration, 1 parameter[stream], 2 gv[stream]. */
 int jb_engine_set_interpolation_weight(jb_engine *e, int which, size_t stream, const double *w,
                                        size_t n);
+/* InterporationWeight::{get_duration, get_parameter, get_gv} (interporation_weight.rs:115-125): *n = number
+ * of voices; w (may be NULL) receives the weights, JB_ERR_BUFFER if cap is too small. */
+int jb_engine_get_interpolation_weight(const jb_engine *e, int which, size_t stream, double *w, size_t cap,
+                                       size_t *n);
 
 /* Engine::synthesize (src/engine.rs:294): label lines ("label" or "start end label").
  * *pcm is library-owned; release with jb_pcm_free.  Zero labels => n_samples 0. */

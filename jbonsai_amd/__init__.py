@@ -5,10 +5,10 @@ The HIP shared library `libjbonsai_amd.so` is the product; this package is the
 thin host-side mirror of the reference's API used by tests and the benchmark.
 """
 from ._ffi import JbError, LIB_PATH, NODATA, build, lib, write_wav  # noqa: F401
-from .batch import (Batch, IndexStreamStates, IndexUtterance, PdfSet, StreamInfo, StreamStates, Utterance,  # noqa: F401
-                    VoiceInfo, paramgen_vocode_batch)
+from .batch import (Batch, IndexStreamStates, IndexUtterance, PdfSet, StreamInfo, StreamStates, TrackUtterance,  # noqa: F401
+                    Utterance, VoiceInfo, mlpg_batch, paramgen_vocode_batch, vocode_tracks_batch)
 
 from .engine import Engine, SpeechGenerator  # noqa: F401,E402
 
 __all__ = ["Engine", "SpeechGenerator", "JbError", "LIB_PATH", "NODATA", "build", "lib", "write_wav", "Batch", "StreamInfo", "StreamStates",
-           "Utterance", "VoiceInfo", "paramgen_vocode_batch", "PdfSet", "IndexUtterance", "IndexStreamStates"]
+           "Utterance", "VoiceInfo", "paramgen_vocode_batch", "mlpg_batch", "vocode_tracks_batch", "TrackUtterance", "PdfSet", "IndexUtterance", "IndexStreamStates"]

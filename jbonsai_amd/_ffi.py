@@ -28,6 +28,7 @@ BATCH_WAVE_KERNEL = 8
 BATCH_PAIR_KERNEL = 16
 BATCH_SERIAL_GV = 32
 BATCH_PCM_I16 = 64
+BATCH_MLPG_ONLY = 128
 
 
 class JbError(RuntimeError):
@@ -110,6 +111,15 @@ class IndexUtt(C.Structure):
     ]
 
 
+class TrackUtt(C.Structure):
+    _fields_ = [
+        ("n_spectrum", C.c_size_t), ("n_lf0", C.c_size_t), ("n_lpf", C.c_size_t),
+        ("spectrum_width", C.c_uint32), ("lf0_width", C.c_uint32), ("lpf_width", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("spectrum", C.POINTER(C.c_double)), ("lf0", C.POINTER(C.c_double)), ("lpf", C.POINTER(C.c_double)),
+    ]
+
+
 class BatchOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("chunk_frames", C.c_uint32),
                 ("warmup_frames", C.c_uint32), ("verify_tol", C.c_double), ("mlpg_cus_per_xcd", C.c_uint32), ("reserved", C.c_uint32)]
@@ -119,9 +129,10 @@ class BatchOpts(C.Structure):
 SYMBOLS = [
     "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_last_timing", "jb_batch_size",
     "jb_batch_num_frames", "jb_batch_num_samples", "jb_batch_total_samples", "jb_batch_read_pcm",
-    "jb_batch_read_pcm_i16", "jb_batch_read_pcm_all", "jb_batch_read_pcm_i16_all", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_batch_read_coefficients", "jb_batch_read_first_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
+    "jb_batch_read_pcm_i16", "jb_batch_read_pcm_all", "jb_batch_read_pcm_i16_all", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_set_cached_memory_limit", "jb_batch_read_coefficients", "jb_batch_read_first_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
     "jb_batch_info", "jb_batch_redo_stats", "jb_batch_free", "jb_paramgen_vocode_batch",
-    "jb_engine_load", "jb_engine_load_from_bytes", "jb_engine_free",
+    "jb_mlpg_batch", "jb_batch_create_from_tracks", "jb_vocode_tracks_batch",
+    "jb_engine_load", "jb_engine_load_from_bytes", "jb_engine_new", "jb_engine_free",
     "jb_engine_set_sampling_frequency", "jb_engine_get_sampling_frequency",
     "jb_engine_set_fperiod", "jb_engine_get_fperiod", "jb_engine_set_volume", "jb_engine_get_volume",
     "jb_engine_set_msd_threshold", "jb_engine_get_msd_threshold", "jb_engine_set_gv_weight",
@@ -130,7 +141,7 @@ SYMBOLS = [
     "jb_engine_set_alpha", "jb_engine_get_alpha", "jb_engine_set_beta", "jb_engine_get_beta",
     "jb_engine_set_additional_half_tone", "jb_engine_get_additional_half_tone",
     "jb_engine_num_voices", "jb_engine_num_streams", "jb_engine_num_states",
-    "jb_engine_set_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_write_wav_i16", "jb_write_wav_f64", "jb_synthesize_batch", "jb_synthesize_batch_i16", "jb_pcm_i16_free",
+    "jb_engine_set_interpolation_weight", "jb_engine_get_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_write_wav_i16", "jb_write_wav_f64", "jb_synthesize_batch", "jb_synthesize_batch_i16", "jb_pcm_i16_free",
     "jb_engine_model_shape", "jb_engine_pdf_table", "jb_engine_tree_index",
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
     "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",
@@ -202,6 +213,13 @@ def lib():
     L.jb_batch_free.restype = None
     L.jb_paramgen_vocode_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz,
                                            C.POINTER(BatchOpts), C.POINTER(dp), C.POINTER(sz)]
+    L.jb_mlpg_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz, C.POINTER(BatchOpts),
+                                C.POINTER(dp), C.POINTER(sz)]
+    L.jb_batch_create_from_tracks.argtypes = [C.POINTER(VoiceDesc), C.POINTER(TrackUtt), sz, C.POINTER(BatchOpts),
+                                              C.POINTER(vp)]
+    L.jb_vocode_tracks_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(TrackUtt), sz, C.POINTER(BatchOpts),
+                                         C.POINTER(dp), C.POINTER(sz)]
+    L.jb_set_cached_memory_limit.argtypes = [sz]
     L.jb_lpt_partition.argtypes = [C.POINTER(C.c_uint64), sz, sz, C.POINTER(C.c_uint32)]
     L.jb_paramgen_vocode_batch_multi.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz, C.POINTER(BatchOpts),
                                                  C.POINTER(C.c_int32), sz, C.POINTER(dp), C.POINTER(sz)]

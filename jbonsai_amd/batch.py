@@ -168,35 +168,65 @@ class IndexUtterance:
         return u
 
 
+@dataclass
+class TrackUtterance:
+    """The three parameter tracks of one utterance as SpeechGenerator::new takes them (src/speech.rs:25-50):
+    spectrum [T][nmcp], lf0 [T][1] (NODATA = unvoiced frame), lpf [T][nlpf]."""
+    spectrum: np.ndarray
+    lf0: np.ndarray
+    lpf: np.ndarray
+
+    def __post_init__(self):
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)
+        self.spectrum, self.lpf = f(self.spectrum), f(self.lpf)
+        self.lf0 = f(self.lf0)
+        if self.lf0.ndim == 1:
+            self.lf0 = self.lf0.reshape(-1, 1)
+
+    def c_struct(self):
+        u = F.TrackUtt()
+        u.n_spectrum, u.n_lf0, u.n_lpf = len(self.spectrum), len(self.lf0), len(self.lpf)
+        w = lambda a: int(a.shape[1]) if a.ndim == 2 else 0
+        u.spectrum_width, u.lf0_width, u.lpf_width = w(self.spectrum), w(self.lf0), w(self.lpf)
+        u.spectrum, u.lf0, u.lpf = _dp(self.spectrum), _dp(self.lf0), _dp(self.lpf)
+        return u
+
+
 class Batch:
     """A batch of utterances resident in HBM (jb_batch_*).  `utts` are state-level utterances
     (Utterance), or -- with `pdf_set` -- pdf row indices (IndexUtterance: the per-state Gaussians are
-    gathered and blended on the device, jb_batch_create_indexed)."""
+    gathered and blended on the device, jb_batch_create_indexed), or parameter tracks (TrackUtterance:
+    jb_batch_create_from_tracks, the run starts at the vocoder's frame prologue).  mlpg_only=True: the run
+    ends with the parameter tracks (JB_BATCH_MLPG_ONLY; read them with track())."""
 
     def __init__(self, voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
                  keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
                  kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False,
-                 mlpg_cus_per_xcd: int = 0, pdf_set: Optional[PdfSet] = None):
+                 mlpg_cus_per_xcd: int = 0, pdf_set: Optional[PdfSet] = None, mlpg_only: bool = False):
         L = F.lib()
         self._L = L
         self.voice = voice
         self._utts = list(utts)  # keep host arrays alive during create
         vd, keep = voice.c_struct()
-        arr = ((F.IndexUtt if pdf_set is not None else F.StateUtt) * max(1, len(utts)))()
+        from_tracks = bool(self._utts) and isinstance(self._utts[0], TrackUtterance)
+        ty = F.TrackUtt if from_tracks else F.IndexUtt if pdf_set is not None else F.StateUtt
+        arr = (ty * max(1, len(utts)))()
         for i, u in enumerate(self._utts):
             arr[i] = u.c_struct()
         opts = F.BatchOpts()
         opts.device = device
         opts.flags = ((F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
                       | (F.BATCH_SERIAL if serial else 0) | (F.BATCH_SERIAL_GV if serial_gv else 0)
-                      | (F.BATCH_PCM_I16 if pcm_i16 else 0)
+                      | (F.BATCH_PCM_I16 if pcm_i16 else 0) | (F.BATCH_MLPG_ONLY if mlpg_only else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "pair": F.BATCH_PAIR_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
         opts.mlpg_cus_per_xcd = mlpg_cus_per_xcd
-        self.flags, self.device = opts.flags, device
+        self.flags, self.device = opts.flags | (F.BATCH_KEEP_TRACKS if mlpg_only else 0), device
         h = C.c_void_p()
-        if pdf_set is not None:
+        if from_tracks:
+            F.check(L.jb_batch_create_from_tracks(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
+        elif pdf_set is not None:
             F.check(L.jb_batch_create_indexed(C.byref(vd), pdf_set._h, arr, len(utts), C.byref(opts), C.byref(h)))
         else:
             F.check(L.jb_batch_create(C.byref(vd), arr, len(utts), C.byref(opts), C.byref(h)))
@@ -321,6 +351,45 @@ class Batch:
 
     def __exit__(self, *a):
         self.close()
+
+
+def mlpg_batch(voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1, serial_gv: bool = False):
+    """jb_mlpg_batch = MlpgAdjust::create for every stream of every utterance (mlpg_adjust/mod.rs:31-51):
+    returns [[track of stream 0, 1, 2] per utterance], each [T][L] (NODATA in unvoiced LF0 frames)."""
+    L = F.lib()
+    vd, keep = voice.c_struct()
+    arr = (F.StateUtt * max(1, len(utts)))()
+    for i, u in enumerate(utts):
+        arr[i] = u.c_struct()
+    ns = len(voice.streams)
+    nfr = (C.c_size_t * max(1, len(utts)))()
+    opts = F.BatchOpts()
+    opts.device, opts.flags = device, (F.BATCH_SERIAL_GV if serial_gv else 0)
+    F.check(L.jb_mlpg_batch(C.byref(vd), arr, len(utts), C.byref(opts), None, nfr))
+    out = [[np.empty((nfr[i], voice.streams[s].vector_length)) for s in range(ns)] for i in range(len(utts))]
+    ptrs = (C.POINTER(C.c_double) * max(1, len(utts) * ns))(*[_dp(t) for u in out for t in u])
+    F.check(L.jb_mlpg_batch(C.byref(vd), arr, len(utts), C.byref(opts), ptrs, nfr))
+    del keep
+    return out
+
+
+def vocode_tracks_batch(voice: VoiceInfo, utts: Sequence["TrackUtterance"], device: int = -1):
+    """jb_vocode_tracks_batch = SpeechGenerator::new + generate_all on given parameter tracks
+    (speech.rs:25-50,87-96): a list of f64 PCM arrays."""
+    L = F.lib()
+    vd, keep = voice.c_struct()
+    arr = (F.TrackUtt * max(1, len(utts)))()
+    for i, u in enumerate(utts):
+        arr[i] = u.c_struct()
+    ns = (C.c_size_t * max(1, len(utts)))()
+    opts = F.BatchOpts()
+    opts.device = device
+    F.check(L.jb_vocode_tracks_batch(C.byref(vd), arr, len(utts), C.byref(opts), None, ns))
+    out = [np.empty(ns[i], dtype=np.float64) for i in range(len(utts))]
+    ptrs = (C.POINTER(C.c_double) * max(1, len(utts)))(*[_dp(o) for o in out])
+    F.check(L.jb_vocode_tracks_batch(C.byref(vd), arr, len(utts), C.byref(opts), ptrs, ns))
+    del keep
+    return out
 
 
 def paramgen_vocode_batch(voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,

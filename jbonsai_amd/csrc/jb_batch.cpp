@@ -143,14 +143,15 @@ struct DevPool {
 std::mutex g_pool_mu;
 std::map<int, DevPool> g_pool;
 
-size_t pool_cap()
+std::atomic<size_t> &pool_cap_ref()
 {
-    static const size_t cap = [] {
+    static std::atomic<size_t> cap{[] {
         const char *ev = getenv("JB_DEVICE_POOL_MB");
         return (size_t)(ev ? std::max(0L, atol(ev)) : 65536L) << 20;
-    }();
+    }()};
     return cap;
 }
+size_t pool_cap() { return pool_cap_ref().load(std::memory_order_relaxed); }
 
 size_t pool_round(size_t bytes)
 {
@@ -259,6 +260,21 @@ void release_cached_memory()
         hipSetDevice(kv.first);
         pool_trim_locked(kv.second, 0);
     }
+    if (cur >= 0)
+        hipSetDevice(cur);
+}
+
+void set_cached_memory_limit(size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    pool_cap_ref().store(bytes, std::memory_order_relaxed);
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    for (auto &kv : g_pool)
+        if (kv.second.cached > bytes) {
+            hipSetDevice(kv.first);
+            pool_trim_locked(kv.second, bytes);
+        }
     if (cur >= 0)
         hipSetDevice(cur);
 }
@@ -501,7 +517,7 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
     return JB_OK;
 }
 
-static int check_voice(const jb_voice_desc *v)
+static int check_voice(const jb_voice_desc *v, bool need_windows = true)
 {
     if (!v)
         return JB_ERR_INVALID;
@@ -546,7 +562,7 @@ static int check_voice(const jb_voice_desc *v)
         set_error("Stage::NonZero needs at least a gain and two line spectral frequencies");
         return JB_ERR_INVALID;
     }
-    for (uint32_t i = 0; i < v->nstream; i++) {
+    for (uint32_t i = 0; need_windows && i < v->nstream; i++) {
         const jb_stream_desc &s = v->stream[i];
         if (s.num_windows == 0 || s.num_windows > JB_MAX_WINDOW || !s.win_coef) {
             set_error("bad window description");
@@ -567,12 +583,72 @@ static int check_voice(const jb_voice_desc *v)
 }
 
 int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n, const jb_batch_opts *opts,
-                  Batch **out, const IndexSrc *idx)
+                  Batch **out, const IndexSrc *idx, const TrackSrc *trk)
 {
     *out = nullptr;
-    int rc = check_voice(voice);
+    int rc = check_voice(voice, trk == nullptr);
     if (rc)
         return rc;
+    // Parameter tracks as the source (SpeechGenerator::new, src/speech.rs:25-50).  The kernels behind the
+    // frame prologue want the LF0 stream's voiced flags and voiced runs, which the state walk of that
+    // stream produces: give it the track's runs of voiced / unvoiced frames (a frame is voiced where
+    // lf0 != NODATA, vocoder/mod.rs:73-77) as pseudo-states (msd 1 / 0, threshold 0.5).
+    std::vector<jb_state_utt> pseudo;
+    std::vector<std::vector<uint32_t>> pseudo_dur;
+    std::vector<std::vector<double>> pseudo_msd;
+    if (trk) {
+        if (n && !trk->utts)
+            return JB_ERR_INVALID;
+        pseudo.resize(n);
+        pseudo_dur.resize(n);
+        pseudo_msd.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const jb_track_utt &t = trk->utts[i];
+            if (t.n_spectrum != t.n_lf0 || t.n_spectrum != t.n_lpf) {
+                set_error("The length of spectrum, lf0, and lpf must be the same."); // speech.rs:32-34
+                return JB_ERR_INVALID;
+            }
+            if (t.n_lf0 && t.lf0_width != 1) {
+                set_error("The size of lf0 static vector must be 1."); // speech.rs:35-37
+                return JB_ERR_INVALID;
+            }
+            if (t.n_lpf && t.lpf_width % 2 == 0) {
+                set_error("The number of low-pass filter coefficient must be odd numbers."); // speech.rs:38-40
+                return JB_ERR_INVALID;
+            }
+            if (t.n_lf0 && (t.spectrum_width != voice->stream[0].vector_length ||
+                            t.lpf_width != voice->stream[2].vector_length)) {
+                set_error("track widths differ from the vocoder's nmcp / nlpf (Vocoder::new, vocoder/mod.rs:45-55)");
+                return JB_ERR_INVALID;
+            }
+            if (t.n_lf0 && (!t.spectrum || !t.lf0 || !t.lpf))
+                return JB_ERR_INVALID;
+            if (t.n_lf0 > 0xffffffffull / voice->fperiod) {
+                set_error("utterance too long");
+                return JB_ERR_INVALID;
+            }
+            std::vector<uint32_t> &d = pseudo_dur[i];
+            std::vector<double> &m = pseudo_msd[i];
+            for (size_t f = 0; f < t.n_lf0; f++) {
+                const double v = t.lf0[f] != kNoData ? 1.0 : 0.0;
+                if (m.empty() || m.back() != v) {
+                    m.push_back(v);
+                    d.push_back(0);
+                }
+                d.back()++;
+            }
+            jb_state_utt &u = pseudo[i];
+            memset(&u, 0, sizeof u);
+            u.num_states = (uint32_t)d.size();
+            u.durations = d.data();
+            u.stream[1].msd = m.data();
+            for (int si = 0; si < JB_MAX_STREAM; si++) {
+                u.stream[si].msd_threshold = 0.5;
+                u.stream[si].gv_weight = 1.0;
+            }
+        }
+        utts = pseudo.data();
+    }
     if (n && !utts)
         return JB_ERR_INVALID;
     int ndev = 0;
@@ -597,6 +673,13 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         return hip_fail(e, "hipSetDevice");
     b->device = dev;
     b->flags = opts ? opts->flags : 0;
+    if (b->flags & JB_BATCH_MLPG_ONLY)
+        b->flags |= JB_BATCH_KEEP_TRACKS; // the [frame][dim] tracks are the result
+    if (trk && (b->flags & JB_BATCH_MLPG_ONLY)) {
+        set_error("JB_BATCH_MLPG_ONLY needs state-level input");
+        return JB_ERR_INVALID;
+    }
+    b->from_tracks = trk != nullptr;
     b->voice = *voice;
     // (stream priorities were tried for the critical path and made every latency-bound kernel
     // 2-4x slower on this stack; ordering is done with events instead)
@@ -687,6 +770,11 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                 ds.mean = g.mean;
                 ds.var = g.var;
                 ds.msd = g.msd;
+            } else if (trk) {
+                ds.mean = ds.var = nullptr; // no MLPG: the tracks are given
+                if ((rc = b->upload(hs.msd, sizeof(double) * u.num_states, &dp)))
+                    return rc;
+                ds.msd = (const double *)dp;
             } else {
                 if (u.num_states && (!hs.mean || !hs.var)) {
                     set_error("stream mean/var missing");
@@ -753,10 +841,12 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         memset(&sd, 0, sizeof sd);
         sd.L = (int)hs.vector_length;
         sd.W = (int)hs.num_windows;
-        sd.is_msd = (int)hs.is_msd;
-        sd.use_gv = (int)hs.use_gv;
-        int off = 0, maxw = 0;
-        for (int w = 0; w < sd.W; w++) {
+        sd.is_msd = trk ? (si == 1) : (int)hs.is_msd;
+        sd.use_gv = trk ? 0 : (int)hs.use_gv;
+        if (trk)
+            sd.W = 1; // the window description is not read without MLPG (and may be absent)
+        int off = 0, maxw = trk ? 1 : 0;
+        for (int w = 0; !trk && w < sd.W; w++) {
             sd.win_width[w] = (int)hs.win_width[w];
             sd.win_off[w] = off;
             for (int k = 0; k < sd.win_width[w]; k++)
@@ -770,7 +860,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         sd.mt = (sd.BW == 3 && !sd.generic_solver && sd.L > 2 && sd.L <= mlpg_mt_max_dim()) ? 1 : 0;
         // MCP, non-MSD, [dim][frame]: its transpose is fused with mc2b (enqueue_paramgen)
         // (Stage::NonZero reads the [frame][dim] track itself: k_stage_coef)
-        sd.defer_out = (si == 0 && sd.mt && !sd.is_msd && voice->stage == 0) ? 1 : 0;
+        sd.defer_out = (si == 0 && sd.mt && !sd.is_msd && voice->stage == 0 && !trk) ? 1 : 0;
         const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L, nst = (size_t)sumS;
         if ((rc = b->dalloc(&sd.s_start, nst, false)) || (rc = b->dalloc(&sd.s_vpre, nst, false)) ||
             (rc = b->dalloc(&sd.s_rstart, nst, false)) || (rc = b->dalloc(&sd.s_rend, nst, false)) ||
@@ -783,7 +873,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
             (rc = b->dalloc(&sd.Tv, n, true)) || (rc = b->dalloc(&sd.gvlen, n, true)))
             return rc;
         const bool is_static = sd.BW == 1 && sd.W == 1 && !sd.use_gv && !sd.generic_solver;
-        if (!is_static) {
+        if (!is_static && !trk) {
             for (int j = 0; j < sd.BW; j++)
                 if ((rc = b->dalloc(&sd.A[j], nfl, false)) || (rc = b->dalloc(&sd.F[j], nfl, false)))
                     return rc;
@@ -815,6 +905,15 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         }
         if ((rc = b->dalloc(&sd.out, nfl, false)))
             return rc;
+        if (trk) // the tracks themselves: [frame][dim] per utterance at frame_off * L
+            for (size_t i = 0; i < n; i++) {
+                const jb_track_utt &t = trk->utts[i];
+                const double *src = si == 0 ? t.spectrum : si == 1 ? t.lf0 : t.lpf;
+                const size_t ne = (size_t)b->T[i] * (size_t)sd.L;
+                if (ne && (e = hipMemcpy(sd.out + (size_t)b->frame_off[i] * (size_t)sd.L, src, ne * sizeof(double),
+                                         hipMemcpyHostToDevice)) != hipSuccess)
+                    return hip_fail(e, "hipMemcpy(H2D tracks)");
+            }
     }
 
     // ---- vocoder ----
@@ -849,12 +948,13 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.lf0 = b->sd[1].out;
     vd.lpf = b->sd[2].out;
     const size_t nf = (size_t)sumT;
+    const bool mlpg_only = (b->flags & JB_BATCH_MLPG_ONLY) != 0; // no excitation, no PCM: no slabs for them
     b->total_samples = nf * (size_t)vd.fperiod;
     if ((rc = b->dalloc(&vd.bcoef, nf * (size_t)vd.nmcp, false)) ||
         (rc = b->dalloc(&vd.pitch, nf, false)) || (rc = b->dalloc(&vd.cur_start, nf, false)) ||
         (rc = b->dalloc(&vd.pinc, nf, false)) || (rc = b->dalloc(&vd.counter_start, nf, false)) ||
         (rc = b->dalloc(&vd.pmask, nf * (size_t)vd.nblk, false)) ||
-        (rc = b->dalloc(&vd.xin, b->total_samples, false)))
+        (rc = b->dalloc(&vd.xin, mlpg_only ? 1 : b->total_samples, false)))
         return rc;
     if (vd.stage > 0 && (rc = b->dalloc(&vd.bfirst, (size_t)std::max<size_t>(n, 1) * (size_t)vd.nmcp, true)))
         return rc;
@@ -864,16 +964,16 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
             return rc;
     }
     if (b->flags & JB_BATCH_PCM_I16)
-        rc = b->dalloc(&vd.pcm16, b->total_samples, false);
+        rc = b->dalloc(&vd.pcm16, mlpg_only ? 1 : b->total_samples, false);
     else
-        rc = b->dalloc(&vd.pcm, b->total_samples, false);
+        rc = b->dalloc(&vd.pcm, mlpg_only ? 1 : b->total_samples, false);
     if (rc)
         return rc;
     if (vd.nlpf - 1 > 64) {
         set_error("nlpf > 65 is not supported");
         return JB_ERR_UNSUPPORTED;
     }
-    if (b->flags & JB_BATCH_KEEP_TRACKS)
+    if ((b->flags & JB_BATCH_KEEP_TRACKS) && !mlpg_only)
         if ((rc = b->dalloc(&vd.exc, b->total_samples, false)))
             return rc;
     // frames whose excitation is the noise stream itself are not stored (not with the debug tap, which
@@ -1127,8 +1227,75 @@ static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
     return e;
 }
 
+// MlpgAdjust::create x3 and nothing behind it (JB_BATCH_MLPG_ONLY; jb_mlpg_batch): the three chains as
+// in enqueue_paramgen without pitch, pulses and excitation; the MCP track is turned to [frame][dim].
+int Batch::enqueue_mlpg_only()
+{
+    hipError_t e;
+    hipEventRecord(ev_fork, stream);
+    hipStreamWaitEvent(stream_lf0, ev_fork, 0);
+    hipStreamWaitEvent(stream_lpf, ev_fork, 0);
+    if ((e = launch_prep(bd, sd[1], 1, stream_lf0)) != hipSuccess ||
+        (e = launch_mlpg(bd, sd[1], 1, stream_lf0, nullptr)) != hipSuccess)
+        return hip_fail(e, "k_mlpg(lf0)");
+    hipEventRecord(ev_lf0, stream_lf0);
+    if (voice.nstream > 2) {
+        if ((e = launch_prep(bd, sd[2], 2, stream_lpf)) != hipSuccess ||
+            (e = launch_mlpg(bd, sd[2], 2, stream_lpf, nullptr)) != hipSuccess)
+            return hip_fail(e, "k_mlpg(lpf)");
+    }
+    hipEventRecord(ev_lpf, stream_lpf);
+    if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess ||
+        (e = launch_mlpg(bd, sd[0], 0, stream, ev_mcpbuild)) != hipSuccess)
+        return hip_fail(e, "k_mlpg(mcp)");
+    if (sd[0].defer_out && (e = launch_mc2b_mt(bd, sd[0], vd, true, stream)) != hipSuccess)
+        return hip_fail(e, "k_mc2b_mt");
+    hipStreamWaitEvent(stream, ev_lf0, 0);
+    hipStreamWaitEvent(stream, ev_lpf, 0);
+    return JB_OK;
+}
+
+// SpeechGenerator::new + generate_all on GIVEN parameter tracks (jb_vocode_tracks_batch): the LF0 chain
+// starts at the state walk over the track's voiced / unvoiced runs (voiced flags, run list), then pitch
+// and pulse schedule; the MCP chain is mc2b (or the Stage::NonZero conversion) straight from the track.
+int Batch::enqueue_from_tracks()
+{
+    hipError_t e;
+    hipEventRecord(ev_fork, stream);
+    hipStreamWaitEvent(stream_lf0, ev_fork, 0);
+    hipStreamWaitEvent(stream_lpf, ev_fork, 0);
+    if ((e = launch_prep(bd, sd[1], 1, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_prep(lf0)");
+    hipEventRecord(ev_prep, stream_lf0);
+    if ((e = launch_pitch(bd, vd, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_pitch");
+    if ((e = launch_pulse(bd, vd, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_pulse");
+    hipEventRecord(ev_lpf, stream_lpf); // the LPF track is resident
+    hipStreamWaitEvent(stream_lpf, ev_prep, 0);
+    if ((e = launch_excite_noise(bd, vd, stream_lpf)) != hipSuccess)
+        return hip_fail(e, "k_excite(noise)");
+    hipEventRecord(ev_build, stream_lpf);
+    e = vd.stage > 0 ? launch_stage_coef(bd, vd, stream) : launch_mc2b(bd, vd, stream);
+    if (e != hipSuccess)
+        return hip_fail(e, "k_mc2b");
+    if (vd.beta > 0.0 && (e = launch_postfilter(bd, vd, (uint64_t)sumT, stream)) != hipSuccess)
+        return hip_fail(e, "k_postfilter");
+    hipStreamWaitEvent(stream_lf0, ev_lpf, 0);
+    hipStreamWaitEvent(stream_lf0, ev_build, 0);
+    if ((e = launch_excite(bd, vd, stream_lf0)) != hipSuccess)
+        return hip_fail(e, "k_excite");
+    hipEventRecord(ev_lf0, stream_lf0);
+    hipStreamWaitEvent(stream, ev_lf0, 0);
+    return JB_OK;
+}
+
 int Batch::enqueue_paramgen()
 {
+    if (from_tracks)
+        return enqueue_from_tracks();
+    if (flags & JB_BATCH_MLPG_ONLY)
+        return enqueue_mlpg_only();
     hipError_t e;
     hipEventRecord(ev_fork, stream);
     hipStreamWaitEvent(stream_lf0, ev_fork, 0);
@@ -1185,6 +1352,14 @@ int Batch::run(bool timed)
     hipStreamWaitEvent(stream_voc, ev_mlpg_done, 0);
     if (timed)
         hipEventRecord(ev1, stream_voc);
+    if (flags & JB_BATCH_MLPG_ONLY) { // MlpgAdjust::create only: the tracks are the result
+        if (timed) {
+            hipEventRecord(ev2, stream_voc);
+            hipEventRecord(ev3, stream_voc);
+        }
+        hipEventRecord(ev_voc_done, stream_voc);
+        return JB_OK;
+    }
     if ((rc = enqueue_vocoder()))
         return rc;
     if (timed)
@@ -1453,6 +1628,10 @@ int stage_ring(int device, StageRing **out)
 int Batch::read_pcm_split(void *const *dst, size_t elem)
 {
     const char *slab = elem == 2 ? (const char *)vd.pcm16 : (const char *)vd.pcm;
+    if (flags & JB_BATCH_MLPG_ONLY) {
+        set_error("a JB_BATCH_MLPG_ONLY batch has no PCM");
+        return JB_ERR_INVALID;
+    }
     if (!slab) {
         set_error(elem == 2 ? "16-bit PCM needs JB_BATCH_PCM_I16" : "f64 PCM was replaced by the 16-bit sink");
         return JB_ERR_INVALID;
@@ -1566,6 +1745,18 @@ int jb_batch_create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t
         return JB_ERR_INVALID;
     Batch *b = nullptr;
     int rc = Batch::create(voice, utts, n_utts, opts, &b);
+    *out = (jb_batch *)b;
+    return rc;
+}
+
+int jb_batch_create_from_tracks(const jb_voice_desc *voice, const jb_track_utt *utts, size_t n_utts,
+                                const jb_batch_opts *opts, jb_batch **out)
+{
+    if (!out)
+        return JB_ERR_INVALID;
+    Batch *b = nullptr;
+    jb::TrackSrc src{utts};
+    int rc = Batch::create(voice, nullptr, n_utts, opts, &b, nullptr, &src);
     *out = (jb_batch *)b;
     return rc;
 }
@@ -1704,7 +1895,7 @@ void *jb_batch_device_pcm(jb_batch *hb, size_t *n)
         return nullptr;
     if (n)
         *n = b->total_samples;
-    if (b->sync()) // the slab is handed out finished and certified
+    if ((b->flags & JB_BATCH_MLPG_ONLY) || b->sync()) // the slab is handed out finished and certified
         return nullptr;
     return b->vd.pcm ? (void *)b->vd.pcm : (void *)b->vd.pcm16; // i16 slab for JB_BATCH_PCM_I16 batches
 }
@@ -1714,6 +1905,10 @@ int jb_batch_read_pcm(jb_batch *hb, size_t i, double *dst, size_t cap)
     Batch *b = (Batch *)hb;
     if (!b || i >= (size_t)b->B)
         return JB_ERR_INVALID;
+    if (b->flags & JB_BATCH_MLPG_ONLY) {
+        jb::set_error("a JB_BATCH_MLPG_ONLY batch has no PCM");
+        return JB_ERR_INVALID;
+    }
     size_t ns = (size_t)b->T[i] * b->voice.fperiod;
     if (cap < ns) {
         jb::set_error("pcm buffer too small");
@@ -1735,6 +1930,10 @@ int jb_batch_read_pcm_i16(jb_batch *hb, size_t i, int16_t *dst, size_t cap)
     Batch *b = (Batch *)hb;
     if (!b || i >= (size_t)b->B)
         return JB_ERR_INVALID;
+    if (b->flags & JB_BATCH_MLPG_ONLY) {
+        jb::set_error("a JB_BATCH_MLPG_ONLY batch has no PCM");
+        return JB_ERR_INVALID;
+    }
     if (!b->vd.pcm16) {
         jb::set_error("batch was created without JB_BATCH_PCM_I16");
         return JB_ERR_INVALID;
@@ -1787,6 +1986,12 @@ int jb_batch_read_track(jb_batch *hb, size_t i, uint32_t si, double *dst, size_t
 int jb_release_cached_memory(void)
 {
     jb::release_cached_memory();
+    return JB_OK;
+}
+
+int jb_set_cached_memory_limit(size_t megabytes)
+{
+    jb::set_cached_memory_limit(megabytes << 20);
     return JB_OK;
 }
 
@@ -1886,6 +2091,61 @@ int jb_paramgen_vocode_batch(const jb_voice_desc *voice, const jb_state_utt *utt
         if (ns && (rc = jb_batch_read_pcm(hb, i, pcm[i], ns)))
             return rc;
     }
+    return JB_OK;
+}
+
+int jb_vocode_tracks_batch(const jb_voice_desc *voice, const jb_track_utt *utts, size_t n, const jb_batch_opts *opts,
+                           double *const *pcm, size_t *n_samples)
+{
+    jb_batch *hb = nullptr;
+    int rc = jb_batch_create_from_tracks(voice, utts, n, opts, &hb);
+    if (rc)
+        return rc;
+    std::unique_ptr<Batch> guard((Batch *)hb);
+    if (n_samples)
+        for (size_t i = 0; i < n; i++)
+            n_samples[i] = jb_batch_num_samples(hb, i);
+    if (!pcm)
+        return JB_OK;
+    if ((rc = guard->run(false)) || (rc = guard->sync()))
+        return rc;
+    for (size_t i = 0; i < n; i++) {
+        size_t ns = jb_batch_num_samples(hb, i);
+        if (ns && (rc = jb_batch_read_pcm(hb, i, pcm[i], ns)))
+            return rc;
+    }
+    return JB_OK;
+}
+
+int jb_mlpg_batch(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n, const jb_batch_opts *opts,
+                  double *const *tracks, size_t *n_frames)
+{
+    jb_batch_opts o{};
+    if (opts)
+        o = *opts;
+    else
+        o.device = -1;
+    o.flags |= JB_BATCH_MLPG_ONLY;
+    jb_batch *hb = nullptr;
+    int rc = jb_batch_create(voice, utts, n, &o, &hb);
+    if (rc)
+        return rc;
+    std::unique_ptr<Batch> guard((Batch *)hb);
+    if (n_frames)
+        for (size_t i = 0; i < n; i++)
+            n_frames[i] = jb_batch_num_frames(hb, i);
+    if (!tracks)
+        return JB_OK;
+    if ((rc = guard->run(false)) || (rc = guard->sync()))
+        return rc;
+    const uint32_t ns = voice->nstream;
+    for (size_t i = 0; i < n; i++)
+        for (uint32_t si = 0; si < ns; si++) {
+            double *dst = tracks[i * ns + si];
+            const size_t ne = jb_batch_num_frames(hb, i) * (size_t)voice->stream[si].vector_length;
+            if (dst && ne && (rc = jb_batch_read_track(hb, i, si, dst, ne)))
+                return rc;
+        }
     return JB_OK;
 }
 

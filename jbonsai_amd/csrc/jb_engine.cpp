@@ -568,6 +568,29 @@ int jb_engine_load_from_bytes(const uint8_t *const *bufs, const size_t *lens, si
     return finish_load(e, out);
 }
 
+// Engine::new(voices, condition) (src/engine.rs:289-291).  The reference's VoiceSet holds Arc<Voice>
+// (voice_set.rs:17): the new engine SHARES the voices of `voices_of` and takes a COPY of the Condition of
+// `condition_of`.  With both arguments the same engine this is Engine::clone (engine.rs:246).
+int jb_engine_new(const jb_engine *voices_of, const jb_engine *condition_of, jb_engine **out)
+{
+    if (!out || !voices_of || !condition_of)
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    const jb::Engine *a = CENG(voices_of), *c = CENG(condition_of);
+    // a Condition made for another voice set: the interpolation weights and the per-stream arrays must fit
+    if (c->cond.w_duration.size() != a->voices.size() || c->cond.w_param.size() != a->voices[0]->streams.size() ||
+        c->cond.msd_threshold.size() != a->voices[0]->streams.size()) {
+        set_error("Weights length is invalid; the condition was made for another voice set");
+        return JB_ERR_WEIGHT;
+    }
+    std::unique_ptr<jb::Engine> e(new jb::Engine());
+    e->voices = a->voices;
+    e->cond = c->cond;
+    e->refresh_desc();
+    *out = (jb_engine *)e.release();
+    return JB_OK;
+}
+
 void jb_engine_free(jb_engine *e) { delete ENG(e); }
 
 // ---- Condition (src/engine.rs:127-243) ----
@@ -679,6 +702,31 @@ int jb_engine_set_interpolation_weight(jb_engine *e, int which, size_t stream, c
     } else {
         return JB_ERR_INVALID;
     }
+    return JB_OK;
+}
+
+// InterporationWeight::{get_duration, get_parameter, get_gv} (src/model/interporation_weight.rs:115-125)
+int jb_engine_get_interpolation_weight(const jb_engine *e, int which, size_t stream, double *w, size_t cap, size_t *n)
+{
+    const Condition &c = CENG(e)->cond;
+    const std::vector<double> *v = nullptr;
+    if (which == 0)
+        v = &c.w_duration;
+    else if (which == 1 || which == 2) {
+        const auto &tab = which == 1 ? c.w_param : c.w_gv;
+        if (stream >= tab.size())
+            return JB_ERR_INVALID; // reference: index panic
+        v = &tab[stream];
+    } else {
+        return JB_ERR_INVALID;
+    }
+    if (n)
+        *n = v->size();
+    if (!w)
+        return JB_OK;
+    if (cap < v->size())
+        return JB_ERR_BUFFER;
+    std::copy(v->begin(), v->end(), w);
     return JB_OK;
 }
 

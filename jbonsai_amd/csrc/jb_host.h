@@ -24,6 +24,7 @@ struct NoiseDev {
 };
 int noise_table(int device, size_t need, std::shared_ptr<NoiseDev> *out);
 void release_cached_memory(); // empties the per-device pools of finished batches' memory
+void set_cached_memory_limit(size_t bytes); // cap of a device's pool (JB_DEVICE_POOL_MB at start)
 // jb_synthesize_batch[_i16] on one device (jb_engine.cpp); host_threads = 0: default front-half thread count
 int synthesize_batch_impl(const jb_engine *e, const char *const *lines, const size_t *line_off, size_t n_utts,
                           int32_t device, size_t elem, void **pcm, size_t *n_samples, unsigned host_threads = 0);
@@ -41,6 +42,10 @@ struct PdfSet {
 struct IndexSrc {
     const PdfSet *set;
     const jb_index_utt *utts;
+};
+// Parameter tracks as the batch's source (SpeechGenerator::new, src/speech.rs:25-50): no MLPG
+struct TrackSrc {
+    const jb_track_utt *utts;
 };
 
 struct Batch {
@@ -96,8 +101,12 @@ struct Batch {
     ~Batch();
     template <class T> int dalloc(T **p, size_t n, bool zero);
     int upload(const void *host, size_t bytes, const void **dev);
+    bool from_tracks = false;        // created from parameter tracks: run() starts at the frame prologue
     static int create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,
-                      const jb_batch_opts *opts, Batch **out, const IndexSrc *idx = nullptr);
+                      const jb_batch_opts *opts, Batch **out, const IndexSrc *idx = nullptr,
+                      const TrackSrc *trk = nullptr);
+    int enqueue_mlpg_only();
+    int enqueue_from_tracks();
     int gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t n,
                       std::vector<StreamStatesDev> &out); // [n * nstream]: mean/var/msd filled
     int build_work(const jb_batch_opts *opts);

@@ -46,6 +46,8 @@ def _bind(L):
         getattr(L, "jb_engine_" + n).argtypes = [vp]
         getattr(L, "jb_engine_" + n).restype = sz
     L.jb_engine_set_interpolation_weight.argtypes = [vp, C.c_int, sz, dp, sz]
+    L.jb_engine_get_interpolation_weight.argtypes = [vp, C.c_int, sz, dp, sz, C.POINTER(sz)]
+    L.jb_engine_new.argtypes = [vp, vp, C.POINTER(vp)]
     L.jb_engine_model_shape.argtypes = [vp, sz, C.c_int, C.POINTER(sz), C.POINTER(sz)]
     L.jb_engine_pdf_table.argtypes = [vp, sz, C.c_int, sz, C.POINTER(C.POINTER(C.c_float)), C.POINTER(sz)]
     L.jb_engine_tree_index.argtypes = [vp, sz, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_int),
@@ -126,6 +128,17 @@ class _Condition:
         F.check(self._L().jb_engine_set_interpolation_weight(
             self._h(), which, stream, a.ctypes.data_as(C.POINTER(C.c_double)), len(a)))
 
+    def _getw(self, which, stream):
+        n = C.c_size_t()
+        F.check(self._L().jb_engine_get_interpolation_weight(self._h(), which, stream, None, 0, C.byref(n)))
+        a = np.zeros(n.value)
+        F.check(self._L().jb_engine_get_interpolation_weight(
+            self._h(), which, stream, a.ctypes.data_as(C.POINTER(C.c_double)), n.value, C.byref(n)))
+        return a
+
+    def get_interpolation_duration(self): return self._getw(0, 0)
+    def get_interpolation_parameter(self, stream): return self._getw(1, stream)
+    def get_interpolation_gv(self, stream): return self._getw(2, stream)
     def set_interpolation_duration(self, w): self._setw(0, 0, w)
     def set_interpolation_parameter(self, stream, w): self._setw(1, stream, w)
     def set_interpolation_gv(self, stream, w): self._setw(2, stream, w)
@@ -156,6 +169,17 @@ class Engine:
         lens = (C.c_size_t * max(1, len(voices)))(*[len(b) for b in voices])
         F.check(L.jb_engine_load_from_bytes(bufs, lens, len(voices), C.byref(h)))
         return cls(h, L)
+
+    @classmethod
+    def new(cls, voices_of: "Engine", condition_of: "Engine") -> "Engine":
+        """Engine::new(voices, condition) (src/engine.rs:289-291): the voices of one engine (shared) with a
+        copy of the Condition of another; Engine.new(e, e) is Engine::clone."""
+        h = C.c_void_p()
+        F.check(voices_of._L.jb_engine_new(voices_of._h, condition_of._h, C.byref(h)))
+        return cls(h, voices_of._L)
+
+    def clone(self) -> "Engine":
+        return Engine.new(self, self)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -24,6 +24,7 @@ extern "C" {
 #endif
 
 #define JBO_MAX_STREAM 3
+#define JBO_MAX_VOICES 8
 #define JBO_NODATA (-1e10) /* src/constants.rs:13 */
 
 typedef struct jbo_voice jbo_voice;
@@ -163,6 +164,26 @@ int jbo_synthesize(const jbo_voice *v, const jbo_cond *c, const char *const *lin
 int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *lines, int n,
                       double **pcm, size_t *n_samples, uint32_t **dur, uint32_t *S,
                       double **mcp, double **lf0, double **lpf, size_t *T);
+/* ---- several voices (VoiceSet::weighted, src/model/voice_set.rs:80-95) ----------------------
+ * InterporationWeight (src/model/interporation_weight.rs:48-126): one weight vector [nv] for the
+ * durations and one per stream for the parameters and for the GV pdfs.  Metadata, windows and options
+ * are the first voice's.  The single-voice entries above are these with nv = 1, weight 1.0. */
+typedef struct {
+    const double *duration;
+    const double *parameter[JBO_MAX_STREAM];
+    const double *gv[JBO_MAX_STREAM];
+} jbo_weights;
+int jbo_duration_params_multi(const jbo_voice *const *vs, int nv, const double *w, const char *const *labels,
+                              int n, double *mean_var);
+int jbo_durations_multi(const jbo_voice *const *vs, int nv, const double *w, const char *const *labels, int n,
+                        double speed, const double *times, uint32_t *dur_out);
+int jbo_stream_params_multi(const jbo_voice *const *vs, int nv, const double *w, int stream,
+                            const char *const *labels, int n, double *mean, double *var, double *msd);
+int jbo_gv_params_multi(const jbo_voice *const *vs, int nv, const double *w, int stream,
+                        const char *const *labels, int n, double *gv_mean, double *gv_var, uint8_t *gv_switch);
+int jbo_synthesize_multi_ex(const jbo_voice *const *vs, int nv, const jbo_weights *w, const jbo_cond *c,
+                            const char *const *lines, int n, double **pcm, size_t *n_samples, uint32_t **dur,
+                            uint32_t *S, double **mcp, double **lf0, double **lpf, size_t *T);
 /* state-level hot path: MLPG x3 + vocoder.  Returns malloc'd pcm. */
 int jbo_paramgen_vocode(int fs, int fperiod, double alpha, double volume,
                         const jbo_stream st[3], int nstream, uint32_t S, const uint32_t *dur,

@@ -7,8 +7,12 @@
  *   src/label.rs:35-113              (time-aligned label lines)
  *   src/engine.rs:84-125,294-366     (Condition::load_model, Engine::synthesize/generator)
  *   src/model/stream_parameter.rs:29-37 (additional half tone)
- * Single-voice only (interpolation weights = [1.0]): `weighted` multiplies by
- * 1.0, which is exact (src/model/voice_set.rs:80-95).
+ *   src/model/voice_set.rs:80-95     (VoiceSet::weighted: first*w0, then += w_i*param_i in voice order)
+ *   src/model/voice/model.rs:111-129 (ModelParameter::{mul, mul_add_assign})
+ * The single-voice entries are the multi-voice ones with one voice and weight 1.0 (`weighted`
+ * multiplies by 1.0, which is exact), so the reference's goldens pin the shared code.  The blend of
+ * two DIFFERENT voices itself is parity-unpinned: its only golden (`bonsai_multi`, src/lib.rs:77-91)
+ * needs the tohoku-f01 files, which are not in the reference tree.
  */
 #include "jbo_internal.h"
 
@@ -33,22 +37,49 @@ void jbo_cond_default(jbo_cond *c)
 
 void jbo_free(void *p) { free(p); }
 
-/* Models::duration (src/model/mod.rs:80-92): state index 2, nstate MeanVari per label */
-int jbo_duration_params(const jbo_voice *v, const char *const *labels, int n, double *mean_var)
+/* VoiceSet::weighted (src/model/voice_set.rs:80-95) over one pdf row of every voice:
+ * result = first.mul(w0) (model.rs:121-129), then result.mul_add_assign(w_i, param_i) (:111-119)
+ * in voice order; plain multiply then add (no FMA: the file is built with -ffp-contract=off). */
+static void weighted_rows(const float *const *rows, const double *w, int nv, int len, double *out)
 {
-    int ns = v->nstate;
+    for (int k = 0; k < len; k++)
+        out[k] = (double)rows[0][k] * w[0];
+    for (int v = 1; v < nv; v++)
+        for (int k = 0; k < len; k++)
+            out[k] += w[v] * (double)rows[v][k];
+}
+
+static const double ONE_WEIGHT[1] = {1.0};
+
+/* Models::duration (src/model/mod.rs:80-92): state index 2, nstate MeanVari per label */
+int jbo_duration_params_multi(const jbo_voice *const *vs, int nv, const double *w, const char *const *labels,
+                              int n, double *mean_var)
+{
+    int ns = vs[0]->nstate;
+    const float *rows[JBO_MAX_VOICES];
+    double buf[64];
+    if (nv < 1 || nv > JBO_MAX_VOICES || 2 * ns > 64)
+        return -1;
     for (int i = 0; i < n; i++) {
-        int tp, pi;
-        if (jbo_model_get_index(&v->dur, 2, labels[i], &tp, &pi) || tp < 0)
-            return -1;
-        const float *pdf = v->dur.pdf[tp] + (size_t)(pi - 1) * (size_t)v->dur.pdf_len;
+        for (int v = 0; v < nv; v++) {
+            int tp, pi;
+            if (jbo_model_get_index(&vs[v]->dur, 2, labels[i], &tp, &pi) || tp < 0)
+                return -1;
+            rows[v] = vs[v]->dur.pdf[tp] + (size_t)(pi - 1) * (size_t)vs[v]->dur.pdf_len;
+        }
+        weighted_rows(rows, w, nv, 2 * ns, buf);
         for (int s = 0; s < ns; s++) {
             /* ModelParameter::from_linear (voice/model.rs:99-109) */
-            mean_var[2 * (i * ns + s)] = (double)pdf[s];
-            mean_var[2 * (i * ns + s) + 1] = (double)pdf[s + ns];
+            mean_var[2 * (i * ns + s)] = buf[s];
+            mean_var[2 * (i * ns + s) + 1] = buf[s + ns];
         }
     }
     return 0;
+}
+
+int jbo_duration_params(const jbo_voice *v, const char *const *labels, int n, double *mean_var)
+{
+    return jbo_duration_params_multi(&v, 1, ONE_WEIGHT, labels, n, mean_var);
 }
 
 /* Rust f64::round = half away from zero = C round() */
@@ -116,14 +147,14 @@ static void estimate_with_frame_length(const double *mv, size_t n, double frame_
     }
 }
 
-int jbo_durations(const jbo_voice *v, const char *const *labels, int n, double speed,
-                  const double *times, uint32_t *dur)
+int jbo_durations_multi(const jbo_voice *const *vs, int nv, const double *w, const char *const *labels, int n,
+                        double speed, const double *times, uint32_t *dur)
 {
-    size_t ns = (size_t)v->nstate, S = (size_t)n * ns;
+    size_t ns = (size_t)vs[0]->nstate, S = (size_t)n * ns;
     if (n == 0)
         return 0;
     double *mv = (double *)malloc(sizeof(double) * 2 * S);
-    if (jbo_duration_params(v, labels, n, mv)) {
+    if (jbo_duration_params_multi(vs, nv, w, labels, n, mv)) {
         free(mv);
         return -1;
     }
@@ -161,50 +192,91 @@ int jbo_durations(const jbo_voice *v, const char *const *labels, int n, double s
     return 0;
 }
 
-/* Models::stream (src/model/mod.rs:98-118) */
-int jbo_stream_params(const jbo_voice *v, int si, const char *const *labels, int n, double *mean,
-                      double *var, double *msd)
+int jbo_durations(const jbo_voice *v, const char *const *labels, int n, double speed,
+                  const double *times, uint32_t *dur)
 {
-    const jbo_vstream *st = &v->st[si];
-    int ns = v->nstate, WL = st->L * st->W;
+    return jbo_durations_multi(&v, 1, ONE_WEIGHT, labels, n, speed, times, dur);
+}
+
+/* Models::stream (src/model/mod.rs:98-118) */
+int jbo_stream_params_multi(const jbo_voice *const *vs, int nv, const double *w, int si,
+                            const char *const *labels, int n, double *mean, double *var, double *msd)
+{
+    const jbo_vstream *st0 = &vs[0]->st[si];
+    int ns = vs[0]->nstate, WL = st0->L * st0->W, plen = 2 * WL + (st0->is_msd ? 1 : 0);
+    const float *rows[JBO_MAX_VOICES];
+    if (nv < 1 || nv > JBO_MAX_VOICES)
+        return -1;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)plen);
     for (int i = 0; i < n; i++)
         for (int s = 0; s < ns; s++) {
-            int tp, pi;
-            if (jbo_model_get_index(&st->model, 2 + s, labels[i], &tp, &pi) || tp < 0)
-                return -1;
-            const float *pdf = st->model.pdf[tp] + (size_t)(pi - 1) * (size_t)st->model.pdf_len;
+            for (int v = 0; v < nv; v++) {
+                const jbo_vstream *st = &vs[v]->st[si];
+                int tp, pi;
+                if (jbo_model_get_index(&st->model, 2 + s, labels[i], &tp, &pi) || tp < 0) {
+                    free(buf);
+                    return -1;
+                }
+                rows[v] = st->model.pdf[tp] + (size_t)(pi - 1) * (size_t)st->model.pdf_len;
+            }
+            /* mean, variance and (MSD streams) the msd weight blend alike (model.rs:111-129) */
+            weighted_rows(rows, w, nv, plen, buf);
             size_t row = (size_t)(i * ns + s);
             for (int k = 0; k < WL; k++) {
-                mean[row * (size_t)WL + (size_t)k] = (double)pdf[k];
-                var[row * (size_t)WL + (size_t)k] = (double)pdf[k + WL];
+                mean[row * (size_t)WL + (size_t)k] = buf[k];
+                var[row * (size_t)WL + (size_t)k] = buf[k + WL];
             }
             /* msd.unwrap_or(f64::MAX) (mod.rs:113) */
-            msd[row] = st->is_msd ? (double)pdf[2 * WL] : DBL_MAX;
+            msd[row] = st0->is_msd ? buf[2 * WL] : DBL_MAX;
         }
+    free(buf);
     return 0;
 }
 
+int jbo_stream_params(const jbo_voice *v, int si, const char *const *labels, int n, double *mean,
+                      double *var, double *msd)
+{
+    return jbo_stream_params_multi(&v, 1, ONE_WEIGHT, si, labels, n, mean, var, msd);
+}
+
 /* Models::gv (src/model/mod.rs:119-146) */
+int jbo_gv_params_multi(const jbo_voice *const *vs, int nv, const double *w, int si,
+                        const char *const *labels, int n, double *gv_mean, double *gv_var, uint8_t *gv_switch)
+{
+    const jbo_voice *v0 = vs[0];
+    const jbo_vstream *st0 = &v0->st[si];
+    if (!st0->use_gv || n == 0)
+        return 1;
+    const float *rows[JBO_MAX_VOICES];
+    if (nv < 1 || nv > JBO_MAX_VOICES)
+        return -1;
+    for (int v = 0; v < nv; v++) {
+        const jbo_vstream *st = &vs[v]->st[si];
+        int tp, pi;
+        if (jbo_model_get_index(&st->gv, 2, labels[0], &tp, &pi) || tp < 0)
+            return -1;
+        rows[v] = st->gv.pdf[tp] + (size_t)(pi - 1) * (size_t)st->gv.pdf_len;
+    }
+    double *buf = (double *)malloc(sizeof(double) * 2 * (size_t)st0->L);
+    weighted_rows(rows, w, nv, 2 * st0->L, buf);
+    for (int k = 0; k < st0->L; k++) {
+        gv_mean[k] = buf[k];
+        gv_var[k] = buf[k + st0->L];
+    }
+    free(buf);
+    /* gv_off_context of the first voice's global metadata (mod.rs:136-143, voice_set.rs:64-66) */
+    for (int i = 0; i < n; i++) {
+        uint8_t sw = !jbo_gv_off(v0, labels[i]);
+        for (int s = 0; s < v0->nstate; s++)
+            gv_switch[i * v0->nstate + s] = sw;
+    }
+    return 0;
+}
+
 int jbo_gv_params(const jbo_voice *v, int si, const char *const *labels, int n, double *gv_mean,
                   double *gv_var, uint8_t *gv_switch)
 {
-    const jbo_vstream *st = &v->st[si];
-    if (!st->use_gv || n == 0)
-        return 1;
-    int tp, pi;
-    if (jbo_model_get_index(&st->gv, 2, labels[0], &tp, &pi) || tp < 0)
-        return -1;
-    const float *pdf = st->gv.pdf[tp] + (size_t)(pi - 1) * (size_t)st->gv.pdf_len;
-    for (int k = 0; k < st->L; k++) {
-        gv_mean[k] = (double)pdf[k];
-        gv_var[k] = (double)pdf[k + st->L];
-    }
-    for (int i = 0; i < n; i++) {
-        uint8_t sw = !jbo_gv_off(v, labels[i]);
-        for (int s = 0; s < v->nstate; s++)
-            gv_switch[i * v->nstate + s] = sw;
-    }
-    return 0;
+    return jbo_gv_params_multi(&v, 1, ONE_WEIGHT, si, labels, n, gv_mean, gv_var, gv_switch);
 }
 
 /* Labels::load_from_strings + Labels::new (src/label.rs:35-113) */
@@ -291,10 +363,13 @@ int jbo_paramgen_vocode_beta(int fs, int fperiod, double alpha, double beta, dou
 }
 
 /* Engine::generator + generate_all (src/engine.rs:301-366) */
-int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *lines, int n,
-                      double **pcm_out, size_t *n_samples, uint32_t **dur_out, uint32_t *S_out,
-                      double **mcp_out, double **lf0_out, double **lpf_out, size_t *T_out)
+int jbo_synthesize_multi_ex(const jbo_voice *const *voices, int nv, const jbo_weights *w, const jbo_cond *c,
+                            const char *const *lines, int n, double **pcm_out, size_t *n_samples,
+                            uint32_t **dur_out, uint32_t *S_out, double **mcp_out, double **lf0_out,
+                            double **lpf_out, size_t *T_out)
 {
+    /* metadata, windows, options: the first voice's (voice_set.rs:64-77; engine.rs:84-125) */
+    const jbo_voice *v = voices[0];
     *pcm_out = NULL;
     *n_samples = 0;
     if (dur_out)
@@ -326,7 +401,7 @@ int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *
     }
     uint32_t S = (uint32_t)(m * v->nstate);
     uint32_t *dur = (uint32_t *)calloc(S, sizeof(uint32_t));
-    int rc = jbo_durations(v, labels, m, c->speed, c->phoneme_alignment ? times : NULL, dur);
+    int rc = jbo_durations_multi(voices, nv, w->duration, labels, m, c->speed, c->phoneme_alignment ? times : NULL, dur);
     jbo_stream st[3];
     double *mean[3] = {0}, *var[3] = {0}, *msd[3] = {0}, *gm[3] = {0}, *gv[3] = {0};
     uint8_t *gs[3] = {0};
@@ -337,7 +412,7 @@ int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *
         mean[i] = (double *)malloc(sizeof(double) * S * WL);
         var[i] = (double *)malloc(sizeof(double) * S * WL);
         msd[i] = (double *)malloc(sizeof(double) * S);
-        rc = jbo_stream_params(v, i, labels, m, mean[i], var[i], msd[i]);
+        rc = jbo_stream_params_multi(voices, nv, w->parameter[i], i, labels, m, mean[i], var[i], msd[i]);
         st[i].vector_length = (uint32_t)vs->L;
         st[i].num_windows = (uint32_t)vs->W;
         st[i].is_msd = (uint32_t)vs->is_msd;
@@ -353,7 +428,7 @@ int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *
             gm[i] = (double *)malloc(sizeof(double) * (size_t)vs->L);
             gv[i] = (double *)malloc(sizeof(double) * (size_t)vs->L);
             gs[i] = (uint8_t *)malloc(S);
-            if (jbo_gv_params(v, i, labels, m, gm[i], gv[i], gs[i]) == 0) {
+            if (jbo_gv_params_multi(voices, nv, w->gv[i], i, labels, m, gm[i], gv[i], gs[i]) == 0) {
                 st[i].gv_mean = gm[i];
                 st[i].gv_var = gv[i];
                 st[i].gv_switch = gs[i];
@@ -423,6 +498,18 @@ int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *
     free(labels);
     free(times);
     return rc;
+}
+
+int jbo_synthesize_ex(const jbo_voice *v, const jbo_cond *c, const char *const *lines, int n,
+                      double **pcm_out, size_t *n_samples, uint32_t **dur_out, uint32_t *S_out,
+                      double **mcp_out, double **lf0_out, double **lpf_out, size_t *T_out)
+{
+    jbo_weights w;
+    w.duration = ONE_WEIGHT;
+    for (int i = 0; i < JBO_MAX_STREAM; i++)
+        w.parameter[i] = w.gv[i] = ONE_WEIGHT;
+    return jbo_synthesize_multi_ex(&v, 1, &w, c, lines, n, pcm_out, n_samples, dur_out, S_out, mcp_out, lf0_out,
+                                   lpf_out, T_out);
 }
 
 int jbo_synthesize(const jbo_voice *v, const jbo_cond *c, const char *const *lines, int n,

@@ -59,14 +59,38 @@ class Stream(C.Structure):
     ]
 
 
+class Weights(C.Structure):
+    _fields_ = [
+        ("duration", C.POINTER(C.c_double)),
+        ("parameter", C.POINTER(C.c_double) * MAX_STREAM),
+        ("gv", C.POINTER(C.c_double) * MAX_STREAM),
+    ]
+
+
 _lib = None
+_lib_path = None
+
+
+def build_native() -> Path:
+    """The -O3 -march=native build of the same sources, made on the machine that runs it (bench.py's
+    cpu_baseline; oracle/Makefile `native`)."""
+    subprocess.run(["make", "-C", str(_HERE), "native"], check=True, capture_output=True)
+    return _HERE / "build" / "libjbo_oracle_native.so"
+
+
+def use_library(path=None):
+    """Bind the module to another build of the oracle (None: the default checker build)."""
+    global _lib, _lib_path
+    _lib, _lib_path = None, (None if path is None else Path(path))
+    return lib()
 
 
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(str(_LIB))
+        if _lib_path is None:
+            build()
+        L = C.CDLL(str(_lib_path or _LIB))
         L.jbo_voice_load.restype = C.c_void_p
         L.jbo_voice_load.argtypes = [C.c_char_p]
         L.jbo_voice_free.argtypes = [C.c_void_p]
@@ -151,6 +175,18 @@ def lib():
                                         C.POINTER(C.POINTER(C.c_double)),
                                         C.POINTER(C.POINTER(C.c_double)),
                                         C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t)]
+        vpp, dpp = C.POINTER(C.c_void_p), C.POINTER(C.c_double)
+        L.jbo_durations_multi.restype = C.c_int
+        L.jbo_durations_multi.argtypes = [vpp, C.c_int, dpp, C.POINTER(C.c_char_p), C.c_int, C.c_double,
+                                          C.c_void_p, C.c_void_p]
+        L.jbo_stream_params_multi.restype = C.c_int
+        L.jbo_stream_params_multi.argtypes = [vpp, C.c_int, dpp, C.c_int, C.POINTER(C.c_char_p), C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jbo_gv_params_multi.restype = C.c_int
+        L.jbo_gv_params_multi.argtypes = [vpp, C.c_int, dpp, C.c_int, C.POINTER(C.c_char_p), C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.jbo_synthesize_multi_ex.restype = C.c_int
+        L.jbo_synthesize_multi_ex.argtypes = [vpp, C.c_int, C.POINTER(Weights)] + L.jbo_synthesize_ex.argtypes[1:]
         L.jbo_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
@@ -336,6 +372,99 @@ class Voice:
                        mcp=take(mcp, (Tn, self.vector_length[0])),
                        lf0=take(lf0, (Tn,)),
                        lpf=take(lpf, (Tn, self.vector_length[2] if self.nstream > 2 else 0)))
+        for p in (pcm, dur, mcp, lf0, lpf):
+            if p:
+                self.L.jbo_free(p)
+        return res
+
+
+class VoiceSet:
+    """Several voices + InterporationWeight: VoiceSet::weighted (src/model/voice_set.rs:80-95) in front of
+    the single-voice path.  weights: {"duration": [nv], "parameter": [[nv] per stream], "gv": [[nv] per
+    stream]}; missing entries are the equal weights of InterporationWeight::new
+    (src/model/interporation_weight.rs:48-60).  PARITY UNPINNED for two different voices (the reference's
+    `bonsai_multi` golden needs voice files that are not in its tree)."""
+
+    def __init__(self, paths, weights=None):
+        self.voices = [Voice(p) for p in paths]
+        self.v0 = self.voices[0]
+        self.L = lib()
+        nv = len(self.voices)
+        eq = [1.0 / nv] * nv
+        w = dict(weights or {})
+        self.w_duration = np.ascontiguousarray(w.get("duration", eq), dtype=np.float64)
+        self.w_parameter = [np.ascontiguousarray(x, dtype=np.float64)
+                            for x in w.get("parameter", [eq] * self.v0.nstream)]
+        self.w_gv = [np.ascontiguousarray(x, dtype=np.float64) for x in w.get("gv", [eq] * self.v0.nstream)]
+        self._h = (C.c_void_p * nv)(*[v.h for v in self.voices])
+
+    def _weights(self):
+        w = Weights()
+        w.duration = _ptr(self.w_duration, C.c_double)
+        for i in range(self.v0.nstream):
+            w.parameter[i] = _ptr(self.w_parameter[i], C.c_double)
+            w.gv[i] = _ptr(self.w_gv[i], C.c_double)
+        return w
+
+    def durations(self, labels, speed=1.0, times=None):
+        out = np.zeros(len(labels) * self.v0.nstate, dtype=np.uint32)
+        t = None if times is None else np.ascontiguousarray(times, dtype=np.float64)
+        if self.L.jbo_durations_multi(self._h, len(self.voices), _ptr(self.w_duration, C.c_double), _strs(labels),
+                                      len(labels), float(speed), t.ctypes.data if t is not None else None,
+                                      out.ctypes.data):
+            raise RuntimeError("durations_multi")
+        return out
+
+    def stream_states(self, stream, labels, gv_weight=1.0, msd_threshold=0.5) -> StreamStates:
+        v0 = self.v0
+        S = len(labels) * v0.nstate
+        L, W = v0.vector_length[stream], v0.num_windows[stream]
+        mean, var, msd = np.zeros((S, W * L)), np.zeros((S, W * L)), np.zeros(S)
+        nv = len(self.voices)
+        if self.L.jbo_stream_params_multi(self._h, nv, _ptr(self.w_parameter[stream], C.c_double), stream,
+                                          _strs(labels), len(labels), mean.ctypes.data, var.ctypes.data,
+                                          msd.ctypes.data):
+            raise RuntimeError("stream_params_multi")
+        gm = gv = gs = None
+        if v0.use_gv[stream] and len(labels):
+            gm, gv, gs = np.zeros(L), np.zeros(L), np.zeros(S, dtype=np.uint8)
+            if self.L.jbo_gv_params_multi(self._h, nv, _ptr(self.w_gv[stream], C.c_double), stream, _strs(labels),
+                                          len(labels), gm.ctypes.data, gv.ctypes.data, gs.ctypes.data):
+                raise RuntimeError("gv_params_multi")
+        ww = [len(w) for w in v0.windows[stream]]
+        wc = [c for w in v0.windows[stream] for c in w]
+        return StreamStates(L, W, v0.is_msd[stream], v0.use_gv[stream], ww, wc, mean, var, msd, gm, gv, gs,
+                            gv_weight, msd_threshold)
+
+    def synthesize(self, lines, speed=1.0, volume=1.0, half_tone=0.0, alignment=False, beta=0.0,
+                   want_tracks=False):
+        c = Cond()
+        self.L.jbo_cond_default(C.byref(c))
+        c.speed, c.volume, c.additional_half_tone, c.beta = speed, volume, half_tone, beta
+        c.phoneme_alignment = int(alignment)
+        w = self._weights()
+        pcm, n = C.POINTER(C.c_double)(), C.c_size_t()
+        dur, S = C.POINTER(C.c_uint32)(), C.c_uint32()
+        mcp, lf0, lpf, T = C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.POINTER(C.c_double)(), C.c_size_t()
+        r = self.L.jbo_synthesize_multi_ex(self._h, len(self.voices), C.byref(w), C.byref(c), _strs(lines),
+                                           len(lines), C.byref(pcm), C.byref(n), C.byref(dur), C.byref(S),
+                                           C.byref(mcp), C.byref(lf0), C.byref(lpf), C.byref(T))
+        if r:
+            raise RuntimeError(f"oracle synthesize_multi failed: {r}")
+
+        def take(p, shape):
+            if not p or int(np.prod(shape)) == 0:
+                return np.zeros(shape)
+            return np.ctypeslib.as_array(p, shape=shape).copy()
+
+        out = take(pcm, (n.value,))
+        res = out
+        if want_tracks:
+            Tn, v0 = T.value, self.v0
+            res = dict(pcm=out, T=Tn,
+                       dur=(np.ctypeslib.as_array(dur, shape=(S.value,)).copy() if dur else np.zeros(0, np.uint32)),
+                       mcp=take(mcp, (Tn, v0.vector_length[0])), lf0=take(lf0, (Tn,)),
+                       lpf=take(lpf, (Tn, v0.vector_length[2] if v0.nstream > 2 else 0)))
         for p in (pcm, dur, mcp, lf0, lpf):
             if p:
                 self.L.jbo_free(p)

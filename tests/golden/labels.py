@@ -2,8 +2,46 @@
 
 SAMPLE_SENTENCE_1 / _2: /root/reference/src/lib.rs:27-36, 99-120.
 ALIGNED_1: /root/reference/src/label.rs:167-176 (same labels with times).
-BENCH_3: /root/reference/benches/bonsais.rs (43-label sentence is not reproduced).
+BENCH_LETTER: the 43-label sentence of /root/reference/benches/bonsais.rs:71-140
+  (bench_letter_labels.txt).
+GENJI: the 1,456 labels of /root/reference/examples/genji/genji.lab (genji_labels.txt), the only long
+  label sequence in the reference tree.
 """
+from pathlib import Path as _Path
+
+
+def _label_file(name):
+    text = (_Path(__file__).resolve().parent / name).read_text()
+    return [ln for ln in text.split("\n") if ln and not ln.startswith("#")]
+
+
+def label_pool_utterances(n, seed=11, lo=4, hi=24):
+    """n distinct utterances cut from the GENJI pool: seeded spans of lo..hi consecutive labels (what a
+    'batch of distinct label utterances' is made of in the BASELINE config 4/5 tests and bench records;
+    splitmix64, the generator of jbonsai_amd/synth.py)."""
+    mask = (1 << 64) - 1
+    state = [0x6A626F6E73616921 ^ seed]
+
+    def nxt():
+        state[0] = (state[0] + 0x9E3779B97F4A7C15) & mask
+        z = state[0]
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        return z ^ (z >> 31)
+
+    out, seen = [], set()
+    while len(out) < n:
+        k = lo + nxt() % (hi - lo + 1)
+        a = nxt() % (len(GENJI) - k)
+        if (a, k) in seen:
+            continue
+        seen.add((a, k))
+        out.append(GENJI[a:a + k])
+    return out
+
+
+BENCH_LETTER = _label_file("bench_letter_labels.txt")
+GENJI = _label_file("genji_labels.txt")
 
 SAMPLE_SENTENCE_1 = [
     "xx^xx-sil+b=o/A:xx+xx+xx/B:xx-xx_xx/C:xx_xx+xx/D:xx+xx_xx/E:xx_xx!xx_xx-xx/F:xx_xx#xx_xx@xx_xx|xx_xx/G:4_4%0_xx_xx/H:xx_xx/I:xx-xx@xx+xx&xx-xx|xx+xx/J:1_4/K:1+1-4",

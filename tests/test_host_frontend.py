@@ -133,6 +133,37 @@ def test_interpolation_weight_errors():
     assert ei.value.code == -7  # InvalidLength
 
 
+def test_interpolation_weight_getters_and_engine_new():
+    """InterporationWeight::{get_duration, get_parameter, get_gv} (interporation_weight.rs:115-125) and
+    Engine::new(voices, condition) / Engine::clone (engine.rs:246,289-291)."""
+    e = J.Engine.load([VOICE, VOICE])
+    c = e.condition
+    assert c.get_interpolation_duration().tolist() == [0.5, 0.5]
+    c.set_interpolation_duration([0.7, 0.3])
+    c.set_interpolation_parameter(1, [0.25, 0.75])
+    c.set_interpolation_gv(0, [1.0, 0.0])
+    assert c.get_interpolation_duration().tolist() == [0.7, 0.3]
+    assert c.get_interpolation_parameter(1).tolist() == [0.25, 0.75]
+    assert c.get_interpolation_parameter(0).tolist() == [0.5, 0.5]
+    assert c.get_interpolation_gv(0).tolist() == [1.0, 0.0]
+    with pytest.raises(J.JbError):
+        c.get_interpolation_parameter(3)
+    c.set_speed(1.3)
+    k = e.clone()
+    assert k.condition.get_speed() == 1.3 and k.condition.get_interpolation_duration().tolist() == [0.7, 0.3]
+    k.condition.set_speed(0.9)          # a copy of the condition, not a view
+    assert c.get_speed() == 1.3
+    assert k.states(SAMPLE_SENTENCE_1).durations.sum() > e.states(SAMPLE_SENTENCE_1).durations.sum()
+    e.close()                           # the voices are shared and outlive the first engine
+    assert k.states(SAMPLE_SENTENCE_1).durations.size == 40
+    one = J.Engine.load([VOICE])
+    with pytest.raises(J.JbError) as ei:
+        J.Engine.new(k, one)            # a condition made for one voice over a set of two
+    assert ei.value.code == -7
+    mixed = J.Engine.new(one, J.Engine.load([VOICE]))
+    assert mixed.num_voices == 1
+
+
 def test_two_voice_blend_matches_reference_formula(oracle_voice):
     """VoiceSet::weighted (voice_set.rs:80-95) with the same voice twice: the blend
     w0*p + w1*p must reproduce first*w0 then += w1*p."""

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
+from tests.conftest import VOICE
 from tests.golden.labels import ALIGNED_1, SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
 
 EPS = 1.0e-10  # approx::assert_abs_diff_eq!(..., epsilon = 1.0e-10)
@@ -245,3 +246,19 @@ def test_postfilter_changes_first_frame_only_gradually(oracle_voice):
     assert len(p1) == len(r["pcm"]) == 66480
     assert np.isfinite(p1).all()
     assert not np.allclose(p1, r["pcm"])
+
+
+def test_native_build_same_bits():
+    """bench.py's cpu_baseline times the oracle built -O3 -march=native (oracle/Makefile
+    `native`).  Contraction stays off and there is no fast-math: it must give the checker build's bits, so
+    the timed code is the pinned code."""
+    from tests.golden.labels import SAMPLE_SENTENCE_1
+
+    ref = O.Voice(VOICE).synthesize(SAMPLE_SENTENCE_1)
+    try:
+        O.use_library(O.build_native())
+        got = O.Voice(VOICE).synthesize(SAMPLE_SENTENCE_1)
+    finally:
+        O.use_library(None)
+    assert np.array_equal(got, ref)
+    assert abs(got[30000] - -980.6757547598129) < 1e-10  # src/lib.rs:46

@@ -68,6 +68,49 @@ def test_bench_launcher_spawns_ranks_and_plans_config3():
     assert "error" not in plan
 
 
+def _children_of(pid):
+    out = subprocess.run(["ps", "-o", "pid=", "--ppid", str(pid)], capture_output=True, text=True).stdout.split()
+    return [int(x) for x in out]
+
+
+def test_bench_launcher_deadline_and_signals():
+    """The launcher never waits for ever and never leaves ranks behind: with hanging ranks it ends them at
+    JB_BENCH_TIMEOUT_S and exits 124; on SIGTERM it ends them and exits 128+15."""
+    import signal
+    import time
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(JB_BENCH_DRYRUN="1", JB_BENCH_DRYRUN_SLEEP_S="300", JB_BENCH_TIMEOUT_S="12")
+    t0 = time.monotonic()
+    p = subprocess.Popen([sys.executable, str(root / "bench.py"), "--gpus", "2", "--utts", "8"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    kids = []
+    while time.monotonic() - t0 < 20 and len(kids) < 2:
+        kids = _children_of(p.pid)
+        time.sleep(0.2)
+    assert len(kids) == 2
+    assert p.wait(timeout=120) == 124
+    assert time.monotonic() - t0 < 90
+    time.sleep(0.5)
+    for k in kids:
+        assert not Path(f"/proc/{k}").exists() or "Z" in Path(f"/proc/{k}/stat").read_text().split()[2]
+    env["JB_BENCH_TIMEOUT_S"] = "600"
+    p = subprocess.Popen([sys.executable, str(root / "bench.py"), "--gpus", "2", "--utts", "8"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    t0 = time.monotonic()
+    kids = []
+    while time.monotonic() - t0 < 20 and len(kids) < 2:
+        kids = _children_of(p.pid)
+        time.sleep(0.2)
+    assert len(kids) == 2
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+    for k in kids:
+        assert not Path(f"/proc/{k}").exists()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

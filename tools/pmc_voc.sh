@@ -1,9 +1,13 @@
 #!/bin/bash
-# SQ counter passes for the dominant vocoder kernel (one bench step each; separate passes).
+# SQ counter passes for the dominant vocoder kernel (one bench step each; separate passes).  With JSON=path
+# the totals are also written as a record carrying the workload and the kernel-source fingerprint of the
+# bench line they were measured on (profiles/r03_pmc_sq_k_vocoder_lt.json: what bench.py may quote).
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=gpurun_out/pmc_voc
 mkdir -p $out
+[ -n "$JSON" ] && rm -f "$JSON"
+export JSON
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
@@ -21,5 +25,16 @@ for fn in f:
         if (sys.argv[2] if len(sys.argv) > 2 else "k_vocoder_l") in k:
             acc[r["Counter_Name"]]+=float(r["Counter_Value"]); n[r["Counter_Name"]]+=1
 for k,v in acc.items(): print(f"{k} {v:.4g} (dispatches {n[k]})")
+import json, os
+jp = os.environ.get("JSON")
+if jp:
+    rec = json.load(open(jp)) if os.path.exists(jp) else {"counters": {}}
+    rec["counters"].update({k: v for k, v in acc.items()})
+    line = [l for l in open(sys.argv[1] + ".log").read().splitlines() if l.startswith('{"metric"')][-1]
+    b = json.loads(line)
+    rec.update(kernel=sys.argv[2], batch=b["config"]["batch_per_gpu"], frames=b["config"]["frames_per_utterance"],
+               kernel_sources_sha16=b.get("kernel_sources_sha16"),
+               note="rocprofv3 --pmc, four separate passes of `bench.py --steps 1 --warmup 0`, totals over the kernel's dispatches")
+    json.dump(rec, open(jp, "w"), indent=1)
 PY
 done

@@ -2,15 +2,16 @@
 # Everything profiles/rNN_* is made from, in one go on the GPU box (separate rocprofv3 passes):
 #   bench line, kernel stats (streams overlapped and one-stream), timeline of one step, SQ counters of the
 #   dominant kernel, HBM traffic per kernel, section profile of the resident GV kernel.
-# usage: bash tools/profile_round.sh r02      -> gpurun_out/prof_r02/*
+# usage: bash tools/profile_round.sh r03      -> gpurun_out/prof_r03/* (and the files bench.py quotes -> profiles/)
 cd "$(dirname "$0")/.."
-R=${1:-r02}
+R=${1:-r03}
 out=gpurun_out/prof_$R
 rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
-# counters first: the bench line quotes them (profiles/${R}_traffic.json, profiles/${R}_pmc_sq_k_vocoder_lt.txt)
-bash tools/pmc_voc.sh > $out/${R}_pmc_sq_k_vocoder_lt.txt 2>&1 && cp $out/${R}_pmc_sq_k_vocoder_lt.txt profiles/
-bash tools/traffic.sh > $out/traffic.log 2>&1 && cp profiles/traffic.json $out/${R}_traffic.json && cp profiles/traffic.json profiles/${R}_traffic.json
+# counters first: the bench line quotes them (profiles/${R}_traffic.json, profiles/${R}_pmc_sq_k_vocoder_lt.json;
+# copy them from $out to profiles/ after the call: only gpurun_out/ comes back from the box)
+JSON=profiles/${R}_pmc_sq_k_vocoder_lt.json bash tools/pmc_voc.sh > $out/${R}_pmc_sq_k_vocoder_lt.txt 2>&1 && cp profiles/${R}_pmc_sq_k_vocoder_lt.json $out/
+bash tools/traffic.sh $R > $out/traffic.log 2>&1 && cp profiles/${R}_traffic.json $out/${R}_traffic.json
 python bench.py --steps 20 --warmup 5 > $out/${R}_bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 STEPS=4 bash tools/kstats.sh > $out/${R}_kernel_ms_per_step.txt 2>&1
 cp gpurun_out/kstats/k_kernel_stats.csv $out/${R}_kernel_stats.csv

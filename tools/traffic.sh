@@ -1,16 +1,19 @@
 #!/bin/bash
 # HBM traffic per kernel for one bench step: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in
-# SEPARATE passes (they do not fit one), kernel trace only.  Writes profiles/traffic.json.
+# SEPARATE passes (they do not fit one), kernel trace only.  Writes profiles/${R}_traffic.json (R = $1,
+# default r03) with the workload and the kernel-source fingerprint of the bench line it was measured on:
+# bench.py quotes it only for that workload on those sources.
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+R=${1:-r03}
 out=gpurun_out/traffic
 rm -rf $out; mkdir -p $out
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $out/$c -o p --output-format csv -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/$c.log 2>&1 || { echo "$c pass failed"; tail -5 $out/$c.log; exit 1; }
 done
-python3 - $out <<'PY'
+python3 - $out $R <<'PY'
 import sys, glob, csv, json, collections
-out = sys.argv[1]
+out, R = sys.argv[1], sys.argv[2]
 acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 cnt = collections.Counter()
 for c in acc:
@@ -28,6 +31,9 @@ dom = max((k for k in acc["FETCH_SIZE"] if "k_vocoder" in k), key=lambda k: acc[
 samples = cfg["samples_per_step_per_gpu"]
 res = {
     "batch": cfg["batch_per_gpu"], "frames": cfg["frames_per_utterance"], "kernel": dom,
+    "kernel_sources_sha16": bench.get("kernel_sources_sha16"),
+    "whole_step_hbm_bytes": sum(acc["FETCH_SIZE"].values()) + sum(acc["WRITE_SIZE"].values()),
+    "whole_step_fetch_bytes_raw": sum(acc["FETCH_SIZE"].values()), "whole_step_write_bytes": sum(acc["WRITE_SIZE"].values()),
     "fetch_bytes_raw": acc["FETCH_SIZE"][dom], "write_bytes": acc["WRITE_SIZE"][dom],
     "hbm_bytes_per_launch": acc["FETCH_SIZE"][dom] + acc["WRITE_SIZE"][dom],
     "algorithmic_bytes_per_launch": 8.67 * samples,
@@ -40,7 +46,7 @@ res = {
     "all_kernels": {k: {"fetch_bytes_raw": acc["FETCH_SIZE"][k], "write_bytes": acc["WRITE_SIZE"][k], "launches": cnt[k]}
                     for k in sorted(acc["FETCH_SIZE"])},
 }
-json.dump(res, open("profiles/traffic.json", "w"), indent=1)
+json.dump(res, open(f"profiles/{R}_traffic.json", "w"), indent=1)
 tot_f = sum(acc["FETCH_SIZE"].values()); tot_w = sum(acc["WRITE_SIZE"].values())
 print(f"dominant {dom}: fetch {res['fetch_bytes_raw']/1e9:.2f} GB write {res['write_bytes']/1e9:.2f} GB; whole step fetch {tot_f/1e9:.1f} GB write {tot_w/1e9:.1f} GB")
 PY
