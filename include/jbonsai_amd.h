@@ -402,6 +402,15 @@ size_t jb_generator_total_frames(const jb_generator *g);
 /* generate_step: writes fperiod samples to buf, returns fperiod, 0 when exhausted,
  * or a negative jb_status (JB_ERR_BUFFER where the reference panics). */
 long jb_generator_step(jb_generator *g, double *buf, size_t buf_len);
+/* Up to max_frames generate_step calls in one: writes n * fperiod samples to buf, n = min(max_frames,
+ * frames left, buf_len / fperiod), and returns that sample count (0 when exhausted, JB_ERR_BUFFER if buf
+ * cannot hold one frame).  One device-to-host copy for the n frames.
+ * How the generator works: the whole utterance is enqueued on the device when the generator is made (the
+ * path of jb_synthesize: nothing a SpeechGenerator holds can change between steps) and the call returns
+ * without waiting; steps hand out the finished PCM.  While the utterance is still in flight the first 8
+ * single-frame steps are served by the serial recursion with persistent state on a side stream, so the
+ * first frame does not wait for the last. */
+long jb_generator_step_n(jb_generator *g, double *buf, size_t buf_len, size_t max_frames);
 void jb_generator_free(jb_generator *g);
 
 /* ------------------------------------------------------------------------ */

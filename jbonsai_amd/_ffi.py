@@ -145,7 +145,7 @@ SYMBOLS = [
     "jb_engine_model_shape", "jb_engine_pdf_table", "jb_engine_tree_index",
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
     "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",
-    "jb_generator_total_frames", "jb_generator_step", "jb_generator_free",
+    "jb_generator_total_frames", "jb_generator_step", "jb_generator_step_n", "jb_generator_free",
     "jb_lpt_partition", "jb_paramgen_vocode_batch_multi", "jb_synthesize_batch_multi", "jb_synthesize_batch_i16_multi",
     "jb_last_error", "jb_device_count", "jb_device_arch", "jb_version",
 ]

@@ -510,10 +510,24 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
     return JB_OK;
 }
 
+// SpeechGenerator (src/speech.rs:9-96).  The reference's generator owns its three parameter tracks and a
+// Vocoder and advances one frame per generate_step; nothing can change between steps, so what a step
+// returns is fixed when the generator is made.  Here the whole utterance is put on the device's queue at
+// creation (parameter generation, the time-chunked vocoder, the hand-off certification: the path of
+// jb_synthesize) and NOT waited for; a step hands out the next frame(s) of the finished PCM from a block
+// cache on the host.  Until that run has finished, the first kGenSerialFrames steps are served by the
+// serial recursion one frame at a time on a side stream (persistent filter / excitation state in
+// vd.state), so that the first samples arrive without waiting for the last ones.
 struct Generator {
     std::unique_ptr<Batch> batch;
     size_t fperiod = 0, next = 0, total = 0;
+    bool ahead_ready = false;   // the whole-utterance run is finished and certified
+    bool serial_armed = false;  // the side stream waits for parameter generation
+    std::vector<double> cache;  // PCM of frames [cache_first, cache_first + cache_frames)
+    size_t cache_first = 0, cache_frames = 0;
 };
+constexpr size_t kGenSerialFrames = 8;  // steps that may be served serially while the utterance is in flight
+constexpr size_t kGenBlockFrames = 256; // frames per D2H block of the cache (480 KB at 240 samples per frame)
 
 } // namespace jb
 
@@ -1131,17 +1145,15 @@ int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_
     std::unique_ptr<jb::Generator> g(new jb::Generator());
     jb_batch_opts opts{};
     opts.device = -1;
-    opts.flags = JB_BATCH_SERIAL;
     jb::Batch *b = nullptr;
     if ((rc = jb::Batch::create(&CENG(e)->desc, &st.utt, 1, &opts, &b)))
         return rc;
     g->batch.reset(b);
     g->fperiod = b->voice.fperiod;
     g->total = b->T[0];
-    // Engine::generator runs all three MLPGs before returning (src/engine.rs:333-357)
-    if (hipSetDevice(b->device) != hipSuccess)
-        return JB_ERR_DEVICE;
-    if ((rc = b->enqueue_paramgen()) || (rc = b->sync()) || (rc = b->build_generator_work()))
+    // Engine::generator runs all three MLPGs before returning (src/engine.rs:333-357); here they are
+    // enqueued, with the vocoder behind them, and the call returns while the device works
+    if ((rc = b->build_generator_work()) || (rc = b->run(false)))
         return rc;
     *out = (jb_generator *)g.release();
     return JB_OK;
@@ -1153,6 +1165,18 @@ size_t jb_generator_synthesized_frames(const jb_generator *g)
     return g ? ((const jb::Generator *)g)->next : 0;
 }
 size_t jb_generator_total_frames(const jb_generator *g) { return g ? ((const jb::Generator *)g)->total : 0; }
+
+// waits for the whole-utterance run (and its certification / redo) once
+static int generator_finish(jb::Generator *g)
+{
+    if (g->ahead_ready)
+        return JB_OK;
+    int rc = g->batch->sync();
+    if (rc)
+        return rc;
+    g->ahead_ready = true;
+    return JB_OK;
+}
 
 long jb_generator_step(jb_generator *hg, double *buf, size_t buf_len)
 {
@@ -1168,16 +1192,62 @@ long jb_generator_step(jb_generator *hg, double *buf, size_t buf_len)
     jb::Batch *b = g->batch.get();
     if (hipSetDevice(b->device) != hipSuccess)
         return JB_ERR_DEVICE;
-    hipError_t he = launch_vocoder(b->bd, b->vd, b->gen_work_dev + g->next, 1, b->stream);
-    if (he != hipSuccess)
-        return hip_fail(he, "k_vocoder");
-    int rc = b->sync();
-    if (rc)
+    int rc;
+    if (!g->ahead_ready && (g->next >= kGenSerialFrames || hipEventQuery(b->ev_voc_done) == hipSuccess) &&
+        (rc = generator_finish(g)))
         return rc;
-    if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, buf, g->fperiod * sizeof(double), false)))
-        return rc;
+    if (!g->ahead_ready) {
+        // the utterance is still in flight: this frame from the serial recursion on the side stream
+        hipStream_t ss = b->stream_lf0;
+        if (!g->serial_armed) {
+            hipStreamWaitEvent(ss, b->ev_mlpg_done, 0);
+            g->serial_armed = true;
+        }
+        hipError_t he = launch_vocoder(b->bd, b->vd, b->gen_work_dev + g->next, 1, ss);
+        if (he != hipSuccess)
+            return hip_fail(he, "k_vocoder");
+        if ((he = hipStreamSynchronize(ss)) != hipSuccess)
+            return hip_fail(he, "generator step");
+        if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, buf, g->fperiod * sizeof(double), false)))
+            return rc;
+        g->next++;
+        return (long)g->fperiod;
+    }
+    if (g->next < g->cache_first || g->next >= g->cache_first + g->cache_frames) {
+        const size_t nf = std::min(kGenBlockFrames, g->total - g->next);
+        g->cache.resize(nf * g->fperiod);
+        if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, g->cache.data(), nf * g->fperiod * sizeof(double), false)))
+            return rc;
+        g->cache_first = g->next;
+        g->cache_frames = nf;
+    }
+    memcpy(buf, g->cache.data() + (g->next - g->cache_first) * g->fperiod, g->fperiod * sizeof(double));
     g->next++;
     return (long)g->fperiod;
+}
+
+long jb_generator_step_n(jb_generator *hg, double *buf, size_t buf_len, size_t max_frames)
+{
+    jb::Generator *g = (jb::Generator *)hg;
+    if (!g)
+        return JB_ERR_INVALID;
+    if (g->total <= g->next || max_frames == 0)
+        return 0;
+    if (buf_len < g->fperiod || !buf) {
+        set_error("The length of speech buffer must be larger than fperiod.");
+        return JB_ERR_BUFFER;
+    }
+    const size_t nf = std::min(std::min(max_frames, g->total - g->next), buf_len / g->fperiod);
+    jb::Batch *b = g->batch.get();
+    if (hipSetDevice(b->device) != hipSuccess)
+        return JB_ERR_DEVICE;
+    int rc = generator_finish(g);
+    if (rc)
+        return rc;
+    if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, buf, nf * g->fperiod * sizeof(double), false)))
+        return rc;
+    g->next += nf;
+    return (long)(nf * g->fperiod);
 }
 
 void jb_generator_free(jb_generator *g) { delete (jb::Generator *)g; }

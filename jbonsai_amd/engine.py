@@ -77,6 +77,8 @@ def _bind(L):
         getattr(L, "jb_generator_" + n).restype = sz
     L.jb_generator_step.argtypes = [vp, dp, sz]
     L.jb_generator_step.restype = C.c_long
+    L.jb_generator_step_n.argtypes = [vp, dp, sz, sz]
+    L.jb_generator_step_n.restype = C.c_long
     L.jb_generator_free.argtypes = [vp]
     L.jb_generator_free.restype = None
     L._engine_bound = True
@@ -325,13 +327,23 @@ class SpeechGenerator:
             F.check(int(r))
         return int(r)
 
+    def generate_steps(self, speech: np.ndarray, max_frames: int) -> int:
+        """Up to max_frames generate_step calls in one (jb_generator_step_n): returns the samples written."""
+        assert speech.dtype == np.float64 and speech.flags["C_CONTIGUOUS"]
+        r = self._L.jb_generator_step_n(self._h, speech.ctypes.data_as(C.POINTER(C.c_double)), speech.size,
+                                        int(max_frames))
+        if r < 0:
+            F.check(int(r))
+        return int(r)
+
     def generate_all(self) -> np.ndarray:
+        """generate_all (src/speech.rs:87-96): the frames not yet synthesized."""
         fp = self.fperiod()
-        n0 = self.synthesized_frames()
-        buf = np.zeros((self.total_frames() - n0) * fp)
-        k = 0
-        while self.generate_step(buf[k * fp:]) > 0:
-            k += 1
+        left = self.total_frames() - self.synthesized_frames()
+        buf = np.zeros(left * fp)
+        if left:
+            got = self.generate_steps(buf, left)
+            assert got == left * fp
         return buf
 
     def close(self):
