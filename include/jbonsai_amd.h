@@ -115,7 +115,7 @@ typedef struct jb_batch_opts {
 #define JB_BATCH_GENERIC_MLPG 2u /* un-fused, reference-shaped MLPG kernels (A/B parity tests) */
 #define JB_BATCH_SERIAL 4u       /* one wave per utterance, no time-chunking (reference-shaped recursion) */
 #define JB_BATCH_WAVE_KERNEL 8u  /* always the wave-per-chunk vocoder kernel (A/B tests) */
-#define JB_BATCH_PAIR_KERNEL 16u /* always the lane-pair throughput kernel (A/B tests) */
+#define JB_BATCH_LANE_KERNEL 16u /* always the lane-triple throughput kernel, whatever the batch size (A/B tests) */
 #define JB_BATCH_PCM_I16 64u     /* fused 16-bit sink: the vocoder writes clamped i16 PCM (value.min(32767).max(-32768)
                                     as i16, examples/is-bonsai/main.rs:44-48) instead of f64: 2 B/sample leave
                                     the GPU instead of 8.  jb_batch_read_pcm / device_pcm then fail; use the

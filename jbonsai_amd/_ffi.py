@@ -25,7 +25,7 @@ BATCH_KEEP_TRACKS = 1
 BATCH_GENERIC_MLPG = 2
 BATCH_SERIAL = 4
 BATCH_WAVE_KERNEL = 8
-BATCH_PAIR_KERNEL = 16
+BATCH_LANE_KERNEL = 16
 BATCH_SERIAL_GV = 32
 BATCH_PCM_I16 = 64
 BATCH_MLPG_ONLY = 128

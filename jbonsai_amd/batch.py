@@ -219,7 +219,7 @@ class Batch:
         opts.flags = ((F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
                       | (F.BATCH_SERIAL if serial else 0) | (F.BATCH_SERIAL_GV if serial_gv else 0)
                       | (F.BATCH_PCM_I16 if pcm_i16 else 0) | (F.BATCH_MLPG_ONLY if mlpg_only else 0)
-                      | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "pair": F.BATCH_PAIR_KERNEL}[kernel])
+                      | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "triple": F.BATCH_LANE_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
         opts.mlpg_cus_per_xcd = mlpg_cus_per_xcd
         self.flags, self.device = opts.flags | (F.BATCH_KEEP_TRACKS if mlpg_only else 0), device

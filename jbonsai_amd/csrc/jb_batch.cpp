@@ -857,7 +857,9 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         sd.BW = (maxw / 2) * 2 + 1; // Windows::max_width()*2+1 (window.rs:19-21, mlpg.rs:27)
         sd.generic_solver = (b->flags & JB_BATCH_GENERIC_MLPG) ? 1 : 0;
         sd.serial_gv = (b->flags & JB_BATCH_SERIAL_GV) ? 1 : 0;
-        sd.mt = (sd.BW == 3 && !sd.generic_solver && sd.L > 2 && sd.L <= mlpg_mt_max_dim()) ? 1 : 0;
+        // [dim][frame] workspace with the fused kernels: band width 3, up to three windows (the sliding-window
+        // build), 3..60 dims; everything else takes the generic reference-shaped kernels
+        sd.mt = (sd.BW == 3 && sd.W <= 3 && !sd.generic_solver && sd.L > 2 && sd.L <= mlpg_mt_max_dim()) ? 1 : 0;
         // MCP, non-MSD, [dim][frame]: its transpose is fused with mc2b (enqueue_paramgen)
         // (Stage::NonZero reads the [frame][dim] track itself: k_stage_coef)
         sd.defer_out = (si == 0 && sd.mt && !sd.is_msd && voice->stage == 0 && !trk) ? 1 : 0;
@@ -888,11 +890,10 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                 if ((rc = b->dalloc(&sd.gv_part, 7 * nbl * (size_t)sd.gv_ntile * 4, false)) ||
                     (rc = b->dalloc(&sd.gv_scal, 6 * nbl * 4, false)))
                     return rc;
-                // resident GV (one persistent launch, jb_gv_gang.hip) unless JB_GV_GANG=0 or the CUs are
-                // partitioned (its grid is sized for the whole device)
-                static const bool gang_off = getenv("JB_GV_GANG") && atoi(getenv("JB_GV_GANG")) == 0;
+                // resident GV (one persistent launch, jb_gv_gang.hip) unless the CUs are partitioned (its
+                // grid is sized for the whole device) or a row has more tiles than a gang can hold
                 int tiles = 0, gangs = 0;
-                if (!gang_off && !b->cu_split && maxT > 0 &&
+                if (!b->cu_split && maxT > 0 &&
                     gv_gang_plan(dev, maxT, (uint32_t)nbl, &tiles, &gangs)) {
                     uint8_t *ctl;
                     if ((rc = b->dalloc(&ctl, gv_gang_ctl_bytes(gangs), true)))
@@ -978,8 +979,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
             return rc;
     // frames whose excitation is the noise stream itself are not stored (not with the debug tap, which
     // wants every sample, nor with the one-pass kernel for other tap counts / frame periods)
-    static const bool skip_off = getenv("JB_EXCITE_SKIP") && atoi(getenv("JB_EXCITE_SKIP")) == 0;
-    vd.skip_unvoiced = (!skip_off && !vd.exc && excite_is_split(vd)) ? 1 : 0;
+    vd.skip_unvoiced = (!vd.exc && excite_is_split(vd)) ? 1 : 0;
     vd.state_stride = vd.stage > 0 ? mglsa_state_doubles(vd.stage) : vocoder_state_doubles(vd.nmcp);
     if ((rc = b->dalloc(&vd.state, (size_t)vd.state_stride * n, true)))
         return rc;
@@ -1018,28 +1018,22 @@ int Batch::build_work(const jb_batch_opts *opts)
     // utterances a few hundred fail at every length and settle at their checkpoint).  24 -> 20 earlier in the
     // round: vocoder 67.8 -> 66.3 ms, 136 -> 220 failing hand-offs with distinct utterances.
     warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 18;
-    if (!(opts && opts->warmup_frames) && getenv("JB_WARMUP_FRAMES")) // tuning aid
-        warmup_frames = (uint32_t)std::max(1, atoi(getenv("JB_WARMUP_FRAMES")));
     verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
     uint32_t ch = opts ? opts->chunk_frames : 0;
-    // lane-pair throughput kernel: worth it once the batch holds enough frames to give
-    // every SIMD 32 chunks that are long against the warm-up
-    // (measured crossover against the wave kernel at one item per SIMD: between 6 and 8 utterances of
-    // 25.5 k frames -- 22.4 vs 26.7 ms at 6, 28.5 vs 26.9 at 8; tools/ab_lpmin.sh)
-    uint64_t lp_min = 190000;
-    if (const char *e = getenv("JB_LP_MIN_FRAMES"))
-        lp_min = strtoull(e, nullptr, 10);
+    // lane-triple throughput kernel: worth it once the batch holds enough frames to give every SIMD two
+    // waves of 21 chunks that are long against the warm-up (measured crossover against the wave kernel at
+    // one item per SIMD: between 6 and 8 utterances of 25.5 k frames -- 22.4 vs 26.7 ms at 6, 28.5 vs 26.9
+    // at 8)
+    constexpr uint64_t lp_min = 190000;
     // (the lane-triple kernel walks the samples of a frame two at a time)
     lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vd.stage == 0 && vocoder_ls_supported(vd.nmcp) &&
               (vd.fperiod & 1) == 0 &&
-              (sumT >= lp_min || (flags & JB_BATCH_PAIR_KERNEL));
+              (sumT >= lp_min || (flags & JB_BATCH_LANE_KERNEL));
     if (serial) {
         ch = 0;
     } else if (ch == 0 && lp_mode) {
         // two waves on every SIMD the vocoder may use: 8 XCDs x (32 - k) CUs x 4 SIMDs x 2
-        uint64_t target = 64ull * (32 - cu_split) * (uint64_t)vocoder_ls_chunks_per_wave();
-        if (const char *e = getenv("JB_LP_TARGET"))
-            target = strtoull(e, nullptr, 10);
+        const uint64_t target = 64ull * (32 - cu_split) * (uint64_t)vocoder_ls_chunks_per_wave();
         uint64_t c = (sumT + target - 1) / target;
         // while the batch cannot fill the chip the time of the launch is that of ONE chunk (chunk +
         // warm-up frames): chunks down to 16 frames.  Shorter chunks mean more hand-off positions and
@@ -1049,14 +1043,10 @@ int Batch::build_work(const jb_batch_opts *opts)
         // step, 64 x 4,600 32.7 -> 23.0, 256 x 2,000 33.4 -> 23.5, 1024 x 500 22.8 -> 21.0 -- and 12 or
         // 8 gain nothing more.  (The earlier floor had been tuned on copies of one utterance, whose
         // hand-offs all pass.)
-        uint64_t cmin = 16;
-        if (const char *e = getenv("JB_CHUNK_MIN"))
-            cmin = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
+        constexpr uint64_t cmin = 16;
         ch = (uint32_t)std::max<uint64_t>(c, cmin);
         // (no rounding of the chunk length: 153 frames instead of 156 on config 2 is 1.7 % fewer frames per
         // chunk-with-warm-up and still fits the chip -- 42,752 items for 43,008 slots)
-        static const int ch_gran = getenv("JB_LP_CHUNK_GRAN") ? std::max(1, atoi(getenv("JB_LP_CHUNK_GRAN"))) : 1;
-        ch = (ch + ch_gran - 1) / ch_gran * ch_gran;
         // every utterance rounds its chunk count up: with ragged lengths the items can exceed the two
         // waves per SIMD the target stands for, and the waves over the limit run as a tail after the
         // others -- lengthen the chunks until the items fit
@@ -1067,7 +1057,7 @@ int Batch::build_work(const jb_batch_opts *opts)
             return it;
         };
         for (int guard = 0; guard < 256 && c >= cmin && items_at(ch) > target; guard++)
-            ch += (uint32_t)ch_gran;
+            ch += 1;
     } else if (ch == 0) {
         // auto (wave kernel): one item per SIMD, two once the batch is large.  The launch takes as long
         // as ONE item (warm-up + chunk frames at 0.25 us per sample; 0.47 with two items on a SIMD), so a
@@ -1075,22 +1065,12 @@ int Batch::build_work(const jb_batch_opts *opts)
         // call; below 16 the extra hand-off positions and their occasional redo round cost more than
         // they save) -- but never more items than SIMDs: the kernel's four-wave workgroups are what puts
         // exactly one on each.  (64 x 2000 frames: 16.0 ms with 1344 items of 96 frames, 11.6 with 1000 of 128.)
-        uint64_t target = sumT >= 400000 ? 2048 : 1024;
-        if (const char *e = getenv("JB_CHUNK_TARGET"))
-            target = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
-        uint64_t floor_ = 16;
-        if (const char *e = getenv("JB_CHUNK_FLOOR"))
-            floor_ = std::max<uint64_t>(4, strtoull(e, nullptr, 10));
-        ch = (uint32_t)std::max<uint64_t>((sumT + target - 1) / target, floor_);
+        const uint64_t target = sumT >= 400000 ? 2048 : 1024;
+        ch = (uint32_t)std::max<uint64_t>((sumT + target - 1) / target, 16);
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
     vd.ckpt_frames = ch >= 2 * kVocCkptFrames ? kVocCkptFrames : (ch >= kVocCkptFramesShort + 12 ? kVocCkptFramesShort : 0);
-    if (const char *e = getenv("JB_CKPT_FRAMES")) { // tuning aid: checkpoint position of long chunks
-        const uint32_t v = (uint32_t)std::max(8, atoi(e));
-        if (ch >= 2 * v)
-            vd.ckpt_frames = v;
-    }
     work.clear();
     const int stride = vd.state_stride;
     for (int i = 0; i < B; i++) {
@@ -1192,23 +1172,17 @@ int Batch::enqueue_vocoder()
 // main stream, LF0 -> pitch -> pulse schedule and LPF on side streams, forked after
 // whatever the main stream was doing (a previous run may still read the tracks) and
 // joined before the vocoder.
-// Hook of the MCP chain, called between its band solve and its GV sweeps: enqueues the LPF chain and
-// the pulse-free excitation pass (side stream by default; on the main stream, at this point of the MCP
-// chain, with JB_EXCITE_SIDE=0).
+// Hook of the MCP chain, called between its band solve and its GV: enqueues the LPF chain (width-1 static
+// window: one bandwidth-bound kernel) and, behind it on the same side stream, the pulse-free excitation
+// pass: both start with the step, beside the MCP build and band solve.  (Until the band solve shed a third
+// of its traffic, the excitation pass beside it stretched both by more than its own time and ran on the
+// main stream between band solve and GV: 98.8 ms per step that way, 97.8 this way.  With JB_ONE_STREAM the
+// side streams are the main stream and the order is simply sequential.)
 static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
 {
     Batch *b = (Batch *)ctx;
     hipError_t e;
-    // LPF chain (width-1 static window: one bandwidth-bound kernel) and, behind it on the same side stream,
-    // the pulse-free excitation pass: both start with the step, beside the MCP build and band solve.
-    // (Until the band solve shed a third of its traffic and its movers their stalls, beside it the
-    // excitation pass stretched both by more than its own time, and it ran on the main stream between band
-    // solve and GV instead, with the LPF chain held back until the MCP build was done: step 98.8 ms that
-    // way now, 97.8 this way -- the pulse repair pass, which needs this one, then starts ~4 ms earlier.
-    // JB_EXCITE_SIDE=0 / JB_LPF_EARLY=0 restore the old order, A/B aids.)
-    static const bool lpf_early = !(getenv("JB_LPF_EARLY") && atoi(getenv("JB_LPF_EARLY")) == 0);
-    if (!lpf_early)
-        hipStreamWaitEvent(b->stream_lpf, b->ev_mcpbuild, 0);
+    (void)stream;
     if (b->voice.nstream > 2) {
         if ((e = launch_prep(b->bd, b->sd[2], 2, b->stream_lpf)) != hipSuccess)
             return e;
@@ -1216,14 +1190,9 @@ static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
             return e;
     }
     hipEventRecord(b->ev_lpf, b->stream_lpf);
-    static const bool side_env = !(getenv("JB_EXCITE_SIDE") && atoi(getenv("JB_EXCITE_SIDE")) == 0);
-    const bool side = side_env && b->stream_lpf != stream;
-    hipStream_t es = side ? b->stream_lpf : stream;
-    hipStreamWaitEvent(es, b->ev_prep, 0); // voiced flags (LF0 state walk)
-    if (!side)
-        hipStreamWaitEvent(es, b->ev_lpf, 0); // LPF track
-    e = launch_excite_noise(b->bd, b->vd, es);
-    hipEventRecord(b->ev_build, es); // "pulse-free excitation done"
+    hipStreamWaitEvent(b->stream_lpf, b->ev_prep, 0); // voiced flags (LF0 state walk)
+    e = launch_excite_noise(b->bd, b->vd, b->stream_lpf);
+    hipEventRecord(b->ev_build, b->stream_lpf); // "pulse-free excitation done"
     return e;
 }
 
@@ -1501,9 +1470,6 @@ int Batch::finish_verify()
         // chunk k+1 again and put k+1 on the list if it fails.  (A chunk settled at its checkpoint kept
         // its first-pass end state, whose trajectory was certified at the checkpoint: nothing to re-check.)
         std::vector<uint32_t> succ;
-        static const bool no_recert = getenv("JB_NO_RECERT") && atoi(getenv("JB_NO_RECERT")) != 0; // A/B aid (tests)
-        if (no_recert)
-            full_ids.clear();
         for (uint32_t k : full_ids)
             if (k + 1 < n_items && work[k + 1].utt == work[k].utt && work[k + 1].save_warm && !pending[k + 1] &&
                 work[k].save_end)
@@ -1657,7 +1623,6 @@ int Batch::read_pcm_split(void *const *dst, size_t elem)
     for (auto &st : state)
         st.store(FREE);
     std::atomic<int> failed{0};
-    const bool noscatter = getenv("JB_STAGE_NOSCATTER") != nullptr; // tuning aid: link rate alone
     auto worker = [&](int k, int stride) {
         hipSetDevice(device);
         for (size_t c = (size_t)k; c < nchunks; c += (size_t)stride) {
@@ -1674,7 +1639,7 @@ int Batch::read_pcm_split(void *const *dst, size_t elem)
             size_t u = (size_t)(std::upper_bound(uoff.begin(), uoff.end(), lo) - uoff.begin()) - 1;
             for (; u < (size_t)B && uoff[u] < hi; u++) {
                 const size_t a = std::max(lo, uoff[u]), b2 = std::min(hi, uoff[u + 1]);
-                if (b2 > a && dst[u] && !noscatter)
+                if (b2 > a && dst[u])
                     memcpy((char *)dst[u] + (a - uoff[u]), (const char *)ring->slot[sl] + (a - lo), b2 - a);
             }
             state[sl].store(FREE, std::memory_order_release);

@@ -764,8 +764,6 @@ int gv_gang_plan(int device, uint32_t maxT, uint32_t n_rows, int *tiles_per_gang
     int g = cap / (int)nt;
     if ((uint32_t)g > n_rows)
         g = (int)n_rows;
-    if (const char *e = getenv("JB_GV_GANGS")) // tuning aid
-        g = atoi(e) > 0 && atoi(e) < g ? atoi(e) : g;
     *tiles_per_gang = (int)nt;
     *n_gangs = g;
     return 1;

@@ -7,7 +7,7 @@
 //                            -- elementwise in time: thread per (frame, dim)
 //   k_mlpg_fb_lds     A5/A6  band LDL^T + substitutions             (mlpg.rs:79-115)
 //                            -- serial in time: one solver wave per utterance (lane = dim) fed
-//                            through LDS by mover waves; (k_mlpg_fb_mt: lane-per-row fallback)
+//                            through LDS by mover waves
 //   k_mlpg_gv_tp      A8     GV ascent, time-parallel (MCP)         (mlpg.rs:145-292)
 //   k_mlpg_gv_vt      A8     GV ascent, lanes over time with the sums in serial order (LF0)
 //   k_mlpg_solve3/solve A5-A9 fused serial-order sweeps / generic band width (bit-exact A/B paths)
@@ -24,9 +24,6 @@
 #include "jb_device.h"
 
 #include <cstdlib>
-#ifndef JB_SIDE_PRIO
-#define JB_SIDE_PRIO 0 // s_setprio in the LF0-chain kernels: stretches the throughput kernels beside them
-#endif
 #include <type_traits>
 
 namespace jb {
@@ -294,17 +291,11 @@ __global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
     sd.bvec[o] = wum;
 }
 
-#ifndef JB_CHAIN_PRIO
-#define JB_CHAIN_PRIO 0 // s_setprio level of the MCP chain's throughput kernels (A/B aid; 0 = default)
-#endif
 // MeanVari::with_ivar per (state, window, dim), once per batch: a frame's inverse variance is
 // its state's, and each is used by up to three neighbouring frames of every window, so the
 // table replaces ~6 f64 divisions per (frame, dim) in the build by loads.
 __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 {
-#if JB_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(JB_CHAIN_PRIO);
-#endif
     const int b = blockIdx.y;
     const UttDev *up = bd.utt + b;
     const uint32_t WL = (uint32_t)(sd.W * sd.L);
@@ -319,153 +310,11 @@ __global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 // kBuildTF contiguous frames per dim.  What depends on the frame alone (state index, MSD
 // boundary distances of the frame and its +-1 neighbours) is looked up once per block.
 // Same arithmetic, in the same order, as build_elem.
-#ifndef JB_BUILD_PROFILE
-#define JB_BUILD_PROFILE 0 // 1: a few blocks print the cycles of their sections
-#endif
-#ifndef JB_VT_FUSE2
-#define JB_VT_FUSE2 1
-#endif
-#ifndef JB_FL_WPE
-#define JB_FL_WPE 1 // register budget of the band solve in waves per SIMD: 2 = 256 registers per wave (it then spills to
-                    // scratch: 5.55 against 5.0 ms alone, and the step gains nothing from fitting beside the LF0 GV kernel)
-#endif
-#ifndef JB_FL_SPLIT
-#define JB_FL_SPLIT 1
-#endif
-#ifndef JB_FL_SCHED
-#define JB_FL_SCHED 0
-#endif
-#ifndef JB_FL_LP_CONST
-#define JB_FL_LP_CONST 1
-#endif
-#ifndef JB_FL_PROFILE
-#define JB_FL_PROFILE 0 // 1: block 3 prints the work / barrier-wait ticks of its solver and first mover per pass
-#endif
-#ifndef JB_BUILD_TF
-#define JB_BUILD_TF 16 // 128-byte pieces per row reach the same HBM rate as longer ones (tools/microbench/piece_bw.hip)
-                       // and twice as many workgroups fit a CU: 16 frames 3.6 ms, 32 4.5, 64 4.6, 8 4.6
-#endif
-constexpr int kBuildTF = JB_BUILD_TF;
+// 16 frames per block: 128-byte pieces per row reach the same HBM rate as longer ones (tools/microbench/piece_bw.hip)
+// and twice as many workgroups fit a CU: 16 frames 3.6 ms, 32 4.5, 64 4.6, 8 4.6
+constexpr int kBuildTF = 16;
 #define JB_MAX_WIN_BUILD 3 // windows served by the sliding-window build (static, delta, acceleration)
 constexpr int kMtMaxDim = 60; // (BW+1) * L * (kBuildTF+1) * 8 B <= 64 KiB of LDS for BW = 3
-template <int BW>
-__global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd, int si)
-{
-    extern __shared__ double tile[]; // [BW+1][L][kBuildTF+1]
-    constexpr int HW = BW / 2;       // frames a window can reach to either side
-    __shared__ uint32_t f_state[kBuildTF + 2 * HW];
-    __shared__ uint8_t f_l[kBuildTF + 2 * HW], f_r[kBuildTF + 2 * HW];
-    const int b = blockIdx.y;
-    const UttDev *up = bd.utt + b;
-    const uint32_t Tv = sd.Tv[b];
-    const uint32_t k0 = blockIdx.x * (uint32_t)kBuildTF;
-    if (k0 >= Tv)
-        return;
-    const int L = sd.L, W = sd.W;
-    const StreamStatesDev st = up->st[si];
-    const uint64_t base = up->frame_off;
-    if (threadIdx.x < kBuildTF + 2 * HW) {
-        const long k = (long)k0 - HW + (long)threadIdx.x;
-        uint32_t s = 0;
-        uint8_t dl = 0, dr = 0;
-        if (k >= 0 && k < (long)Tv) {
-            const uint32_t f = sd.vidx[base + k];
-            s = sd.fstate[base + f];
-            dl = sd.fl[base + f];
-            dr = sd.fr[base + f];
-        }
-        f_state[threadIdx.x] = s;
-        f_l[threadIdx.x] = dl;
-        f_r[threadIdx.x] = dr;
-    }
-    __syncthreads();
-    const double *ivt = sd.ivar + up->state_off * (uint64_t)(W * L);
-    const double *mnt = st.mean;
-    const int pitch = kBuildTF + 1, plane = L * pitch;
-    const int WL = W * L;
-    static_assert(BW == 3, "window loops below are unrolled for widths <= 3");
-    for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
-        const int kl = e / L, m = e - kl * L;
-        const uint32_t k = k0 + (uint32_t)kl;
-        if (k >= Tv)
-            continue;
-        double wuw[BW], wum = 0.0;
-#pragma unroll
-        for (int j = 0; j < BW; j++)
-            wuw[j] = 0.0;
-        // The reference's loop nest (mlpg.rs:25-70: windows, then taps from last to first, then
-        // the taps from last down to this one) with the tap loops unrolled: every branch on a
-        // coefficient or a width is wave-uniform and the band index j is a constant.
-        for (int w = 0; w < W; w++) {
-            const int ww = sd.win_width[w];
-            const double *coef = sd.win_coef + sd.win_off[w];
-            const int lw = ww / 2, rw = ww - lw - 1;
-            double cf[3];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-                cf[i] = i < ww ? coef[i] : 0.0;
-            const uint32_t mo = (uint32_t)(L * w + m);
-            // The six table loads of the window (mean, 1/var of up to three source frames) are
-            // unconditional -- source index clamped into the block's frame window -- and issued
-            // before the arithmetic; loads behind the per-lane edge tests were waited for one at a
-            // time (77 % of the kernel's wave cycles).  A tap that does not exist (past the window
-            // width, zero coefficient, source outside the utterance) enters with wu = 0 and adds
-            // exact zeros where the reference skips it.
-            double mv[3], iv[3];
-            bool ok[3];
-#pragma unroll
-            for (int index = 2; index >= 0; index--) {
-                const int d = index - lw; // source frame k - d
-                const long idx = (long)k - (long)d;
-                ok[index] = index < ww && idx >= 0 && idx < (long)Tv;
-                int fi = kl - d + HW;
-                fi = fi < 0 ? 0 : (fi > kBuildTF + 2 * HW - 1 ? kBuildTF + 2 * HW - 1 : fi);
-                const uint64_t pi = (uint64_t)(f_state[fi] * (uint32_t)WL + mo);
-                mv[index] = mnt[pi];
-                double ivar = ivt[pi];
-                // dynamic windows touching an MSD boundary get ivar = 0 (mod.rs:69-80)
-                if (w != 0 && ((int)f_l[fi] < lw || (int)f_r[fi] < rw))
-                    ivar = 0.0;
-                iv[index] = ivar;
-            }
-#pragma unroll
-            for (int index = 2; index >= 0; index--) {
-                const double wu = ok[index] ? cf[index] * iv[index] : 0.0;
-                wum += wu * mv[index];
-                bool live = true; // the reference leaves the inner loop at the first tap past the end
-#pragma unroll
-                for (int inner = 2; inner >= 0; inner--) {
-                    if (inner < index)
-                        continue;
-                    const int j = inner - index;
-                    // (a zero coefficient is skipped BEFORE the end test in the reference)
-                    if (cf[inner] != 0.0 && inner < ww && (uint64_t)k + (uint64_t)j >= Tv)
-                        live = false;
-                    if (live)
-                        wuw[j] += wu * cf[inner];
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < BW; j++)
-            tile[j * plane + m * pitch + kl] = wuw[j];
-        tile[BW * plane + m * pitch + kl] = wum;
-    }
-    __syncthreads();
-    const uint64_t row0 = base * (uint64_t)L, Tu = up->T;
-    for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
-        const int m = e / kBuildTF, kl = e % kBuildTF;
-        const uint32_t k = k0 + (uint32_t)kl;
-        if (k < Tv) {
-            const uint64_t o = row0 + (uint64_t)m * Tu + k;
-#pragma unroll
-            for (int j = 0; j < BW; j++)
-                sd.A[j][o] = tile[j * plane + m * pitch + kl];
-            sd.bvec[o] = tile[BW * plane + m * pitch + kl];
-        }
-    }
-}
-
 // Same kernel with the table loads of neighbouring frames SHARED.  k_mlpg_build_mt loads, for every
 // (frame, dim), mean and 1/var of up to three source frames of every window -- 18 loads per element,
 // 34 GB through the texture addressers for config 2, which is what its 4.8 ms are (10 % VALU busy,
@@ -473,10 +322,7 @@ __global__ __launch_bounds__(256) void k_mlpg_build_mt(BatchDev bd, StreamDev sd
 // dim and slides a three-frame window over the table: 6 loads per element (2 for a one-tap window).
 // The arithmetic per element is the reference's loop nest, unchanged and in the same order
 // (test_fused_mlpg_equals_generic_bitwise holds it to the un-fused kernels bit for bit).
-#ifndef JB_BUILD_RUN
-#define JB_BUILD_RUN 4
-#endif
-constexpr int kBuildRun = JB_BUILD_RUN;
+constexpr int kBuildRun = 4;
 typedef const double __attribute__((address_space(1))) *Gp;
 template <int BW>
 __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
@@ -484,9 +330,6 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
     extern __shared__ double tile[]; // [BW+1][L][kBuildTF+1]
     constexpr int HW = BW / 2;       // frames a window can reach to either side
     static_assert(BW == 3 && HW == 1, "written for three-tap windows");
-#if JB_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(JB_CHAIN_PRIO); // MCP chain = critical path of the step: ahead of side-stream waves
-#endif
     __shared__ uint32_t f_state[kBuildTF + 2 * HW];
     __shared__ uint8_t f_l[kBuildTF + 2 * HW], f_r[kBuildTF + 2 * HW];
     const int b = blockIdx.y;
@@ -495,9 +338,6 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
     const uint32_t k0 = blockIdx.x * (uint32_t)kBuildTF;
     if (k0 >= Tv)
         return;
-#if JB_BUILD_PROFILE
-    const long long pt0 = clock64();
-#endif
     const int L = sd.L, W = sd.W;
     const StreamStatesDev st = up->st[si];
     const uint64_t base = up->frame_off;
@@ -517,9 +357,6 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
         f_r[threadIdx.x] = dr;
     }
     __syncthreads();
-#if JB_BUILD_PROFILE
-    const long long pt1 = clock64();
-#endif
     const double *ivt = sd.ivar + up->state_off * (uint64_t)(W * L);
     const double *mnt = st.mean;
     const int pitch = kBuildTF + 1, plane = L * pitch;
@@ -659,13 +496,7 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
         else
             run(std::false_type{});
     }
-#if JB_BUILD_PROFILE
-    const long long pt2 = clock64();
-#endif
     __syncthreads();
-#if JB_BUILD_PROFILE
-    const long long pt3 = clock64();
-#endif
     const uint64_t row0 = base * (uint64_t)L, Tu = up->T;
     for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
         const int m = e / kBuildTF, kl = e % kBuildTF;
@@ -678,13 +509,6 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
             sd.bvec[o] = tile[BW * plane + m * pitch + kl];
         }
     }
-#if JB_BUILD_PROFILE
-    __builtin_amdgcn_s_waitcnt(0);
-    const long long pt4 = clock64();
-    if (blockIdx.y == 3 && blockIdx.x % 200 == 100 && (threadIdx.x == 0 || threadIdx.x == 256))
-        printf("build_mt2 block %d thread %d: desc %lld compute %lld barrier %lld store %lld cycles\n", (int)blockIdx.x,
-               (int)threadIdx.x, pt1 - pt0, pt2 - pt1, pt3 - pt2, pt4 - pt3);
-#endif
 }
 
 // --------------------------------------------------------------------------
@@ -915,10 +739,7 @@ __global__ void k_mlpg_static(BatchDev bd, StreamDev sd, int si)
 //   * passes are fused wherever the reference's order of additions allows
 //     (mean of the next GV iteration accumulates while par is updated, variance +
 //     gradient + objective in one sweep): 15 sweeps instead of 31.
-#ifndef JB_MU
-#define JB_MU 8
-#endif
-constexpr int MU = JB_MU;
+constexpr int MU = 8;
 
 template <bool NONMSD, bool DOGV, bool MT = false>
 __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, int si)
@@ -1198,188 +1019,10 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
 }
 
 // --------------------------------------------------------------------------
-// A5/A6 for the [dim][frame] workspace: band LDL^T + forward substitution, then backward
-// substitution (mlpg.rs:79-115), one lane per (utterance, dim), every lane streaming its own
-// contiguous row.  Same arithmetic and order as k_mlpg_solve3's F and B passes.  A lone wave
-// per CU has nothing but its own loads in flight, so (a) each lane moves 16 bytes per memory
-// instruction (dwordx4: half the address-processing work of 8-byte accesses, which is what
-// bounds an uncoalesced wave), and (b) the loads run kFbNB-1 chunks of kFbMU frames ahead in a
-// register ring, which also keeps the sweep from stretching when other kernels load the
-// memory system.
-constexpr int kFbMU = 4; // frames per chunk (even)
-constexpr int kFbNB = 4; // ring depth in chunks: loads run (kFbNB-1)*kFbMU frames ahead
-typedef double v2d8 __attribute__((ext_vector_type(2), aligned(8)));
-
-// whole chunk [tb, tb+MU): unconditional wide loads (the caller clamps tb to a valid chunk, so
-// that no branch surrounds a load: hipcc otherwise merges wait states at the join and drains
-// the whole ring with s_waitcnt vmcnt(0) at every use)
-__device__ __forceinline__ void fb_load(double (&dst)[kFbMU], const double *arr, uint32_t tb)
-{
-#pragma unroll
-    for (int u = 0; u < kFbMU; u += 2) {
-        const v2d8 x = *reinterpret_cast<const v2d8 *>(arr + tb + u);
-        dst[u] = x.x;
-        dst[u + 1] = x.y;
-    }
-}
-__device__ __forceinline__ void fb_store2(double *arr, uint32_t t, double x0, double x1)
-{
-    v2d8 x;
-    x.x = x0;
-    x.y = x1;
-    *reinterpret_cast<v2d8 *>(arr + t) = x;
-}
-
-__global__ __launch_bounds__(64) void k_mlpg_fb_mt(BatchDev bd, StreamDev sd, int si)
-{
-    const int b = blockIdx.y;
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    const int L = sd.L;
-    if (m >= L)
-        return;
-    const UttDev *up = bd.utt + b;
-    const uint32_t n = sd.Tv[b];
-    if (n == 0)
-        return;
-    const uint64_t row = up->frame_off * (uint64_t)L + (uint64_t)m * (uint64_t)up->T;
-    const double *A0 = sd.A[0] + row, *A1 = sd.A[1] + row, *A2 = sd.A[2] + row, *Bv = sd.bvec + row;
-    double *F0 = sd.F[0] + row, *F1 = sd.F[1] + row, *F2 = sd.F[2] + row, *Gv = sd.g + row;
-    double *Pv = sd.par + row;
-    const uint32_t nfull = n / kFbMU, rem = n - nfull * kFbMU;
-    const uint32_t lastc = nfull ? nfull - 1 : 0; // prefetches past the end re-read this chunk
-
-    // ---- pass F: ldl_factorization + forward substitution (mlpg.rs:79-105) ----
-    double p1_0 = 0, p1_1 = 0, p1_2 = 0, p2_0 = 0, p2_2 = 0, g1 = 0, g2 = 0;
-    auto fstep = [&](uint32_t t, double r0, double r1, double r2, double g, double &o0, double &o1,
-                     double &o2, double &og) {
-        if (t >= 1)
-            r0 -= p1_1 * p1_1 * p1_0;
-        if (t >= 2)
-            r0 -= p2_2 * p2_2 * p2_0;
-        if (t >= 1)
-            r1 -= p1_1 * p1_2 * p1_0;
-        r1 /= r0;
-        r2 /= r0;
-        if (t >= 1)
-            g -= p1_1 * g1;
-        if (t >= 2)
-            g -= p2_2 * g2;
-        o0 = r0;
-        o1 = r1;
-        o2 = r2;
-        og = g;
-        p2_0 = p1_0;
-        p2_2 = p1_2;
-        g2 = g1;
-        p1_0 = r0;
-        p1_1 = r1;
-        p1_2 = r2;
-        g1 = g;
-    };
-    if (nfull) {
-        double ring[kFbNB][4][kFbMU];
-#pragma unroll
-        for (int s = 0; s < kFbNB - 1; s++) {
-            const uint32_t tb = ((uint32_t)s < lastc ? (uint32_t)s : lastc) * kFbMU;
-            fb_load(ring[s][0], A0, tb);
-            fb_load(ring[s][1], A1, tb);
-            fb_load(ring[s][2], A2, tb);
-            fb_load(ring[s][3], Bv, tb);
-        }
-        for (uint32_t c0 = 0; c0 < nfull; c0 += kFbNB) {
-#pragma unroll
-            for (int s = 0; s < kFbNB; s++) {
-                const uint32_t c = c0 + (uint32_t)s;
-                if (c < nfull) {
-                    const int sp = (s + kFbNB - 1) % kFbNB; // slot freed by the previous chunk
-                    const uint32_t cp = c + kFbNB - 1;
-                    const uint32_t tp = (cp < lastc ? cp : lastc) * kFbMU;
-                    fb_load(ring[sp][0], A0, tp);
-                    fb_load(ring[sp][1], A1, tp);
-                    fb_load(ring[sp][2], A2, tp);
-                    fb_load(ring[sp][3], Bv, tp);
-                    const uint32_t tb = c * kFbMU;
-#pragma unroll
-                    for (int uu = 0; uu < kFbMU; uu += 2) {
-                        double a0, a1, a2, ag, b0, b1, b2, bg;
-                        fstep(tb + uu, ring[s][0][uu], ring[s][1][uu], ring[s][2][uu], ring[s][3][uu], a0, a1,
-                              a2, ag);
-                        fstep(tb + uu + 1, ring[s][0][uu + 1], ring[s][1][uu + 1], ring[s][2][uu + 1],
-                              ring[s][3][uu + 1], b0, b1, b2, bg);
-                        fb_store2(F0, tb + uu, a0, b0);
-                        fb_store2(F1, tb + uu, a1, b1);
-                        fb_store2(F2, tb + uu, a2, b2);
-                        fb_store2(Gv, tb + uu, ag, bg);
-                    }
-                }
-            }
-        }
-    }
-    for (uint32_t t = nfull * kFbMU; t < n; t++) { // ragged tail
-        double o0, o1, o2, og;
-        fstep(t, A0[t], A1[t], A2[t], Bv[t], o0, o1, o2, og);
-        F0[t] = o0;
-        F1[t] = o1;
-        F2[t] = o2;
-        Gv[t] = og;
-    }
-
-    // ---- pass B: backward substitution (mlpg.rs:106-113), t descending ----
-    // whole chunks from the top: chunk c covers [n-(c+1)*MU, n-c*MU); the ragged part [0, rem)
-    // comes last
-    double q1 = 0, q2 = 0;
-    auto bstep = [&](uint32_t t, double f0, double f1, double f2, double g) {
-        double p = g / f0;
-        if (t + 1 < n)
-            p -= f1 * q1;
-        if (t + 2 < n)
-            p -= f2 * q2;
-        q2 = q1;
-        q1 = p;
-        return p;
-    };
-    if (nfull) {
-        double ring[kFbNB][4][kFbMU];
-#pragma unroll
-        for (int s = 0; s < kFbNB - 1; s++) {
-            const uint32_t lo = n - (((uint32_t)s < lastc ? (uint32_t)s : lastc) + 1) * kFbMU;
-            fb_load(ring[s][0], F0, lo);
-            fb_load(ring[s][1], F1, lo);
-            fb_load(ring[s][2], F2, lo);
-            fb_load(ring[s][3], Gv, lo);
-        }
-        for (uint32_t c0 = 0; c0 < nfull; c0 += kFbNB) {
-#pragma unroll
-            for (int s = 0; s < kFbNB; s++) {
-                const uint32_t c = c0 + (uint32_t)s;
-                if (c < nfull) {
-                    const int sp = (s + kFbNB - 1) % kFbNB;
-                    const uint32_t cp = c + kFbNB - 1;
-                    const uint32_t lp = n - ((cp < lastc ? cp : lastc) + 1) * kFbMU;
-                    fb_load(ring[sp][0], F0, lp);
-                    fb_load(ring[sp][1], F1, lp);
-                    fb_load(ring[sp][2], F2, lp);
-                    fb_load(ring[sp][3], Gv, lp);
-                    const uint32_t lo = n - (c + 1) * kFbMU;
-#pragma unroll
-                    for (int uu = kFbMU - 2; uu >= 0; uu -= 2) { // frames lo+uu+1, then lo+uu
-                        const double pb = bstep(lo + uu + 1, ring[s][0][uu + 1], ring[s][1][uu + 1],
-                                                ring[s][2][uu + 1], ring[s][3][uu + 1]);
-                        const double pa = bstep(lo + uu, ring[s][0][uu], ring[s][1][uu], ring[s][2][uu],
-                                                ring[s][3][uu]);
-                        fb_store2(Pv, lo + uu, pa, pb);
-                    }
-                }
-            }
-        }
-    }
-    for (uint32_t r = rem; r-- > 0;) // ragged part, frames rem-1 .. 0
-        Pv[r] = bstep(r, F0[r], F1[r], F2[r], Gv[r]);
-}
-
-// --------------------------------------------------------------------------
-// A5/A6 again, LDS-STAGED: k_mlpg_fb_mt's per-lane row streams are bound by the texture
-// addresser (an uncoalesced wave access costs ~150 cycles whatever its width), not by latency.
+// A5/A6 for the [dim][frame] workspace (band LDL^T + forward substitution, then backward substitution,
+// mlpg.rs:79-115), LDS-STAGED.  With one lane per (utterance, dim) streaming its own row, a wave touches 35
+// cache lines per memory instruction and the texture addresser sets the pace (an uncoalesced wave access
+// costs ~150 cycles whatever its width: 10.3 ms; tools/experiments/README.md).
 // Here one block owns an utterance: wave 0 is the SOLVER (lane = dim, the same recurrences in the
 // same order, operands and results in LDS as [frame][dim] tiles, so its accesses are
 // conflict-free), waves 1-3 are MOVERS that stream the [dim][frame] rows between HBM and LDS with
@@ -1432,11 +1075,7 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
     // immediate offset (with a run-time pitch the solver spent 4 of its 42 instructions per frame forming them)
     // (the pitch must stay odd: the movers walk a tile frame-fastest, and with 36 doubles between frames
     // their LDS accesses collide eight ways -- the kernel took 11.9 ms instead of 5.6)
-#if JB_FL_LP_CONST
     const int LP = LMAX == 36 ? 37 : L;
-#else
-    const int LP = L;
-#endif
     const int nch = (int)((n + kFlCT - 1) / kFlCT);
     double *inb = lds;                                // [kFlIn][NIN][kFlCT][LP]
     double *outb = lds + kFlIn * 4 * kFlCT * LP;      // [kFlOut][NOUT][kFlCT][LP]
@@ -1475,9 +1114,6 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
             regs[a2][kk] = 0.0;
     // Phase p: the solver works on chunk p.  The phase barrier is a raw s_barrier behind lgkmcnt(0) only:
     // __syncthreads() would also wait for the movers' stores and loads in flight (vmcnt(0)).
-#if JB_FL_PROFILE
-    long long t_work = 0, t_wait = 0, t0 = clock64();
-#endif
     auto mover_phase = [&](const int p) {
         if ((((p + 2) % NG) + NG) % NG == grp) {
             const int cw = p + 2; // loaded NG phases ago
@@ -1593,26 +1229,9 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
     };
     auto phase_end = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if JB_FL_PROFILE
-        const long long t1 = clock64();
-        t_work += t1 - t0;
-#endif
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-#if JB_FL_PROFILE
-        t0 = clock64();
-        t_wait += t0 - t1;
-#endif
     };
-#if JB_FL_PROFILE
-    struct Report {
-        long long &w, &b; int nch; bool back;
-        __device__ ~Report() {
-            if (blockIdx.x == 3 && (threadIdx.x == 0 || threadIdx.x == 64))
-                printf("fl_pass %s thread %d: chunks %d work %lld wait %lld ticks\n", back ? "B" : "F", (int)threadIdx.x, nch, w, b);
-        }
-    } report{t_work, t_wait, nch, BACKWARD};
-#endif
     static_assert(kFlGroups == 3 && kFlOut == 3, "roles: park c-2 / drain c+2 fall on different groups for 3");
     for (int p = -2 - kFlGroups; p <= nch + 1; p++) {
         if (solver)
@@ -1624,7 +1243,7 @@ __device__ __forceinline__ void fl_pass(double *lds, const double *const (&in)[N
 }
 
 template <int LMAX>
-__global__ __launch_bounds__(kFlNT, JB_FL_WPE) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd, int si)
+__global__ __launch_bounds__(kFlNT, 1) void k_mlpg_fb_lds(BatchDev bd, StreamDev sd, int si)
 {
     extern __shared__ double lds[];
     const int b = (int)bd.order[blockIdx.x]; // longest utterance first: the serial sweeps of a ragged
@@ -1820,10 +1439,7 @@ __device__ __forceinline__ double serial_add64(double acc, double v)
 
 // Loads of kVtNB blocks of 64 frames are issued together before their serial sums run, so a
 // lone wave pays one memory latency per 512 frames instead of one per 64.
-#ifndef JB_VT_NB
-#define JB_VT_NB 8 // 4: 3.08 ms, 8: 2.85, 16: 2.90 (LF0 of config 2, alone)
-#endif
-constexpr int kVtNB = JB_VT_NB;
+constexpr int kVtNB = 8; // 4: 3.08 ms, 8: 2.85, 16: 2.90 (LF0 of config 2, alone)
 
 // In-order sum of one value per lane, acc += v[lane 0]; acc += v[lane 1]; ... -- through LDS:
 // the wave parks the values and every lane reads them back in order with broadcast
@@ -1899,9 +1515,6 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
     const uint32_t gvl = sd.gvlen[b];
     if (n == 0 || !(sd.use_gv && st.gv_mean && gvl > 0))
         return;
-#if JB_SIDE_PRIO
-    __builtin_amdgcn_s_setprio(3); // latency chain: do not take turns with throughput waves
-#endif
     const int L = sd.L;
     const uint64_t base = up->frame_off;
     const uint64_t o0 = base * (uint64_t)L + (uint64_t)m, Ls = (uint64_t)L;
@@ -2052,12 +1665,7 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
             for (int q = 0; q < kVtNB; q++)
                 if (tb + 64u * q < n) {
                     // hmmobj has no switch: frames beyond n contribute nothing (exact: + 0.0)
-#if JB_VT_FUSE2
                     serial_add2_lds(vsum, sbuf[0][q], hmmobj, sbuf[1][q]);
-#else
-                    vsum = serial_add_lds(vsum, sbuf[0][q]);
-                    hmmobj = serial_add_lds(hmmobj, sbuf[1][q]);
-#endif
                 }
         }
         vari = vsum / glen;
@@ -2144,14 +1752,8 @@ __global__ __launch_bounds__(64) void k_mlpg_gv_vt(BatchDev bd, StreamDev sd, in
 // One pass over par, A0..A2, bvec per iteration instead of the serial kernel's two sweeps
 // at one lane per dim: ~70 GB of traffic over >100k blocks instead of 13 x 25k dependent
 // steps on 256 waves.
-#ifndef JB_GV_TT
-#define JB_GV_TT 2048
-#endif
-#ifndef JB_GV_NT
-#define JB_GV_NT 512
-#endif
-constexpr int kGvTT = JB_GV_TT;                  // frames per tile
-constexpr int kGvNT = JB_GV_NT;                  // threads per block
+constexpr int kGvTT = 2048;                      // frames per tile
+constexpr int kGvNT = 512;                       // threads per block
 constexpr int kGvKX = (kGvTT + 4 + kGvNT - 1) / kGvNT; // per-thread frames incl. halo
 
 struct GvScal {
@@ -2480,8 +2082,7 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
         return hipSuccess;
     {
         dim3 grid(bd.B), block(64);
-        static const bool dense_ok = !(getenv("JB_PREP_DENSE") && atoi(getenv("JB_PREP_DENSE")) == 0);
-        if (!sd.is_msd && dense_ok)
+        if (!sd.is_msd)
             hipLaunchKernelGGL(k_prep_states_dense, grid, block, 0, stream, bd, sd, si);
         else
             hipLaunchKernelGGL(k_prep_states, grid, block, 0, stream, bd, sd, si);
@@ -2493,7 +2094,8 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int si, hipStrea
     return hipGetLastError();
 }
 
-// F/B sweeps of the [dim][frame] workspace: LDS-staged block per utterance, or lane-per-row
+// F/B sweeps of the [dim][frame] workspace: LDS-staged block per utterance (L <= kMtMaxDim = 60 dims:
+// 2688 B of LDS per dim fit the CU's 160 KB)
 template <int LMAX>
 static void launch_fb_lds(const BatchDev &bd, const StreamDev &sd, int si, size_t lds, hipStream_t stream)
 {
@@ -2506,20 +2108,15 @@ static void launch_fb_lds(const BatchDev &bd, const StreamDev &sd, int si, size_
 
 static void launch_fb(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
 {
-    static const bool use_lds = !(getenv("JB_FB_LDS") && atoi(getenv("JB_FB_LDS")) == 0);
     // per dim of the tile pitch: input slots of four arrays, output slots of at most three (L1, L2, g/D)
-    const size_t lds1 = sizeof(double) * (size_t)(kFlIn * 4 + kFlOut * 3) * kFlCT;
-    if (use_lds && sd.L <= 64 && lds1 * (size_t)sd.L <= 160 * 1024) {
-        if (sd.L == 1)
-            launch_fb_lds<1>(bd, sd, si, lds1, stream);
-        else if (sd.L <= 36)
-            launch_fb_lds<36>(bd, sd, si, lds1 * (JB_FL_LP_CONST ? 37 : (size_t)sd.L), stream); // tile pitch (fl_pass)
-        else
-            launch_fb_lds<64>(bd, sd, si, lds1 * (size_t)sd.L, stream); // up to 160 KB: the whole LDS of a CU
-    } else {
-        dim3 grid((sd.L + 63) / 64, bd.B), block(64);
-        hipLaunchKernelGGL(k_mlpg_fb_mt, grid, block, 0, stream, bd, sd, si);
-    }
+    constexpr size_t lds1 = sizeof(double) * (size_t)(kFlIn * 4 + kFlOut * 3) * kFlCT;
+    static_assert(lds1 * kMtMaxDim <= 160 * 1024, "the widest [dim][frame] stream must fit the LDS of a CU");
+    if (sd.L == 1)
+        launch_fb_lds<1>(bd, sd, si, lds1, stream);
+    else if (sd.L <= 36)
+        launch_fb_lds<36>(bd, sd, si, lds1 * 37, stream); // tile pitch (fl_pass)
+    else
+        launch_fb_lds<64>(bd, sd, si, lds1 * (size_t)sd.L, stream); // up to 160 KB: the whole LDS of a CU
 }
 
 template <int BW>
@@ -2536,25 +2133,14 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             dim3 grid((unsigned)((ne + 255) / 256), bd.B), block(256);
             hipLaunchKernelGGL(k_mlpg_ivar, grid, block, 0, stream, bd, sd, si);
         }
-        // A/B aid: JB_LPF_AFTER_IVAR=1 records the caller's event here instead of behind the build
-        static const bool ev_after_ivar = getenv("JB_LPF_AFTER_IVAR") && atoi(getenv("JB_LPF_AFTER_IVAR")) != 0;
-        if (after_build && ev_after_ivar)
-            (void)hipEventRecord(after_build, stream);
         {
-            dim3 grid((bd.maxT + kBuildTF - 1) / kBuildTF, bd.B), block(256);
+            // sliding-window loads for up to three windows (StreamDev::mt requires W <= 3, L <= 60: 256 threads)
+            dim3 grid((bd.maxT + kBuildTF - 1) / kBuildTF, bd.B);
             const size_t lds = sizeof(double) * (size_t)(BW + 1) * sd.L * (kBuildTF + 1);
-            // sliding-window loads (k_mlpg_build_mt2) for up to three windows; JB_BUILD_V2=0: the
-            // element-per-thread kernel (same bits)
-            static const bool v2_off = getenv("JB_BUILD_V2") && atoi(getenv("JB_BUILD_V2")) == 0;
             const int nthr = ((kBuildTF / kBuildRun) * sd.L + 63) / 64 * 64;
-            if (!v2_off && sd.W <= JB_MAX_WIN_BUILD && nthr <= 1024) {
-                dim3 b2((unsigned)(nthr < 64 ? 64 : nthr));
-                hipLaunchKernelGGL(k_mlpg_build_mt2<BW>, grid, b2, lds, stream, bd, sd, si);
-            } else {
-                hipLaunchKernelGGL(k_mlpg_build_mt<BW>, grid, block, lds, stream, bd, sd, si);
-            }
+            hipLaunchKernelGGL(k_mlpg_build_mt2<BW>, grid, dim3((unsigned)nthr), lds, stream, bd, sd, si);
         }
-        if (after_build && !ev_after_ivar)
+        if (after_build)
             (void)hipEventRecord(after_build, stream);
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         const bool tp = sd.use_gv && !sd.serial_gv && sd.gv_part;
@@ -2607,15 +2193,13 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
         dim3 grid((sd.L + 63) / 64, bd.B), block(64);
         if (BW == 3 && !sd.generic_solver) {
             // F/B recurrences lane-per-dim; the GV ascent with lanes over time (one wave per dim)
-            static const bool vt = !(getenv("JB_MLPG_VT") && atoi(getenv("JB_MLPG_VT")) == 0);
-            const bool gv_vt = vt && sd.use_gv && sd.L <= 2; // frames contiguous per lane only for tiny L
+            const bool gv_vt = sd.use_gv && sd.L <= 2; // frames contiguous per lane only for tiny L
             dim3 gvgrid(sd.L, bd.B);
             if (sd.is_msd) {
                 if (gv_vt) {
                     // L == 1: [frame][1] is [1][frame]; one lane per voiced run (the compacted system is block
-                    // diagonal), or the LDS-staged sweeps over the whole utterance (JB_FB_RUNS=0): same bits
-                    static const bool runs_off = getenv("JB_FB_RUNS") && atoi(getenv("JB_FB_RUNS")) == 0;
-                    if (sd.L == 1 && !runs_off && bd.maxS > 0) {
+                    // diagonal: same bits as a sweep over the whole utterance)
+                    if (sd.L == 1 && bd.maxS > 0) {
                         dim3 rg((bd.maxS + 63) / 64, bd.B);
                         hipLaunchKernelGGL(k_mlpg_fb_runs, rg, dim3(64), 0, stream, bd, sd, si);
                     } else if (sd.L == 1)

@@ -28,9 +28,6 @@
 #include "jb_device.h"
 
 #include <cstdlib>
-#ifndef JB_SIDE_PRIO
-#define JB_SIDE_PRIO 0
-#endif
 #include <cstring>
 
 namespace jb {
@@ -156,18 +153,6 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
         }
         prevp = p; // Excitation::end
     }
-}
-
-// Static form: one lane per voiced run, 64 consecutive runs of an utterance per wave.  Every wave
-// then lasts as long as its longest run, and ~2,800 of them issue instructions for the whole
-// 6 ms beside the throughput kernels.
-__global__ void k_pulse(BatchDev bd, VocDev vd)
-{
-    const int b = (int)bd.order[blockIdx.y]; // longest utterance first
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= vd.nruns[b])
-        return;
-    pulse_run(bd, vd, b, r);
 }
 
 // Exclusive prefix of the per-utterance run counts (one block), and the counter reset.
@@ -314,224 +299,34 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     vd.xin[base * (uint64_t)fp + n] = x;
 }
 
-// Same excitation, ONE WAVE PER FRAME with FOUR CONSECUTIVE SAMPLES PER LANE (fperiod % 4 == 0,
+// Split excitation, ONE WAVE PER FRAME with FOUR CONSECUTIVE SAMPLES PER LANE (fperiod % 4 == 0,
 // fperiod <= 256, nlpf <= 33).  k_excite above reads e[] and two tap sets from LDS for every
 // (sample, tap): ~93 LDS reads per sample, which made it LDS-bound (21 ms at config 2).  Here a
-// lane keeps the 34-sample window e[4j-30 .. 4j+3] of its four outputs in registers (8.5 LDS
-// reads per sample; the LDS image is stored [sample mod 4][sample div 4] so that the window
-// reads of adjacent lanes are adjacent words) and the taps of the frame are wave-uniform.
+// lane keeps the window e[4j-30 .. 4j+3] of its four outputs in registers and the taps of the
+// frame are wave-uniform.
 // The reference adds the terms of a sample in tap order k = 0..nlpf-1, and the source sample
 // n-k lies in this frame for k <= i and in the previous one (previous frame's taps) after
 // that.  Two passes in tap order reproduce that order bit for bit: the first over the frame's
 // own e (previous-frame entries read as zero: x + 0*c == x), the second over the previous
 // frame's e with its taps, executed only by the lanes that own the first 32 samples and only
 // when that frame was voiced.
+// A sample whose window holds no pulse does not depend on the LF0 track: k_excite_noise4 computes
+// EVERY sample that way from the MSD voiced flags and the LPF taps alone (it can start with the
+// step); after the pulse walk, k_excite_fix recomputes the samples behind each pulse.  Together
+// they are bit-identical to k_excite.
 constexpr int kExw = 4;           // samples per lane
 constexpr int kExwHalo = 32;      // staged history, multiple of kExw, >= nlpf-1
 constexpr int kExwQ = (256 + kExwHalo) / kExw; // LDS row pitch (q = (m + halo) / 4)
 
-// NLPF is a template parameter: with a run-time tap count every tap becomes its own scalar
-// load + branch and the wave pays one scalar-cache latency per tap (measured 14 ms); known at
-// compile time, the taps arrive in a few wide scalar loads.
-template <int NLPF, bool NOISE_ONLY>
-__global__ __launch_bounds__(256) void k_excite_w4(BatchDev bd, VocDev vd, int utt_fastest)
-{
-    static_assert(NLPF - 1 <= kExwHalo - 2, "history window too short");
-    constexpr int kExwWin = NLPF - 1 + kExw; // window e[4j-(NLPF-1) .. 4j+3]
-    // utt_fastest: consecutive workgroups are the SAME four frames of consecutive utterances.  The noise
-    // is one table for all utterances (excitation.rs:177-237, seed fixed), indexed by the sample's
-    // position in its utterance: in this order the workgroups in flight read the same few KB of it (L2
-    // hits) instead of each utterance streaming the whole table from the Infinity Cache again.
-    const int b = utt_fastest ? blockIdx.x : blockIdx.y;
-    const uint32_t bx = utt_fastest ? blockIdx.y : blockIdx.x;
-    const UttDev *u = bd.utt + b;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx * 4u + (uint32_t)wv));
-    // wave-private LDS images: no block barrier is needed (and a wave past the end of the
-    // utterance may leave early), only wave-level ordering of the LDS writes and reads
-    if (fr >= u->T)
-        return;
-    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
-    constexpr int nlpf = NLPF;
-    const int anti = (nlpf - 1) / 2;
-    const uint64_t base = u->frame_off;
-    const uint64_t f = base + fr;
-    const uint64_t n0 = (uint64_t)fr * (uint64_t)fp; // first sample of the frame in the utterance
-    __shared__ double ec_s[4][kExw][kExwQ]; // this frame's e, zero in the history part
-    __shared__ double ep_s[4][2 * kExwHalo]; // previous frame's last 32 e, then 32 zeros (linear)
-    __shared__ double xs_s[4][kExwHalo];     // first 32 outputs, turned sample-per-lane for pass 2
-    __shared__ double nz_s[4][kExw][kExwQ]; // noise[n0 - 32 ..]
-    double(*ec)[kExwQ] = ec_s[wv];
-    double *ep = ep_s[wv];
-    double *xs = xs_s[wv];
-    double(*nz)[kExwQ] = nz_s[wv];
-    // NOISE_ONLY: every sample as if no pulse fell into its window (e = -noise in voiced frames);
-    // needs the MSD voiced flags only, not the pitch track.  k_excite_fix repairs the rest.
-    // A wave is a chain of memory round trips (7 waves per SIMD hide only so many: the kernel ran 47 %
-    // VALU-busy at 2.1 TB/s of stores), so everything it will read from memory is requested HERE, in one
-    // go behind the utterance descriptor: both voiced flags, the noise, and the taps of this frame and of
-    // the previous one as one value per lane (the tap loops take them out with v_readlane: as scalar
-    // loads they were issued after the staging barrier, those of pass 2 in five dependent pieces).
-    const uint64_t fprev = fr > 0 ? f - 1 : f;
-    uint32_t vflag_c, vflag_p;
-    if (NOISE_ONLY) {
-        vflag_c = vd.voiced[f];
-        vflag_p = vd.voiced[fprev];
-    } else {
-        vflag_c = vd.pitch[f] != 0.0;
-        vflag_p = vd.pitch[fprev] != 0.0;
-    }
-    const double *tc = vd.lpf + f * (uint64_t)nlpf;
-    const double tcv = lane < NLPF ? tc[lane] : 0.0;
-    const double tpv = lane < NLPF ? vd.lpf[fprev * (uint64_t)nlpf + (uint64_t)lane] : 0.0;
-    // ---- stage noise and e for samples m = -32 .. fp-1 of this frame ----
-    // (all noise loads of the wave are issued before the first one is consumed: the wave is
-    // latency-bound otherwise, one memory round trip per 64 samples)
-    constexpr int kIt = (256 + kExwHalo + 63) / 64;
-    double nvr[kIt];
-#pragma unroll
-    for (int it = 0; it < kIt; it++) {
-        const int idx = lane + 64 * it;
-        const long g = (long)n0 + idx - kExwHalo;
-        nvr[it] = (idx < fp + kExwHalo && g >= 0) ? vd.noise[g] : 0.0;
-    }
-    const bool vcur = __builtin_amdgcn_readfirstlane((int)vflag_c) != 0;
-    const bool vprev = fr > 0 && __builtin_amdgcn_readfirstlane((int)vflag_p) != 0;
-    // an unvoiced frame behind an unvoiced frame is the noise stream itself, delayed: nothing to store,
-    // the vocoder reads the noise table (VocDev::skip_unvoiced; 8 % of the frames of config 2, whose
-    // synthetic utterance is 90 % voiced)
-    if (vd.skip_unvoiced && fr >= 1 && !vcur && !vprev)
-        return;
-    auto tap = [](double v, int k) { // value of lane k, wave-uniform (k is a constant after unrolling)
-        const int lo = __builtin_amdgcn_readlane(__double2loint(v), k);
-        const int hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
-        return __hiloint2double(hi, lo);
-    };
-#pragma unroll
-    for (int it = 0; it < kIt; it++) {
-        const int idx = lane + 64 * it;
-        if (idx >= fp + kExwHalo)
-            break;
-        const int m = idx - kExwHalo;
-        const int row = idx & (kExw - 1), q = idx >> 2;
-        const long g = (long)n0 + m; // sample index in the utterance
-        const double nv = nvr[it];
-        double ev = 0.0;
-        if (g >= 0) {
-            const bool cur = m >= 0;
-            if (cur ? vcur : vprev) {
-                const uint64_t ff = cur ? f : f - 1;
-                const int i = cur ? m : m + fp;
-                double pulse = 0.0;
-                if (!NOISE_ONLY) {
-                    const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
-                    if ((pm >> (i % bs)) & 1ull)
-                        pulse = sqrt(fma((double)i, vd.pinc[ff], vd.cur_start[ff]));
-                }
-                ev = pulse - nv;
-            }
-        }
-        nz[row][q] = nv;
-        if (m >= 0)
-            ec[row][q] = ev;
-        else {
-            ec[row][q] = 0.0;
-            ep[idx] = ev;
-        }
-    }
-    if (lane < kExwHalo)
-        ep[kExwHalo + lane] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int i0 = lane * kExw;
-    // lanes past the end of the frame own no samples but stay: pass 2 turns the first NLPF-1
-    // samples to one per lane and needs lanes 0..NLPF-2 whatever the frame period
-    const bool own = i0 < fp;
-    double x[kExw];
-#pragma unroll
-    for (int r = 0; r < kExw; r++) {
-        // noise[n - anti], n = n0 + i0 + r  (zero before the utterance starts)
-        const int o = i0 + r - anti + kExwHalo;
-        x[r] = ((long)n0 + i0 + r - anti >= 0) ? nz[o & (kExw - 1)][o >> 2] : 0.0;
-    }
-    if (vcur && own) {
-        double ck[NLPF];
-#pragma unroll
-        for (int k = 0; k < NLPF; k++)
-            ck[k] = tap(tcv, k);
-        double w[kExwWin]; // w[c] = e[i0 - (NLPF-1) + c]
-#pragma unroll
-        for (int c = 0; c < kExwWin; c++) {
-            const int o = c + kExwHalo - (NLPF - 1);
-            w[c] = ec[o & (kExw - 1)][lane + (o >> 2)];
-        }
-#pragma unroll
-        for (int k = 0; k < NLPF; k++) {
-#pragma unroll
-            for (int r = 0; r < kExw; r++)
-                x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
-        }
-    }
-    if (vprev) {
-        // pass 2: sources in the previous frame (taps k > i), previous frame's taps.  Only the first
-        // NLPF-1 samples have any; they are turned to one sample per lane through LDS so that the
-        // pass costs NLPF-1 FMAs per wave instead of 4*(NLPF-1) on eight busy lanes.  ep[] continues
-        // with zeros where this frame starts: x + 0*c == x, the order of the remaining terms is the
-        // tap order.
-        if (own && i0 < kExwHalo) {
-#pragma unroll
-            for (int r = 0; r < kExw; r++)
-                xs[i0 + r] = x[r];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        {
-            double tk[NLPF];
-#pragma unroll
-            for (int k = 1; k < NLPF; k++)
-                tk[k] = tap(tpv, k);
-            if (lane < NLPF - 1 && lane < fp) {
-                double xv = xs[lane];
-#pragma unroll
-                for (int k = 1; k < NLPF; k++)
-                    xv = fma(ep[lane - k + kExwHalo], tk[k], xv);
-                xs[lane] = xv;
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (own && i0 < kExwHalo) {
-#pragma unroll
-            for (int r = 0; r < kExw; r++)
-                x[r] = xs[i0 + r];
-        }
-    }
-    if (!own)
-        return;
-    const uint64_t o = base * (uint64_t)fp + n0 + (uint64_t)i0;
-    *reinterpret_cast<double2 *>(vd.xin + o) = make_double2(x[0], x[1]);
-    *reinterpret_cast<double2 *>(vd.xin + o + 2) = make_double2(x[2], x[3]);
-    if (vd.exc) {
-        *reinterpret_cast<double2 *>(vd.exc + o) = make_double2(x[0], x[1]);
-        *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[2], x[3]);
-    }
-}
-
-// The pulse-free pass once more, trimmed for instruction count: k_excite_w4<NLPF, true> spends two thirds of
-// its VALU instructions outside its FMAs (1.72e9 wave instructions per launch for 0.63e9 of FMAs: five passes
-// of index arithmetic to stage 272 samples through three LDS images, two v_readlane per tap and pass), and
-// with 7 waves per SIMD the VALU pipe is what it fills first (3.5 of its 5.6 ms).  Here a lane loads the four
-// noise values of its own samples as one 32-byte piece and keeps them (the only LDS image is this frame's e,
-// for the 30-sample history of a lane's window), the start values noise[n - 15] come straight from memory
-// (the L1 has the lines), the previous frame's tail is loaded by the eight lanes that need it, and the taps
-// of the frame are scalar loads issued WITH everything else at the top (written before the staging fences,
-// which is where the compiler leaves them).  Same terms in the same order: the same bits.
-#ifndef JB_N4_GROUP
-#define JB_N4_GROUP 4 // taps per window group of pass 1 (0: the whole window in registers)
-#endif
+// The pulse-free pass.  NLPF is a template parameter (with a run-time tap count every tap is its own
+// scalar load + branch: 14 ms).  A lane loads the four noise values of its own samples as one 32-byte piece
+// and keeps them (the only LDS image is this frame's e, for the 30-sample history of a lane's window), the
+// start values noise[n - 15] come straight from memory (the L1 has the lines), the previous frame's tail is
+// loaded by the eight lanes that need it, and the taps of the frame are scalar loads issued WITH everything
+// else at the top: a wave is a chain of memory round trips, so everything it will read is requested in one
+// go behind the utterance descriptor.  (An earlier form staged 272 samples through three LDS images and
+// spent two thirds of its VALU instructions outside its FMAs: tools/experiments/README.md.)
+constexpr int kN4Group = 4; // taps per window group of pass 1
 template <int NLPF>
 __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, int utt_fastest)
 {
@@ -539,6 +334,10 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
     constexpr int kExwWin = NLPF - 1 + kExw;
     constexpr int anti = (NLPF - 1) / 2;
     constexpr int HQ = kExwHalo / kExw; // history columns of the image
+    // utt_fastest: consecutive workgroups are the SAME four frames of consecutive utterances.  The noise
+    // is one table for all utterances (excitation.rs:177-237, seed fixed), indexed by the sample's
+    // position in its utterance: in this order the workgroups in flight read the same few KB of it (L2
+    // hits) instead of each utterance streaming the whole table from the Infinity Cache again.
     const int b = utt_fastest ? blockIdx.x : blockIdx.y;
     const uint32_t bx = utt_fastest ? blockIdx.y : blockIdx.x;
     const UttDev *u = bd.utt + b;
@@ -622,12 +421,11 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (vcur && own) {
-#if JB_N4_GROUP > 0
         // the window e[i0 - (NLPF-1) .. i0 + 3] a GROUP of taps at a time (taps k0..k1 touch eleven of its 34
         // values): with the whole window in registers the kernel needs 62 VGPRs and only one of its waves fits
         // a SIMD beside the resident GV kernel's two of 208, under which its last third runs; same order of the
         // additions, so the same bits
-        constexpr int G = JB_N4_GROUP;
+        constexpr int G = kN4Group;
 #pragma unroll
         for (int k0 = 0; k0 < NLPF; k0 += G) {
             const int k1 = k0 + G - 1 < NLPF - 1 ? k0 + G - 1 : NLPF - 1;
@@ -654,26 +452,11 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
                     x[r] = fma(wg[NLPF - 1 + r - k - lo], ck[k], x[r]);
             }
         }
-#else
-        double w[kExwWin]; // w[c] = e[i0 - (NLPF-1) + c]
-#pragma unroll
-        for (int c = 0; c < NLPF - 1; c++) {
-            const int o = c + kExwHalo - (NLPF - 1);
-            w[c] = ec[o & (kExw - 1)][lane + (o >> 2)];
-        }
-#pragma unroll
-        for (int r = 0; r < kExw; r++)
-            w[NLPF - 1 + r] = 0.0 - nv[r];
-#pragma unroll
-        for (int k = 0; k < NLPF; k++) {
-#pragma unroll
-            for (int r = 0; r < kExw; r++)
-                x[r] = fma(w[NLPF - 1 + r - k], ck[k], x[r]);
-        }
-#endif
     }
     if (vprev) {
-        // pass 2 (previous frame's sources and taps), one sample per lane: as in k_excite_w4
+        // pass 2 (previous frame's sources and taps): only the first NLPF-1 samples have any; they are turned
+        // to one sample per lane through LDS so that the pass costs NLPF-1 FMAs per wave.  ep[] continues
+        // with zeros where this frame starts: x + 0*c == x, the order of the remaining terms is the tap order
         if (own && i0 < kExwHalo) {
 #pragma unroll
             for (int r = 0; r < kExw; r++)
@@ -721,16 +504,11 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
 // Second half of the split excitation: one wave per frame; frames without a pulse leave at
 // once.  For every pulse (sample p of the frame) lanes 0..NLPF-1 recompute the NLPF samples
 // p .. p+NLPF-1 that see it, from the complete e[] (all pulses, both neighbouring frames) in tap
-// order -- the same chain of FMAs as k_excite_w4's two passes, so the two kernels together are
+// order -- the same chain of FMAs as the pulse-free pass's two passes, so the two kernels together are
 // bit-identical to the one-pass form.  Samples covered by two pulses are written twice with the
 // same value.
-#ifndef JB_FIX_PARK_EARLY
-#define JB_FIX_PARK_EARLY 1
-#endif
 constexpr int kFixFrames = 8;
-#ifndef JB_FIX_UNROLL
-#define JB_FIX_UNROLL 8
-#endif
+#define JB_FIX_UNROLL 8 // (a pragma operand must be a literal)
 
 template <int NLPF>
 __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
@@ -789,7 +567,6 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
         if (any == 0ull)
             continue;
         const long n0 = (long)fr * (long)fp;
-#if JB_FIX_PARK_EARLY
         // taps of the three frames a window can touch, parked at once: held in registers until the first window
         // is staged they cost six VGPRs, and at 52 only ONE wave of this kernel fits a SIMD beside the resident
         // GV kernel's two of 208 (at 48, two)
@@ -802,17 +579,6 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                 tp3[j][lane] = (ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
             }
         }
-        bool taps_parked = true;
-#else
-        // taps of the three frames a window can touch: requested here, needed after the window is staged
-        double tpv[3];
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const long ff = (long)fr - 1 + j;
-            tpv[j] = (lane < NLPF && ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
-        }
-        bool taps_parked = false;
-#endif
         for (int q = 0; q < nblk; q++) {
             unsigned long long word;
             if (q < 4) {
@@ -859,17 +625,6 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                 __builtin_amdgcn_wave_barrier(); // the previous pulse's reads of es[] are done
                 if (lane <= 2 * H)
                     es[lane] = ev;
-#if !JB_FIX_PARK_EARLY
-                if (!taps_parked) {
-                    if (lane < NLPF) {
-#pragma unroll
-                        for (int t3 = 0; t3 < 3; t3++)
-                            tp3[t3][lane] = tpv[t3];
-                    }
-                    taps_parked = true;
-                }
-#endif
-                (void)taps_parked;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1168,302 +923,27 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
 }
 
 // --------------------------------------------------------------------------
-// Lane-pair throughput kernel: ONE CHUNK PER LANE PAIR.
-// With time-chunking there are tens of thousands of independent recursions per
-// batch, so the cross-lane machinery of k_vocoder (DPP scans, readlane combines:
-// ~128 VALU instructions per sample, most of them data movement) can be dropped.
-// The five Pade stages of df2 exchange data only BETWEEN samples (stage i reads
-// d22[i-1] of the previous sample, mlsa.rs:71-77), so a chunk is split over two
-// adjacent lanes: the even lane runs stages 1-3, the odd lane stages 4-5 (+ an inert
-// slot), each with its (nmcp-1)-tap state in architectural VGPRs (102 doubles), taps
-// outermost so the three slots give 3-way ILP.  Per sample the pair swaps three
-// values with quad_perm DPP; everything else is lane-local.  The interpolated
-// coefficients c(n) = c0 + i*cinc live in LDS as [tap][pair] pairs (broadcast
-// ds_read_b128).  ~17 VALU instructions per sample instead of ~128.
-// Inputs: gained excitation (k_excite) and bcoef; each pair streams its own column.
-// State dumps use k_vocoder's layout so that verification and re-do are shared
-// (slots nobody writes stay zero: the state buffers are zeroed at allocation).
-constexpr int DPP_QUAD_SWAP = 0xB1; // quad_perm:[1,0,3,2]
-
-#ifndef JB_LP_WAVES
-#define JB_LP_WAVES 2
-#endif
-template <int NM, int TPLW>
-__global__ __launch_bounds__(64, JB_LP_WAVES) void k_vocoder_lp(BatchDev bd, VocDev vd,
-                                                       const VocWork *__restrict__ work,
-                                                       const uint32_t *__restrict__ order,
-                                                       uint32_t n_items)
-{
-    constexpr int M = NM - 1; // live taps 1..M
-    constexpr int NS = 3;     // stage slots per lane
-    const int lane = threadIdx.x;
-    const int pair = lane >> 1;
-    const bool isA = (lane & 1) == 0; // even lane: stages 0..2; odd lane: stages 3,4 + inert slot
-    const uint32_t slot = blockIdx.x * 32u + (uint32_t)pair;
-    const bool has = slot < n_items;
-    // only the scalars of the work item stay live; its pointers are re-read at the rare
-    // save points (registers are the scarce resource of this kernel)
-    const uint32_t item = has ? order[slot] : 0u;
-    struct {
-        uint32_t utt, t_start, t_out, t_end;
-        const double *load_state;
-    } wk = {0, 0, 0, 0, nullptr};
-    if (has) {
-        const VocWork &w0 = work[item];
-        wk.utt = w0.utt;
-        wk.t_start = w0.t_start;
-        wk.t_out = w0.t_out;
-        wk.t_end = w0.t_end;
-        wk.load_state = w0.load_state;
-    }
-    const uint32_t T = has ? bd.utt[wk.utt].T : 0;
-    if (wk.t_end > T)
-        wk.t_end = T;
-    const uint32_t nfr = wk.t_end > wk.t_start ? wk.t_end - wk.t_start : 0;
-    uint32_t maxfr = nfr;
-    for (int o = 32; o > 0; o >>= 1)
-        maxfr = max(maxfr, (uint32_t)__shfl_xor((int)maxfr, o));
-    if (maxfr == 0)
-        return;
-    const uint64_t base = has ? bd.utt[wk.utt].frame_off : 0;
-    const int fp = vd.fperiod;
-    const double a = vd.alpha, na = -a, iaa = 1.0 - a * a, vol = vd.volume;
-    const int s0 = isA ? 0 : 3; // first stage of this lane
-
-    // 34*512 + 12*256 = 20480 B = 160 KiB / 8: two blocks per SIMD fit the CU's LDS
-    __shared__ double2 cc[NM - 1][32]; // row k-1: (c_k at frame start, per-sample increment) per pair
-    __shared__ double f1s[12][32];     // df1 state d11[0..5], d12[0..5] per pair (both lanes compute it)
-
-    double d[NS][M + 1];
-    double u[NS]; // slot inputs (d22[stage])
-    double gain = 1.0;
-#pragma unroll
-    for (int q = 0; q < NS; q++) {
-        u[q] = 0.0;
-#pragma unroll
-        for (int j = 0; j <= M; j++)
-            d[q][j] = 0.0;
-    }
-#pragma unroll
-    for (int i = 0; i < 12; i++)
-        f1s[i][pair] = 0.0;
-
-    // k_vocoder state layout: tap j of stage s at [64*k + 12*s + g], j-1 = g*TPLW + k
-    if (wk.load_state) {
-        const double *sp = wk.load_state;
-#pragma unroll
-        for (int q = 0; q < NS; q++) {
-            const int st = s0 + q;
-            if (st < kPade) {
-                u[q] = sp[64 * TPLW + kGroups * st];
-#pragma unroll
-                for (int j = 1; j <= M; j++)
-                    d[q][j] = sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 12; i++)
-            f1s[i][pair] = sp[64 * TPLW + 64 + i];
-    }
-    auto save_state = [&](double *sp) {
-#pragma unroll
-        for (int q = 0; q < NS; q++) {
-            const int st = s0 + q;
-            if (st < kPade) {
-                sp[64 * TPLW + kGroups * st] = u[q];
-#pragma unroll
-                for (int j = 1; j <= M; j++)
-                    sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW] = d[q][j];
-            }
-        }
-        if (isA) {
-#pragma unroll
-            for (int i = 0; i < 12; i++)
-                sp[64 * TPLW + 64 + i] = f1s[i][pair];
-        }
-    };
-
-    for (uint32_t tl = 0; tl < maxfr; tl++) {
-        const bool act = tl < nfr;
-        const uint32_t t = wk.t_start + (act ? tl : 0);
-        const uint64_t f = base + t;
-        const bool emit = act && t >= wk.t_out;
-        if (act && t == wk.t_out && wk.t_out > wk.t_start) {
-            double *sw_ = work[item].save_warm;
-            if (sw_)
-                save_state(sw_);
-        }
-        if (act && t == wk.t_out + vd.ckpt_frames) {
-            double *sc_ = work[item].save_ckpt;
-            if (sc_)
-                save_state(sc_);
-        }
-        // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
-        // the two lanes of a pair fill alternate taps
-        __syncthreads();
-        if (has) {
-            const double *bcur = vd.bcoef + f * (uint64_t)NM;
-            const double *bprev = (t > 0) ? bcur - NM : (vd.bfirst ? vd.bfirst + (uint64_t)wk.utt * NM : bcur);
-            for (int k = 1 + (lane & 1); k < NM; k += 2) {
-                const double c0v = bprev[k], c1v = bcur[k];
-                cc[k - 1][pair] = make_double2(c0v, (c1v - c0v) / (double)fp);
-            }
-            // V5 gain exp(c[0]) (mod.rs:129-131): exp once per frame, gain *= exp(cinc0) per sample;
-            // the per-sample ratio sits in the unused d11[0] slot of the df1 LDS state
-            gain = exp(bprev[0]);
-            if (isA)
-                f1s[0][pair] = exp((bcur[0] - bprev[0]) / (double)fp);
-        }
-        __syncthreads();
-        const double *xp = exc_frame_ptr(vd, base, t);
-        double *op = vd.pcm + (base + t) * (uint64_t)fp;
-        double xn = act ? xp[0] : 0.0;
-        const double gq = f1s[0][pair];
-        // PCM leaves in 32-byte sectors: over 4 samples the even lane latches samples 0,1 and
-        // the odd lane 2,3 of the group, then both store 16 B (8-byte per-lane stores would
-        // cost a whole sector each: measured 4x write amplification)
-        double o0 = 0.0, o1 = 0.0;
-        const bool quad = (fp & 3) == 0;
-        for (int i = 0; i < fp; i++) {
-            double x = xn * gain;
-            gain *= gq;
-            if (i + 1 < fp)
-                xn = act ? xp[i + 1] : 0.0;
-            const double fi = (double)i;
-            // ---- V6 df1 (mlsa.rs:54-66), both lanes of the pair redundantly ----
-            {
-                const double2 c1p = cc[0][pair];
-                const double c1 = fma(fi, c1p.y, c1p.x);
-                double out = 0.0;
-#pragma unroll
-                for (int ii = 5; ii >= 1; ii--) {
-                    const double n11 = fma(iaa, f1s[6 + ii - 1][pair], a * f1s[ii][pair]);
-                    const double n12 = n11 * c1;
-                    if (isA) {
-                        f1s[ii][pair] = n11;
-                        f1s[6 + ii][pair] = n12;
-                    }
-                    const double v = n12 * kPPade[ii];
-                    x += (ii & 1) ? v : -v;
-                    out += v;
-                }
-                if (isA)
-                    f1s[6][pair] = x;
-                x += out;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- V7 df2: fir() of this lane's stage slots, taps outermost (mlsa.rs:127-163) ----
-            double r[NS], y[NS];
-#pragma unroll
-            for (int q = 0; q < NS; q++) {
-                r[q] = u[q];
-                y[q] = 0.0;
-            }
-#pragma unroll
-            for (int j = 1; j <= M; j++) {
-                double cj = 0.0;
-                if (j >= 2) {
-                    const double2 cp = cc[j - 1][pair];
-                    cj = fma(fi, cp.y, cp.x);
-                }
-#pragma unroll
-                for (int q = 0; q < NS; q++) {
-                    // all-pass section: rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem',
-                    // as three-address v_fma_f64 (hipcc's v_fmac form costs a v_mov_b64 per tap
-                    // to undo the register rotation of the loop-carried d[])
-                    double rn, dn;
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rn) : "s"(na), "v"(r[q]), "v"(d[q][j]));
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dn) : "s"(a), "v"(rn), "v"(r[q]));
-                    d[q][j] = dn;
-                    r[q] = rn;
-                    if (j >= 2)
-                        y[q] = fma(cj, dn, y[q]);
-                }
-                // keep the scheduler from hoisting all coefficient reads to the top of the
-                // sample (it would need ~140 extra VGPRs): LDS reads run 4 taps ahead at most
-#ifndef JB_LP_SB
-#define JB_LP_SB 2
-#endif
-                if ((j % JB_LP_SB) == 0)
-                    __builtin_amdgcn_sched_barrier(0);
-            }
-            // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, swapped within the pair ----
-            // slot weights: even lane stages 1,2,3 (signs +,-,+), odd lane stages 4,5 (-,+) and 0
-            const double w0 = isA ? kPPade[1] : kPPade[4], w1 = isA ? kPPade[2] : kPPade[5],
-                         w2 = isA ? kPPade[3] : 0.0;
-            const double v0 = w0 * y[0], v1 = w1 * y[1], v2 = w2 * y[2];
-            const double sb = (v0 + v1) + v2;
-            const double sa = isA ? (v0 - v1) + v2 : v1 - v0;
-            const double oa = dpp_f64<DPP_QUAD_SWAP>(sa), ob = dpp_f64<DPP_QUAD_SWAP>(sb);
-            const double y2p = dpp_f64<DPP_QUAD_SWAP>(y[2]); // odd lane: partner's stage-2 output
-            // same order of additions in both lanes: even-lane partial first
-            const double ssum = isA ? sa + oa : oa + sa;
-            const double psum = isA ? sb + ob : ob + sb;
-            const double xmid = x + ssum; // d22[0]
-            x = xmid + psum;
-            // next-sample slot inputs: stage s+1 <- y of stage s; stage 0 <- xmid
-            u[2] = isA ? y[1] : 0.0;
-            u[1] = y[0];
-            u[0] = isA ? xmid : y2p;
-            const double pv = x * vol;
-            if (quad) {
-                const int ph = i & 3;
-                if (ph == (isA ? 0 : 2))
-                    o0 = pv;
-                if (ph == (isA ? 1 : 3))
-                    o1 = pv;
-                if (ph == 3 && emit) {
-                    if (vd.pcm16)
-                        *reinterpret_cast<uint32_t *>(vd.pcm16 + (base + t) * (uint64_t)fp + (i - 3) +
-                                                      (isA ? 0 : 2)) = pcm_i16x2(o0, o1);
-                    else
-                        *reinterpret_cast<double2 *>(op + (i - 3) + (isA ? 0 : 2)) = make_double2(o0, o1);
-                }
-            } else if (emit && isA) {
-                if (vd.pcm16)
-                    vd.pcm16[(base + t) * (uint64_t)fp + i] = (int16_t)pcm_i16(pv);
-                else
-                    op[i] = pv;
-            }
-        }
-        if (act && tl + 1 == nfr) {
-            double *se_ = work[item].save_end;
-            if (se_)
-                save_state(se_);
-        }
-    }
-}
-
-// --------------------------------------------------------------------------
 // Lane-triple throughput kernel: ONE CHUNK PER THREE ADJACENT LANES.
-// Same idea as k_vocoder_lp, but the register file is the scarce resource there (204
-// state VGPRs per lane => the compiler spills ~10 values inside the sample loop and each
-// reload is a memory round trip).  Here the five Pade stages are spread over three lanes,
-// {1,2} {3,4} {5,-}: 68 state doubles per lane, nothing spills, and there is room to keep
-// LDS reads in flight.  21 triples over lanes 0..62 of the wave (lane 63 idle), so 21 chunks per
-// wave; the per-sample exchange uses the whole-wave DPP shifts (a triple may straddle a 16-lane DPP
-// row): one wave_shr:1 (stage outputs to the next lane) and, per Pade partial sum, two wave_shl:1
-// that fold positions 2 -> 1 -> 0 of the triple.  (Five triples per 16-lane row with lane 15 of each
-// row idle -- row_shr / row_shl -- gave 20 chunks per wave: one more chunk per wave is 5 % more work
-// per launch for the same instructions.)
+// With time-chunking there are tens of thousands of independent recursions per batch, so the
+// cross-lane machinery of k_vocoder (DPP scans, readlane combines: ~128 VALU instructions per
+// sample, most of them data movement) can be dropped.  The five Pade stages of df2 exchange data
+// only BETWEEN samples (stage i reads d22[i-1] of the previous sample, mlsa.rs:71-77), so a chunk
+// is split over three adjacent lanes, stages {1,2} {3,4} {5,-}, each stage with its (nmcp-1)-tap
+// state in architectural VGPRs (68 state doubles per lane), taps outermost so the two slots give
+// 2-way ILP; everything but the per-sample exchange is lane-local.  The interpolated coefficients
+// c(n) = c0 + i*cinc live in LDS as [tap][chunk] pairs (broadcast ds_read_b128).  ~14 VALU
+// instructions per chunk-sample instead of ~128.
+// 21 triples over lanes 0..62 of the wave (lane 63 idle), so 21 chunks per wave; the exchange uses
+// the whole-wave DPP shifts (a triple may straddle a 16-lane DPP row): one wave_shr:1 (stage
+// outputs to the next lane) and, per Pade partial sum, two wave_shl:1 that fold positions
+// 2 -> 1 -> 0 of the triple.  State dumps use k_vocoder's layout so that verification and re-do are
+// shared (slots nobody writes stay zero: the state buffers are zeroed at allocation).
+// (Earlier forms -- a chunk per lane PAIR with 102 state doubles per lane, which spilled; five triples
+// per 16-lane DPP row; single-instruction asm statements; the excitation load behind a per-lane test --
+// are recorded in tools/experiments/README.md.)
 constexpr int DPP_WAVE_SHL1 = 0x130;
-#ifndef JB_LT_CHUNKS
-#define JB_LT_CHUNKS 21
-#endif
-constexpr int kLtChunks = JB_LT_CHUNKS;
-#ifndef JB_LT_PROFILE
-#define JB_LT_PROFILE 0 // 1: one wave prints the cycles of its frame set-ups and of its sample loops
-#endif
-#ifndef JB_LT_XASM
-#define JB_LT_XASM 2 // excitation load outside the compiler's vmcnt bookkeeping: 2 = two samples ahead (needs an
-                     // even frame period), 1 = one sample ahead, 0 = plain load behind the per-lane test
-#endif
-#ifndef JB_LT_PF
-#define JB_LT_PF 4
-#endif
-#ifndef JB_LT_MERGED
-#define JB_LT_MERGED 1 // per-tap FMAs as one asm block (0: single-instruction asm statements, A/B)
-#endif
+constexpr int kLtChunks = 21;
+constexpr int kLtPf = 4; // coefficient reads in flight ahead of their use (2, 3 or 4 measure the same)
 
 template <int NM, int TPLW>
 __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
@@ -1474,18 +954,10 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
     constexpr int M = NM - 1; // live taps 1..M
     constexpr int NS = 2;     // stage slots per lane
     const int lane = threadIdx.x;
-#if JB_LT_CHUNKS == 21
     const bool idle = lane == 63;
     // pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 63 behaves like pos 2)
     const int pos = idle ? 2 : lane % 3;
     const int ci = idle ? 20 : lane / 3; // chunk slot of this lane within the wave
-#else
-    const int row = lane >> 4, p16 = lane & 15;
-    const bool idle = p16 == 15;
-    // pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 15 behaves like pos 2)
-    const int tri = p16 / 3, pos = idle ? 2 : p16 % 3;
-    const int ci = row * 5 + (idle ? 4 : tri); // chunk slot of this lane within the wave
-#endif
     const uint32_t slot = blockIdx.x * (uint32_t)kLtChunks + (uint32_t)ci;
     const bool has = !idle && slot < n_items;
     const bool lead = has && pos == 0;
@@ -1577,13 +1049,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         }
     };
 
-#if JB_LT_PROFILE
-    long long pt_setup = 0, pt_samples = 0;
-#endif
     for (uint32_t tl = 0; tl < maxfr; tl++) {
-#if JB_LT_PROFILE
-        const long long pt0 = clock64();
-#endif
         const bool act = tl < nfr;
         const uint32_t t = wk.t_start + (act ? tl : 0);
         const uint64_t f = base + t;
@@ -1618,16 +1084,6 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
         const double gq = gqs[ci];
-#if JB_LT_PROFILE
-        const long long pt1 = clock64();
-        pt_setup += pt1 - pt0;
-#endif
-#if !JB_LT_XASM
-        // PCM leaves the lead lane 32 bytes at a time (8-byte stores cost a sector each)
-        double o0 = 0.0, o1 = 0.0, o2 = 0.0;
-        const bool quad = (fp & 3) == 0;
-#endif
-#if JB_LT_XASM
         // The next sample's excitation is requested at the top of a sample and used at the top of the next
         // one, a whole sample (~1.5 us) later.  Two things made that load cost 3.7 of the kernel's 66 ms
         // (measured by removing it): it sat behind a per-lane test (`act ? ... : 0`), which splits the
@@ -1639,7 +1095,6 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         // covers is a whole sample old.  (Moving the excitation through an LDS ring filled by LDS-DMA, and
         // a wait that counts the stores, both cost more than they saved: tools/experiments/.)
         const double *xq = act ? xp : vd.noise;
-        const bool pairm = (fp & 1) == 0;
         double oA = 0.0, oB = 0.0;
         auto put_pair = [&](int at) { // samples at, at+1 of this frame
             if (vd.pcm16)
@@ -1647,8 +1102,6 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             else
                 *reinterpret_cast<double2 *>(op + at) = make_double2(oA, oB);
         };
-#endif
-#if JB_LT_XASM == 2
         // TWO samples ahead, the sample loop unrolled by two: x of even samples lives in xn, of odd ones in
         // xo.  An even sample waits with vmcnt(1): everything but the youngest operation, the odd sample's
         // request, is then done -- its own request and the older pair store.  An odd sample waits with
@@ -1680,24 +1133,6 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 else
                     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn) : "v"(xq + nx) : "memory");
             }
-#elif JB_LT_XASM
-        for (int i = 0; i < fp; i++) {
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory");
-            double x = xn * gain;
-            gain *= gq;
-            if (pairm && (i & 1) == 0 && i > 0 && emit)
-                put_pair(i - 2);
-            {
-                const int nx = i + 1 < fp ? i + 1 : i; // (the last sample re-reads itself: nothing past the row)
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn) : "v"(xq + nx) : "memory");
-            }
-#else
-        for (int i = 0; i < fp; i++) {
-            double x = xn * gain;
-            gain *= gq;
-            if (i + 1 < fp)
-                xn = act ? xp[i + 1] : 0.0;
-#endif
             const double fi = (double)i;
             // ---- V6 df1 (mlsa.rs:54-66): every lane runs it, the lead lane's copy is kept ----
             {
@@ -1722,27 +1157,27 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 r[q] = u[q];
                 y[q] = 0.0;
             }
-            // Coefficient reads run JB_LT_PF taps ahead of their use in rotating registers so that
+            // Coefficient reads run kLtPf taps ahead of their use in rotating registers so that
             // their LDS latency overlaps the arithmetic in between.  hipcc sinks ordinary LDS loads
             // next to their use, so they are issued with inline asm and counted s_waitcnt
             // lgkmcnt(N); each wait is tied to its data register ("+v"), which keeps consumers
             // behind it.  LDS returns in order, so the compiler's own waits stay correct.
             typedef double v2d __attribute__((ext_vector_type(2)));
-            v2d cq[JB_LT_PF];
+            v2d cq[kLtPf];
             const uint32_t cca = (uint32_t)(uintptr_t)&cc[0][ci];
 #define JB_LDS_RD(dst, tapj)                                                                     \
     asm volatile("ds_read_b128 %0, %1 offset:%2"                                                 \
                  : "=v"(dst)                                                                     \
                  : "v"(cca), "n"(((tapj)-1) * (int)(sizeof(double2) * kLtChunks)))
 #pragma unroll
-            for (int k = 0; k < JB_LT_PF; k++)
+            for (int k = 0; k < kLtPf; k++)
                 JB_LDS_RD(cq[k], 2 + k); // taps 2 .. 1+PF
 #pragma unroll
             for (int j = 1; j <= M; j++) {
                 double cj = 0.0;
                 if (j >= 2) {
-                    const int slotq = (j - 2) % JB_LT_PF;
-                    const int inflight = (M - j) < (JB_LT_PF - 1) ? (M - j) : (JB_LT_PF - 1);
+                    const int slotq = (j - 2) % kLtPf;
+                    const int inflight = (M - j) < (kLtPf - 1) ? (M - j) : (kLtPf - 1);
                     switch (inflight) { // younger reads that may still be in flight
                     case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[slotq])); break;
                     case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cq[slotq])); break;
@@ -1754,8 +1189,8 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                     default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(cq[slotq])); break;
                     }
                     cj = fma(fi, cq[slotq].y, cq[slotq].x);
-                    if (j + JB_LT_PF <= M)
-                        JB_LDS_RD(cq[slotq], j + JB_LT_PF);
+                    if (j + kLtPf <= M)
+                        JB_LDS_RD(cq[slotq], j + kLtPf);
                 }
                 // all-pass section of tap j for both stage slots, then the dot-product terms:
                 //   rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem' ; y += c_j * d'
@@ -1764,7 +1199,6 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 // loop-carried d[] (69 moves per sample, ~19 % of the VALU work); (b) around
                 // single-instruction asm statements its hazard recogniser pads with s_nop (47 per
                 // sample), inside one block the two slots are interleaved by hand instead.
-#if JB_LT_MERGED
                 static_assert(NS == 2, "the block below is written for two stage slots per lane");
                 {
                     double rn0, rn1;
@@ -1791,40 +1225,21 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                     r[0] = rn0;
                     r[1] = rn1;
                 }
-#else
-#pragma unroll
-                for (int q = 0; q < NS; q++) {
-                    double rn, dn;
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(rn) : "s"(na), "v"(r[q]), "v"(d[q][j]));
-                    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(dn) : "s"(a), "v"(rn), "v"(r[q]));
-                    d[q][j] = dn;
-                    r[q] = rn;
-                    if (j >= 2)
-                        y[q] = fma(cj, dn, y[q]);
-                }
-#endif
             }
 #undef JB_LDS_RD
             // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, gathered on the lead lane ----
             const double v0 = w0 * y[0], v1 = w1 * y[1];
             const double sb = v0 + v1, sa = v0 - v1;
-#if JB_LT_CHUNKS == 21
             // fold position 2 into 1, then 1 into 0: sum(pos 0) = s0 + (s1 + s2)
             const double ssum = sa + dpp_f64<DPP_WAVE_SHL1>(sa + dpp_f64<DPP_WAVE_SHL1>(sa));
             const double psum = sb + dpp_f64<DPP_WAVE_SHL1>(sb + dpp_f64<DPP_WAVE_SHL1>(sb));
             const double yprev = dpp_f64<DPP_WAVE_SHR1>(y[1]); // previous lane's second stage
-#else
-            const double ssum = (sa + dpp_f64<0x101>(sa)) + dpp_f64<0x102>(sa);
-            const double psum = (sb + dpp_f64<0x101>(sb)) + dpp_f64<0x102>(sb);
-            const double yprev = dpp_f64<DPP_ROW_SHR1>(y[1]); // previous lane's second stage
-#endif
             const double xmid = x + ssum; // d22[0] (valid on the lead lane)
             x = xmid + psum;
             // next-sample slot inputs: stage s+1 <- y of stage s; stage 0 <- xmid
             u[1] = y[0];
             u[0] = pos == 0 ? xmid : yprev;
             const double pv = x * vol;
-#if JB_LT_XASM == 2
             if (ODD)
                 oB = pv;
             else
@@ -1839,64 +1254,12 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn), "+v"(xo)::"memory"); // the last samples' (unused) requests
         if (emit)
             put_pair(fp - 2);
-#elif JB_LT_XASM
-            if (pairm) {
-                if ((i & 1) == 0)
-                    oA = pv;
-                else
-                    oB = pv;
-            } else if (emit) {
-                if (vd.pcm16)
-                    vd.pcm16[(base + t) * (uint64_t)fp + i] = (int16_t)pcm_i16(pv);
-                else
-                    op[i] = pv;
-            }
-#else
-            if (quad) {
-                const int ph = i & 3;
-                if (ph == 0)
-                    o0 = pv;
-                else if (ph == 1)
-                    o1 = pv;
-                else if (ph == 2)
-                    o2 = pv;
-                else if (emit) {
-                    if (vd.pcm16) {
-                        *reinterpret_cast<uint2 *>(vd.pcm16 + (base + t) * (uint64_t)fp + (i - 3)) =
-                            make_uint2(pcm_i16x2(o0, o1), pcm_i16x2(o2, pv));
-                    } else {
-                        *reinterpret_cast<double2 *>(op + (i - 3)) = make_double2(o0, o1);
-                        *reinterpret_cast<double2 *>(op + (i - 1)) = make_double2(o2, pv);
-                    }
-                }
-            } else if (emit) {
-                if (vd.pcm16)
-                    vd.pcm16[(base + t) * (uint64_t)fp + i] = (int16_t)pcm_i16(pv);
-                else
-                    op[i] = pv;
-            }
-#endif
-#if JB_LT_XASM != 2
-        }
-#endif
-#if JB_LT_XASM == 1
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn)::"memory"); // the last sample's (unused) request
-        if (pairm && emit)
-            put_pair(fp - 2);
-#endif
-#if JB_LT_PROFILE
-        pt_samples += clock64() - pt1;
-#endif
         if (act && tl + 1 == nfr) {
             double *se_ = work[item].save_end;
             if (se_)
                 save_state(se_);
         }
     }
-#if JB_LT_PROFILE
-    if (blockIdx.x == 777 && lane == 0)
-        printf("k_vocoder_lt wave 777: %u frames, setup %lld cycles, samples %lld cycles\n", maxfr, pt_setup, pt_samples);
-#endif
 }
 
 // --------------------------------------------------------------------------
@@ -2020,50 +1383,31 @@ hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
     return hipGetLastError();
 }
 
-static bool excite_w4_ok(const VocDev &vd)
-{
-    static const bool generic = getenv("JB_EXCITE_GENERIC") && atoi(getenv("JB_EXCITE_GENERIC")) != 0;
-    return !generic && vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo &&
-           (vd.nlpf == 31 || vd.nlpf == 15);
-}
-
+// the split form (k_excite_noise4 + k_excite_fix) is built for these shapes; everything else takes k_excite
 bool excite_is_split(const VocDev &vd)
 {
-    static const bool nosplit = getenv("JB_EXCITE_SPLIT") && atoi(getenv("JB_EXCITE_SPLIT")) == 0;
-    return excite_w4_ok(vd) && !nosplit;
+    return vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo && (vd.nlpf == 31 || vd.nlpf == 15);
 }
 
 hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
 {
     if (bd.B == 0 || bd.maxT == 0 || !excite_is_split(vd))
         return hipSuccess;
-    static const bool no_swap = getenv("JB_EXCITE_UTT_FASTEST") && atoi(getenv("JB_EXCITE_UTT_FASTEST")) == 0;
     dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
-    const int swap = !no_swap && grid.x <= 65535u; // grid.y limit
+    const int swap = grid.x <= 65535u; // grid.y limit
     if (swap)
         grid = dim3(bd.B, (bd.maxT + 3) / 4);
-    // k_excite_noise4: the same pass with fewer instructions (JB_EXCITE_NOISE4=0: k_excite_w4<NLPF, true>, same bits)
-    static const bool old_w4 = getenv("JB_EXCITE_NOISE4") && atoi(getenv("JB_EXCITE_NOISE4")) == 0;
-    if (!old_w4) {
-        // 32 KB of LDS that the kernel does not use ride with every workgroup: they cap the workgroups a CU takes
-        // at three (12 waves instead of up to 40).  This pass runs on a side stream beside the MCP chain's build
-        // and band solve, which are chains of round trips at low occupancy; with all the wave slots it could get
-        // it stretched them by more than it gained (parameter generation 31.4-32.0 ms without the cap, 29.9-30.0
-        // with 20 KB, 29.9-30.6 with 28, 30.1-30.7 with 40, 31.4 with 52, same box, when the kernel had 62 VGPRs;
-        // at 48 VGPRs: 31.0-31.4 with 16 KB, 29.1-30.1 with 24, 28.7-29.6 with 32, 29.2-29.4 with 40; the same cap
-        // on the LPF MLPG or the pulse repair pass loses).  JB_EXCITE_LDS_KB overrides.
-        static const size_t pad =
-            (size_t)(getenv("JB_EXCITE_LDS_KB") ? std::max(0, atoi(getenv("JB_EXCITE_LDS_KB"))) : 32) * 1024;
-        if (vd.nlpf == 31)
-            hipLaunchKernelGGL(k_excite_noise4<31>, grid, block, pad, stream, bd, vd, swap);
-        else
-            hipLaunchKernelGGL(k_excite_noise4<15>, grid, block, pad, stream, bd, vd, swap);
-        return hipGetLastError();
-    }
+    // 32 KB of LDS that the kernel does not use ride with every workgroup: they cap the workgroups a CU takes
+    // at three (12 waves instead of up to 40).  This pass runs on a side stream beside the MCP chain's build
+    // and band solve, which are chains of round trips at low occupancy; with all the wave slots it could get
+    // it stretched them by more than it gained (parameter generation, same box, kernel at 48 VGPRs: 31.0-31.4 ms
+    // with 16 KB, 29.1-30.1 with 24, 28.7-29.6 with 32, 29.2-29.4 with 40; the same cap on the LPF MLPG or
+    // the pulse repair pass loses).
+    constexpr size_t pad = 32 * 1024;
     if (vd.nlpf == 31)
-        hipLaunchKernelGGL((k_excite_w4<31, true>), grid, block, 0, stream, bd, vd, swap);
+        hipLaunchKernelGGL(k_excite_noise4<31>, grid, block, pad, stream, bd, vd, swap);
     else
-        hipLaunchKernelGGL((k_excite_w4<15, true>), grid, block, 0, stream, bd, vd, swap);
+        hipLaunchKernelGGL(k_excite_noise4<15>, grid, block, pad, stream, bd, vd, swap);
     return hipGetLastError();
 }
 
@@ -2071,18 +1415,12 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
-    if (excite_w4_ok(vd)) {
-        dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
-        if (excite_is_split(vd)) {
-            dim3 gfix((bd.maxT + 4 * kFixFrames - 1) / (4 * kFixFrames), bd.B);
-            if (vd.nlpf == 31)
-                hipLaunchKernelGGL(k_excite_fix<31>, gfix, block, 0, stream, bd, vd);
-            else
-                hipLaunchKernelGGL(k_excite_fix<15>, gfix, block, 0, stream, bd, vd);
-        } else if (vd.nlpf == 31)
-            hipLaunchKernelGGL((k_excite_w4<31, false>), grid, block, 0, stream, bd, vd, 0);
+    if (excite_is_split(vd)) {
+        dim3 gfix((bd.maxT + 4 * kFixFrames - 1) / (4 * kFixFrames), bd.B), block(256);
+        if (vd.nlpf == 31)
+            hipLaunchKernelGGL(k_excite_fix<31>, gfix, block, 0, stream, bd, vd);
         else
-            hipLaunchKernelGGL((k_excite_w4<15, false>), grid, block, 0, stream, bd, vd, 0);
+            hipLaunchKernelGGL(k_excite_fix<15>, gfix, block, 0, stream, bd, vd);
         return hipGetLastError();
     }
     const uint64_t maxN = (uint64_t)bd.maxT * (uint64_t)vd.fperiod;
@@ -2091,18 +1429,14 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
     return hipGetLastError();
 }
 
+// 512 waves take the voiced runs from an atomic work queue, utterances longest first
+constexpr unsigned kPulseQueueWaves = 512;
 hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
 {
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
-    static const int qwaves = getenv("JB_PULSE_QUEUE") ? atoi(getenv("JB_PULSE_QUEUE")) : 512;
-    if (qwaves > 0 && vd.run_base) {
-        hipLaunchKernelGGL(k_run_scan, dim3(1), dim3(256), 0, stream, bd, vd);
-        hipLaunchKernelGGL(k_pulse_queue, dim3((unsigned)qwaves), dim3(64), 0, stream, bd, vd);
-        return hipGetLastError();
-    }
-    dim3 grid((bd.maxS + 63) / 64, bd.B), block(64);
-    hipLaunchKernelGGL(k_pulse, grid, block, 0, stream, bd, vd);
+    hipLaunchKernelGGL(k_run_scan, dim3(1), dim3(256), 0, stream, bd, vd);
+    hipLaunchKernelGGL(k_pulse_queue, dim3(kPulseQueueWaves), dim3(64), 0, stream, bd, vd);
     return hipGetLastError();
 }
 
@@ -2128,41 +1462,23 @@ hipError_t launch_voc_verify_pairs(const double *const *pairs_dev, uint32_t n_pa
 
 bool vocoder_ls_supported(int nmcp) { return nmcp == 35 || nmcp == 25; }
 
-int vocoder_ls_chunks_per_wave()
-{
-    static const bool pair = getenv("JB_LP_KERNEL") && !strcmp(getenv("JB_LP_KERNEL"), "pair");
-    return pair ? 32 : kLtChunks;
-}
+int vocoder_ls_chunks_per_wave() { return kLtChunks; }
 
 hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
                              const uint32_t *order_dev, uint32_t n_items, hipStream_t stream)
 {
     if (n_items == 0)
         return hipSuccess;
-    const int cpw = vocoder_ls_chunks_per_wave();
-    dim3 grid((n_items + cpw - 1) / cpw), block(64);
-    if (cpw == 32) {
-        switch (vd.nmcp) {
-        case 35:
-            hipLaunchKernelGGL((k_vocoder_lp<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-            break;
-        case 25:
-            hipLaunchKernelGGL((k_vocoder_lp<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-            break;
-        default:
-            return hipErrorInvalidValue;
-        }
-    } else {
-        switch (vd.nmcp) {
-        case 35:
-            hipLaunchKernelGGL((k_vocoder_lt<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-            break;
-        case 25:
-            hipLaunchKernelGGL((k_vocoder_lt<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-            break;
-        default:
-            return hipErrorInvalidValue;
-        }
+    dim3 grid((n_items + kLtChunks - 1) / kLtChunks), block(64);
+    switch (vd.nmcp) {
+    case 35:
+        hipLaunchKernelGGL((k_vocoder_lt<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+        break;
+    case 25:
+        hipLaunchKernelGGL((k_vocoder_lt<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+        break;
+    default:
+        return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }

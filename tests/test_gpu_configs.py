@@ -234,7 +234,7 @@ def test_other_spectral_orders(ctx, L2):
     vi2 = dataclasses.replace(vi, streams=[st0, vi.streams[1], vi.streams[2]])
     ref, tr = oracle_pcm(vi2, u2)
     assert np.isfinite(ref).all()
-    for kw in (dict(keep_tracks=True), dict(chunk_frames=64, kernel="pair")):
+    for kw in (dict(keep_tracks=True), dict(chunk_frames=64, kernel="triple")):
         with J.Batch(vi2, [u2, u2], **kw) as b:
             b.run()
             b.sync()
@@ -293,7 +293,7 @@ def test_other_frame_periods_and_lpf_orders(ctx, fs, fp, alpha, nlpf):
     u2 = J.Utterance(u.durations, ustreams)
     ref, _ = oracle_pcm(vi2, u2)
     assert len(ref) == 500 * fp and np.isfinite(ref).all()
-    for kw in (dict(), dict(chunk_frames=64, kernel="pair"), dict(chunk_frames=64, kernel="wave")):
+    for kw in (dict(), dict(chunk_frames=64, kernel="triple"), dict(chunk_frames=64, kernel="wave")):
         got, info = run(vi2, [u2, u2], **kw)
         assert np.array_equal(got[0], got[1])
         assert rel_rms(got[0], ref) <= 1e-9, (fs, fp, alpha, nlpf, kw)

@@ -206,7 +206,7 @@ def test_partial_redo_at_checkpoint(ctx_long, have_gpu):
     must occur and the PCM must match the serial recursion to the hand-off tolerance."""
     vi, u = ctx_long
     ser, _ = _run_vi(vi, [u], serial=True)
-    for kern in ("wave", "pair"):
+    for kern in ("wave", "triple"):
         with J.Batch(vi, [u, u], chunk_frames=160, warmup_frames=6, verify_tol=1e-9, kernel=kern) as b:
             b.run()
             b.sync()
@@ -219,7 +219,7 @@ def test_partial_redo_at_checkpoint(ctx_long, have_gpu):
               "rel RMS vs serial", e)
         assert e <= 1e-9
     # 32-frame warm-up, the default-like case: whatever fails, the result stays certified
-    with J.Batch(vi, [u], chunk_frames=136, warmup_frames=32, kernel="pair") as b:
+    with J.Batch(vi, [u], chunk_frames=136, warmup_frames=32, kernel="triple") as b:
         b.run()
         b.sync()
         assert rel_rms(b.pcm(0), ser[0]) <= 1e-9
@@ -235,7 +235,7 @@ def test_pair_kernel_equals_wave_kernel_and_oracle(oracle_voice, have_gpu):
     utts = [to_utt(d2, s2), to_utt(d1, s1), to_utt(d2, s2)]
     ser, _ = _run(v, utts, serial=True)
     wav, _ = _run(v, utts, chunk_frames=64, warmup_frames=32, kernel="wave")
-    par, info = _run(v, utts, chunk_frames=64, warmup_frames=32, kernel="pair")
+    par, info = _run(v, utts, chunk_frames=64, warmup_frames=32, kernel="triple")
     assert info["n_redo"] == 0 and info["n_items"] == 7 + 5 + 7
     ref = [oracle_run(v, d2, s2)[1], oracle_run(v, d1, s1)[1]]
     for i in range(3):
@@ -244,7 +244,7 @@ def test_pair_kernel_equals_wave_kernel_and_oracle(oracle_voice, have_gpu):
     assert rel_rms(par[0], ref[0]) <= PCM_TOL and rel_rms(par[1], ref[1]) <= PCM_TOL
     assert np.array_equal(par[0], par[2])
     print("pair vs serial rel RMS", rel_rms(par[0], ser[0]), rel_rms(par[1], ser[1]))
-    redo, info2 = _run(v, utts, chunk_frames=64, warmup_frames=1, verify_tol=1e-9, kernel="pair")
+    redo, info2 = _run(v, utts, chunk_frames=64, warmup_frames=1, verify_tol=1e-9, kernel="triple")
     assert info2["n_redo"] >= 6
     for i in range(3):
         assert rel_rms(redo[i], ser[i]) <= 1e-12, i
@@ -258,7 +258,7 @@ def test_i16_sink_equals_clamped_cast_of_f64(oracle_voice, have_gpu):
     d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
     d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
     utts = [to_utt(d2, s2), to_utt(d1, s1)] * 4
-    for kw in (dict(serial=True), dict(chunk_frames=64, kernel="wave"), dict(chunk_frames=64, kernel="pair"),
+    for kw in (dict(serial=True), dict(chunk_frames=64, kernel="wave"), dict(chunk_frames=64, kernel="triple"),
                dict(chunk_frames=64)):
         res = []
         for i16 in (False, True):
@@ -324,10 +324,10 @@ def test_cu_partition_gives_identical_pcm(oracle_voice, have_gpu):
     d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
     d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
     utts = [to_utt(d2, s2), to_utt(d1, s1)] * 3
-    ref, _ = _run(v, utts, chunk_frames=64, kernel="pair")
+    ref, _ = _run(v, utts, chunk_frames=64, kernel="triple")
     first = None
     for k in (8, 31):
-        got, info = _run(v, utts, chunk_frames=64, kernel="pair", mlpg_cus_per_xcd=k)
+        got, info = _run(v, utts, chunk_frames=64, kernel="triple", mlpg_cus_per_xcd=k)
         assert info["n_redo"] == 0
         if first is None:
             first = got

@@ -200,7 +200,7 @@ def _serial(vi, u):
         return b.pcm(0)
 
 
-@pytest.mark.parametrize("kern", ["wave", "pair"])
+@pytest.mark.parametrize("kern", ["wave", "triple"])
 def test_recertification_after_full_redo(long_utt, kern):
     """16-frame chunks have no checkpoint: a failing chunk is recomputed to its end.  Its successor
     had been checked against the end state of the first pass -- a trajectory that started wrong and
@@ -233,7 +233,7 @@ def test_repeated_runs_of_a_batch_with_failing_handoffs(ctx, long_utt):
     _, u0 = long_utt
     utts = [u0] + [synth.synth_utterance(tab, 3000, 60 + i) for i in range(3)]
     for cf, wf in ((16, 6), (160, 6)):
-        with J.Batch(vi, utts, chunk_frames=cf, warmup_frames=wf, verify_tol=1e-9, kernel="pair") as b:
+        with J.Batch(vi, utts, chunk_frames=cf, warmup_frames=wf, verify_tol=1e-9, kernel="triple") as b:
             seen = []
             for _ in range(3):
                 b.run()

@@ -1,5 +1,7 @@
-"""Bitwise A/B aid: SHA-256 of the MCP/LF0 tracks and the PCM of a fixed mid-size batch, to compare two
-builds of the library (swap jbonsai_amd/libjbonsai_amd.so between runs)."""
+"""Bitwise A/B aid: SHA-256 of the MCP/LF0 tracks and the PCM of fixed batches, to compare two builds of the
+library (swap jbonsai_amd/libjbonsai_amd.so between runs): a mid-size batch of label utterances (wave
+kernel), and 8 x the 25,546-frame synthetic utterance + 3 distinct ones (lane-triple kernel, resident GV,
+LDS-staged band solve, split excitation: the kernels of BASELINE config 2), f64 and the 16-bit sink."""
 import hashlib
 import os
 import sys
@@ -27,3 +29,27 @@ with J.Batch(voice_info(v), utts * 3, keep_tracks=True) as b:
         for a in arrs:
             h.update(np.ascontiguousarray(a).tobytes())
         print(name, h.hexdigest()[:16])
+
+from jbonsai_amd import synth  # noqa: E402
+
+eng = J.Engine.load([VOICE])
+tab, vi = synth.VoiceTables(eng), eng.voice_info()
+big = [synth.u128(tab, 0)] * 8 + [synth.synth_utterance(tab, 9000 + 700 * i, 50 + i) for i in range(3)]
+with J.Batch(vi, big, keep_tracks=True) as b:
+    b.run()
+    b.sync()
+    print("config-2 kernels:", b.info())
+    for name, arrs in (("mcp", [b.track(i, 0) for i in (0, 8, 10)]), ("lf0", [b.track(i, 1) for i in (0, 8, 10)]),
+                       ("lpf", [b.track(i, 2) for i in (0, 9)]), ("exc", [b.excitation(i) for i in (0, 9)]),
+                       ("pcm", [b.pcm(i) for i in (0, 7, 8, 9, 10)])):
+        h = hashlib.sha256()
+        for a in arrs:
+            h.update(np.ascontiguousarray(a).tobytes())
+        print("big", name, h.hexdigest()[:16])
+with J.Batch(vi, big, pcm_i16=True) as b:
+    b.run()
+    b.sync()
+    h = hashlib.sha256()
+    for i in (0, 8, 10):
+        h.update(b.pcm_i16(i).tobytes())
+    print("big pcm_i16", h.hexdigest()[:16])
