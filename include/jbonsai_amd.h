@@ -129,6 +129,11 @@ typedef struct jb_batch_opts {
                                     three parameter tracks (implies KEEP_TRACKS); no excitation, no PCM, and
                                     no device memory for them.  What jb_mlpg_batch sets */
 
+#define JB_BATCH_TEST_GANG_TIMEOUT 256u /* test aid: the first run behaves as if the resident GV kernel had timed
+                                    out in formation (possible without a fault when several such launches share a
+                                    device), which makes jb_batch_sync redo the step with the multi-launch GV
+                                    sweeps; jb_batch_gang_fallbacks counts these */
+
 /* Time-chunked vocoder (default).  The MLSA recursion is time-serial per utterance
  * (src/vocoder/mlsa.rs), but it forgets its initial state within ~16 frames (measured:
  * <=2e-11 relative after 16, rounding floor after 24; tools/warmup_study.py).  Each
@@ -237,6 +242,9 @@ int jb_batch_info(const jb_batch *b, uint32_t *chunk_frames, uint32_t *warmup_fr
 /* Of the chunks that failed the hand-off check in the last run: how many were settled by
  * recomputing only up to their checkpoint (48 frames) and how many had to be recomputed to the end. */
 int jb_batch_redo_stats(const jb_batch *b, uint32_t *n_partial, uint32_t *n_full);
+/* Times the resident GV kernel of this batch gave up in formation and the step was redone with the
+ * multi-launch sweeps (0 in normal operation; see jb_gv_gang.hip "Liveness"). */
+uint32_t jb_batch_gang_fallbacks(const jb_batch *b);
 void jb_batch_free(jb_batch *b);
 
 /* One-shot convenience: create + run + read + free.  pcm[i] must hold

@@ -29,6 +29,7 @@ BATCH_LANE_KERNEL = 16
 BATCH_SERIAL_GV = 32
 BATCH_PCM_I16 = 64
 BATCH_MLPG_ONLY = 128
+BATCH_TEST_GANG_TIMEOUT = 256
 
 
 class JbError(RuntimeError):
@@ -130,7 +131,7 @@ SYMBOLS = [
     "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_last_timing", "jb_batch_size",
     "jb_batch_num_frames", "jb_batch_num_samples", "jb_batch_total_samples", "jb_batch_read_pcm",
     "jb_batch_read_pcm_i16", "jb_batch_read_pcm_all", "jb_batch_read_pcm_i16_all", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_set_cached_memory_limit", "jb_batch_read_coefficients", "jb_batch_read_first_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
-    "jb_batch_info", "jb_batch_redo_stats", "jb_batch_free", "jb_paramgen_vocode_batch",
+    "jb_batch_info", "jb_batch_redo_stats", "jb_batch_gang_fallbacks", "jb_batch_free", "jb_paramgen_vocode_batch",
     "jb_mlpg_batch", "jb_batch_create_from_tracks", "jb_vocode_tracks_batch",
     "jb_engine_load", "jb_engine_load_from_bytes", "jb_engine_new", "jb_engine_free",
     "jb_engine_set_sampling_frequency", "jb_engine_get_sampling_frequency",
@@ -209,6 +210,8 @@ def lib():
     L.jb_batch_device_pcm.argtypes = [vp, C.POINTER(sz)]
     L.jb_batch_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.jb_batch_redo_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.jb_batch_gang_fallbacks.argtypes = [vp]
+    L.jb_batch_gang_fallbacks.restype = C.c_uint32
     L.jb_batch_free.argtypes = [vp]
     L.jb_batch_free.restype = None
     L.jb_paramgen_vocode_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz,

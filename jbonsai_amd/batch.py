@@ -203,7 +203,8 @@ class Batch:
                  keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
                  kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False,
-                 mlpg_cus_per_xcd: int = 0, pdf_set: Optional[PdfSet] = None, mlpg_only: bool = False):
+                 mlpg_cus_per_xcd: int = 0, pdf_set: Optional[PdfSet] = None, mlpg_only: bool = False,
+                 test_gang_timeout: bool = False):
         L = F.lib()
         self._L = L
         self.voice = voice
@@ -219,6 +220,7 @@ class Batch:
         opts.flags = ((F.BATCH_KEEP_TRACKS if keep_tracks else 0) | (F.BATCH_GENERIC_MLPG if generic_mlpg else 0)
                       | (F.BATCH_SERIAL if serial else 0) | (F.BATCH_SERIAL_GV if serial_gv else 0)
                       | (F.BATCH_PCM_I16 if pcm_i16 else 0) | (F.BATCH_MLPG_ONLY if mlpg_only else 0)
+                      | (F.BATCH_TEST_GANG_TIMEOUT if test_gang_timeout else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "triple": F.BATCH_LANE_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
         opts.mlpg_cus_per_xcd = mlpg_cus_per_xcd
@@ -326,6 +328,10 @@ class Batch:
         a, b = C.c_uint32(), C.c_uint32()
         F.check(self._L.jb_batch_redo_stats(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def gang_fallbacks(self) -> int:
+        """Times the resident GV kernel timed out in formation and the multi-launch sweeps took over."""
+        return self._L.jb_batch_gang_fallbacks(self._h)
 
     def device_pcm(self):
         n = C.c_size_t()

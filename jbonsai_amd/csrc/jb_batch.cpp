@@ -1312,11 +1312,20 @@ int Batch::run(bool timed)
         return hip_fail(e, "hipSetDevice");
     // a previous run's vocoder may still read what this run's parameter generation rewrites
     hipStreamWaitEvent(stream, ev_voc_done, 0);
+    last_run_timed = timed;
+    for (int si = 0; si < kMaxStream; si++)
+        if (sd[si].gv_gang_ctl && !from_tracks)
+            gang_check_pending = true;
+    const bool inject_timeout = (flags & JB_BATCH_TEST_GANG_TIMEOUT) && gang_check_pending && gang_fallbacks == 0;
     if (timed)
         hipEventRecord(ev0, stream);
     int rc = enqueue_paramgen();
     if (rc)
         return rc;
+    if (inject_timeout) // test aid: as if the resident GV kernel had given up in formation
+        for (int si = 0; si < kMaxStream; si++)
+            if (sd[si].gv_gang_ctl)
+                hipMemsetAsync(&((GvGangCtl *)sd[si].gv_gang_ctl)->err, 1, 1, stream);
     hipEventRecord(ev_mlpg_done, stream);
     hipStreamWaitEvent(stream_voc, ev_mlpg_done, 0);
     if (timed)
@@ -1510,18 +1519,25 @@ int Batch::sync()
         e = hipStreamSynchronize(stream);
     if (e != hipSuccess)
         return hip_fail(e, "stream sync");
-    for (int si = 0; si < kMaxStream; si++)
+    // The persistent GV kernel bounds its spins; an overrun is reported, never waited out.  The flag is read
+    // only when such a kernel has been enqueued since the last look (a blocking 4-byte copy per GV stream:
+    // a loop of per-utterance reads must not pay it every time).
+    bool gang_timed_out = false;
+    for (int si = 0; gang_check_pending && si < kMaxStream; si++)
         if (sd[si].gv_gang_ctl) {
-            // the persistent GV kernel bounds its spins; an overrun is reported, never waited out
             uint32_t err = 0;
-            if ((e = hipMemcpy(&err, &((const GvGangCtl *)sd[si].gv_gang_ctl)->err, sizeof err, hipMemcpyDeviceToHost)) !=
-                hipSuccess)
+            uint32_t *derr = &((GvGangCtl *)sd[si].gv_gang_ctl)->err;
+            if ((e = hipMemcpy(&err, derr, sizeof err, hipMemcpyDeviceToHost)) != hipSuccess)
                 return hip_fail(e, "hipMemcpy(gv gang err)");
             if (err) {
-                set_error("k_mlpg_gv_gang: an exchange between the workgroups of a gang timed out");
-                return JB_ERR_DEVICE;
-            }
-            if (getenv("JB_GG_PROFILE_PRINT")) { // library built with -DJB_GG_PROFILE
+                // Formation timed out: with several resident launches on one device each can hold CUs with
+                // incomplete gangs while none owns all its members.  This batch's GV runs as the multi-launch
+                // sweeps from now on (their workspace is allocated either way) and the step is done again.
+                (void)hipMemset(derr, 0, sizeof err);
+                sd[si].gv_gang_ctl = nullptr;
+                gang_timed_out = true;
+                gang_fallbacks++;
+            } else if (getenv("JB_GG_PROFILE_PRINT")) { // library built with -DJB_GG_PROFILE
                 GvGangCtl c;
                 hipMemcpy(&c, sd[si].gv_gang_ctl, sizeof c, hipMemcpyDeviceToHost);
                 const double nb = (double)sd[si].gv_gang_n * sd[si].gv_gang_tiles;
@@ -1532,6 +1548,12 @@ int Batch::sync()
                         c.prof[5] / nb);
             }
         }
+    gang_check_pending = false;
+    if (gang_timed_out) {
+        verify_pending = false; // what that run certified was computed from a GV that did not finish
+        int rc = run(last_run_timed);
+        return rc ? rc : sync();
+    }
     return finish_verify();
 }
 
@@ -2033,6 +2055,8 @@ int jb_batch_redo_stats(const jb_batch *hb, uint32_t *n_partial, uint32_t *n_ful
         *n_full = b->n_redo_full;
     return JB_OK;
 }
+
+uint32_t jb_batch_gang_fallbacks(const jb_batch *b) { return b ? ((const Batch *)b)->gang_fallbacks : 0; }
 
 void jb_batch_free(jb_batch *b) { delete (Batch *)b; }
 

@@ -30,10 +30,15 @@
 //   * rows come from a queue (one atomic per row by the gang's first tile, handed to the others in
 //     the record of an exchange the row needs anyway): an incomplete gang owns no work;
 //   * once formed, all members of a gang are resident and every exchange completes;
-//   * every spin is bounded all the same: on overrun the kernel raises `err` and leaves (the host
-//     reports JB_ERR_DEVICE).
+//   * every spin is bounded all the same: on overrun the kernel raises `err` and leaves.  That can
+//     happen without any fault when SEVERAL of these launches share a device (more than two batches in
+//     flight, or one device listed several times in a *_multi entry): each may hold CUs with incomplete
+//     gangs in formation while none owns all its members.  The host then runs that batch's GV as the
+//     multi-launch sweeps instead (Batch::sync: the step is enqueued again without the resident kernel,
+//     for this batch from then on); it reports JB_ERR_DEVICE only if that fails too.
 #include "jb_device.h"
 
+#include <cstddef>
 #include <cstdlib>
 
 namespace jb {
@@ -775,8 +780,14 @@ hipError_t launch_gv_gang(const BatchDev &bd, const StreamDev &sd, int si, hipSt
         return hipErrorInvalidValue;
     GvGangCtl *ctl = (GvGangCtl *)sd.gv_gang_ctl;
     GvGang *gangs = (GvGang *)(ctl + 1);
-    // tickets, row queue, error flag and gang counters start from zero on every launch
-    hipError_t e = hipMemsetAsync(ctl, 0, gv_gang_ctl_bytes(sd.gv_gang_n), stream);
+    // tickets, row queue and gang counters start from zero on every launch; `err` is STICKY: with
+    // run(); run(); sync() a timeout of the first run must still be there when the host looks
+    // (Batch::sync clears it when it has acted on it)
+    static_assert(offsetof(GvGangCtl, err) == 8 && sizeof(((GvGangCtl *)nullptr)->err) == 4, "layout of GvGangCtl");
+    hipError_t e = hipMemsetAsync(ctl, 0, offsetof(GvGangCtl, err), stream);
+    if (e == hipSuccess)
+        e = hipMemsetAsync((uint8_t *)ctl + offsetof(GvGangCtl, err) + 4, 0,
+                           gv_gang_ctl_bytes(sd.gv_gang_n) - offsetof(GvGangCtl, err) - 4, stream);
     if (e != hipSuccess)
         return e;
     hipLaunchKernelGGL(k_mlpg_gv_gang, dim3((unsigned)(sd.gv_gang_n * sd.gv_gang_tiles)), dim3(kGgNT), 0, stream, bd, sd, si,

@@ -102,6 +102,9 @@ struct Batch {
     template <class T> int dalloc(T **p, size_t n, bool zero);
     int upload(const void *host, size_t bytes, const void **dev);
     bool from_tracks = false;        // created from parameter tracks: run() starts at the frame prologue
+    bool gang_check_pending = false; // a resident GV kernel has been enqueued since its error flag was last read
+    bool last_run_timed = false;
+    uint32_t gang_fallbacks = 0;     // times the resident GV kernel timed out in formation and the sweeps took over
     static int create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,
                       const jb_batch_opts *opts, Batch **out, const IndexSrc *idx = nullptr,
                       const TrackSrc *trk = nullptr);

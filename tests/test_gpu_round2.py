@@ -308,3 +308,32 @@ def test_resident_gv_with_many_tiles_per_row(ctx):
                 b.sync()
                 res.append(b.track(0, 0))
         np.testing.assert_allclose(res[0], res[1], rtol=1e-12, atol=1e-13)
+
+
+def test_gang_formation_timeout_falls_back_to_the_sweeps(ctx):
+    """The resident GV kernel bounds its spins; with several such launches on one device a gang can time out
+    in formation without any fault.  jb_batch_sync then redoes the step with the multi-launch GV sweeps (for
+    that batch from then on) instead of failing.  JB_BATCH_TEST_GANG_TIMEOUT makes the first run behave that
+    way; the error flag is sticky across run(); run(); sync()."""
+    eng, tab, vi = ctx
+    utts = [synth.synth_utterance(tab, T, 700 + i) for i, T in enumerate((3000, 1200, 2600))]
+    with J.Batch(vi, utts, keep_tracks=True) as ref:
+        ref.run()
+        ref.sync()
+        assert ref.gang_fallbacks() == 0
+        want = [ref.pcm(i) for i in range(3)]
+        wtrk = ref.track(0, 0)
+    with J.Batch(vi, utts, keep_tracks=True, test_gang_timeout=True) as b:
+        b.run()
+        b.run()  # the first run's flag must survive the second launch
+        b.sync()
+        assert b.gang_fallbacks() == 1
+        got = [b.pcm(i) for i in range(3)]
+        np.testing.assert_allclose(b.track(0, 0), wtrk, rtol=1e-12, atol=1e-13)
+        b.run()
+        b.sync()
+        assert b.gang_fallbacks() == 1  # the sweeps from now on
+        again = [b.pcm(i) for i in range(3)]
+    for g, a, w in zip(got, again, want):
+        assert np.array_equal(g, a)
+        assert rel_rms(g, w) <= 1e-10
