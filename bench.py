@@ -362,6 +362,22 @@ class Ranks:
         del bufs
         return ms
 
+    def gather_native(self, J, batch):
+        """jb_gather_pcm: every rank's PCM slab onto rank 0 through the library's RCCL binding (no torch
+        tensor involved; torch.distributed only hands the 128-byte communicator id to the ranks).  Returns
+        the max-over-ranks time of the exchange in ms; the communicator setup is not part of it."""
+        ids = [J.comm.unique_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(ids, src=0)
+        c = J.comm.Comm(ids[0], self.world, self.rank, device=self.local_rank)
+        self.barrier()
+        g, ms = c.gather_pcm(batch, root=0)
+        ms = self.max(ms)
+        if g is not None:
+            assert sum(g.samples(r) for r in range(self.world)) >= batch.total_samples
+            g.close()
+        c.close()
+        return ms
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
@@ -854,9 +870,14 @@ def run_rank(args):
 
     gather_ms = None
     if args.gather and R.world > 1:
-        # optional sink of north_star: PCM of all ranks on GPU 0.  The slab is library-owned device
-        # memory viewed zero-copy; rank 0 needs world x 12.6 GB of HBM for config 2.
-        gather_ms = R.gather_slabs(pcm_slab_tensor(batch))
+        # optional sink of north_star: PCM of all ranks on GPU 0 (rank 0 needs world x 12.6 GB of HBM for
+        # config 2).  The library's own gather: grouped ncclSend / ncclRecv over xGMI (jb_gather_pcm); the
+        # communicator id is control plane and travels over the launcher's rendezvous.  In the one-GPU
+        # rehearsal (gloo) RCCL cannot run: there the slabs go through torch.distributed on the host.
+        if R.rehearse:
+            gather_ms = R.gather_slabs(pcm_slab_tensor(batch))
+        else:
+            gather_ms = R.gather_native(J, batch)
 
     info = batch.info()
     redo_stats = batch.redo_stats()

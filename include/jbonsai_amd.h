@@ -296,6 +296,35 @@ int jb_paramgen_vocode_batch_multi(const jb_voice_desc *voice, const jb_state_ut
                                    const jb_batch_opts *opts, const int32_t *devices, size_t n_devices,
                                    double *const *pcm, size_t *n_samples);
 
+/* ---- PCM gather over RCCL (north_star: "RCCL over xGMI only to gather output PCM") --------
+ * One process (or thread) per GPU synthesises its share; nothing is exchanged on the data path.  The one
+ * optional exchange is the sink that wants every rank's PCM slab on ONE GPU: variable-length slabs, so
+ * point to point -- grouped ncclSend / ncclRecv, one message per peer (over xGMI every peer has its own link
+ * into the root).  The reference has no counterpart (single process, single utterance).
+ * RCCL is bound at run time (dlopen "librccl.so.1": the copy the process already holds, else ROCm's); a
+ * communicator of one rank never loads it.  The unique id travels between the ranks by the caller's own
+ * means (a file, an environment variable, the launcher's store): it is control plane. */
+#define JB_COMM_ID_BYTES 128 /* ncclUniqueId */
+typedef struct jb_comm jb_comm;
+typedef struct jb_gathered jb_gathered;
+/* rank 0: a fresh id for jb_comm_init on every rank (ncclGetUniqueId). */
+int jb_comm_unique_id(uint8_t *id, size_t cap);
+/* ncclCommInitRank on `device` (-1 = current); collective over the n_ranks ranks.  n_ranks == 1: id may be NULL. */
+int jb_comm_init(const uint8_t *id, int n_ranks, int rank, int32_t device, jb_comm **out);
+int jb_comm_rank(const jb_comm *c);
+int jb_comm_size(const jb_comm *c);
+void jb_comm_free(jb_comm *c);
+/* Collective: every rank passes its (finished or running: the call waits) batch.  On `root`, *out holds
+ * one device slab per rank (f64 samples, or i16 for JB_BATCH_PCM_I16 batches; utterance i of rank r's batch
+ * at its jb_batch_pcm_offset); the root's own entry aliases its batch's slab (no copy: valid while that
+ * batch lives).  On the other ranks *out is NULL.  *ms (may be NULL) = wall time of the exchange. */
+int jb_gather_pcm(jb_comm *c, jb_batch *b, int root, jb_gathered **out, float *ms);
+size_t jb_gathered_samples(const jb_gathered *g, int rank);
+void *jb_gathered_device(const jb_gathered *g, int rank);
+/* Device-to-host copy of rank r's slab (cap in BYTES). */
+int jb_gathered_read(const jb_gathered *g, int rank, void *dst, size_t cap_bytes);
+void jb_gathered_free(jb_gathered *g);
+
 /* ------------------------------------------------------------------------ */
 /* (2) engine level                                                         */
 /* ------------------------------------------------------------------------ */

@@ -9,6 +9,7 @@ from .batch import (Batch, IndexStreamStates, IndexUtterance, PdfSet, StreamInfo
                     Utterance, VoiceInfo, mlpg_batch, paramgen_vocode_batch, vocode_tracks_batch)
 
 from .engine import Engine, SpeechGenerator  # noqa: F401,E402
+from . import comm  # noqa: F401,E402
 
 __all__ = ["Engine", "SpeechGenerator", "JbError", "LIB_PATH", "NODATA", "build", "lib", "write_wav", "Batch", "StreamInfo", "StreamStates",
            "Utterance", "VoiceInfo", "paramgen_vocode_batch", "mlpg_batch", "vocode_tracks_batch", "TrackUtterance", "PdfSet", "IndexUtterance", "IndexStreamStates"]

@@ -147,6 +147,8 @@ SYMBOLS = [
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
     "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",
     "jb_generator_total_frames", "jb_generator_step", "jb_generator_step_n", "jb_generator_free",
+    "jb_comm_unique_id", "jb_comm_init", "jb_comm_rank", "jb_comm_size", "jb_comm_free", "jb_gather_pcm",
+    "jb_gathered_samples", "jb_gathered_device", "jb_gathered_read", "jb_gathered_free",
     "jb_lpt_partition", "jb_paramgen_vocode_batch_multi", "jb_synthesize_batch_multi", "jb_synthesize_batch_i16_multi",
     "jb_last_error", "jb_device_count", "jb_device_arch", "jb_version",
 ]
@@ -223,6 +225,20 @@ def lib():
     L.jb_vocode_tracks_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(TrackUtt), sz, C.POINTER(BatchOpts),
                                          C.POINTER(dp), C.POINTER(sz)]
     L.jb_set_cached_memory_limit.argtypes = [sz]
+    L.jb_comm_unique_id.argtypes = [C.c_char_p, sz]
+    L.jb_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int32, C.POINTER(vp)]
+    L.jb_comm_rank.argtypes = [vp]
+    L.jb_comm_size.argtypes = [vp]
+    L.jb_comm_free.argtypes = [vp]
+    L.jb_comm_free.restype = None
+    L.jb_gather_pcm.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_float)]
+    L.jb_gathered_samples.argtypes = [vp, C.c_int]
+    L.jb_gathered_samples.restype = sz
+    L.jb_gathered_device.argtypes = [vp, C.c_int]
+    L.jb_gathered_device.restype = vp
+    L.jb_gathered_read.argtypes = [vp, C.c_int, vp, sz]
+    L.jb_gathered_free.argtypes = [vp]
+    L.jb_gathered_free.restype = None
     L.jb_lpt_partition.argtypes = [C.POINTER(C.c_uint64), sz, sz, C.POINTER(C.c_uint32)]
     L.jb_paramgen_vocode_batch_multi.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz, C.POINTER(BatchOpts),
                                                  C.POINTER(C.c_int32), sz, C.POINTER(dp), C.POINTER(sz)]

@@ -10,8 +10,12 @@
 #include "jb_host.h"
 
 #include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <dlfcn.h>
 #include <numeric>
 #include <queue>
+#include <rccl/rccl.h> // types only: the library is bound at run time (below)
 #include <thread>
 
 namespace jb {
@@ -231,5 +235,280 @@ int jb_synthesize_batch_i16_multi(const jb_engine *e, const char *const *label_l
     return jb::synthesize_multi(e, label_lines, line_off, n_utts, devices, n_devices, sizeof(int16_t), (void **)pcm,
                                 n_samples);
 }
+
+
+// ---- PCM gather over RCCL (north_star: "RCCL over xGMI only to gather output PCM") --------
+// Utterance-sharded synthesis needs no data-path collective; the one optional exchange is the sink that
+// wants every rank's PCM on one GPU.  The slabs differ in length, so the gather is point to point: grouped
+// ncclSend / ncclRecv, one message per peer -- over xGMI every peer has its own link into the root.
+// RCCL is bound with dlopen at first use ("librccl.so.1": the copy the process already holds, e.g. the one a
+// PyTorch host loaded, else ROCm's), so the library carries no link-time dependency on it and a
+// single-rank communicator never loads it.
+} // extern "C"
+
+namespace jb {
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+const Rccl *rccl()
+{
+    static const Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (x.h)
+                break;
+        }
+        if (!x.h)
+            return x;
+        auto sym = [&](const char *n) { return dlsym(x.h, n); };
+        x.GetUniqueId = (decltype(x.GetUniqueId))sym("ncclGetUniqueId");
+        x.CommInitRank = (decltype(x.CommInitRank))sym("ncclCommInitRank");
+        x.CommDestroy = (decltype(x.CommDestroy))sym("ncclCommDestroy");
+        x.GroupStart = (decltype(x.GroupStart))sym("ncclGroupStart");
+        x.GroupEnd = (decltype(x.GroupEnd))sym("ncclGroupEnd");
+        x.Send = (decltype(x.Send))sym("ncclSend");
+        x.Recv = (decltype(x.Recv))sym("ncclRecv");
+        x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
+        x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+        if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.GroupStart || !x.GroupEnd || !x.Send || !x.Recv ||
+            !x.AllGather || !x.GetErrorString)
+            x.h = nullptr;
+        return x;
+    }();
+    return r.h ? &r : nullptr;
+}
+
+int rccl_fail(const Rccl *r, ncclResult_t e, const char *what)
+{
+    set_error(std::string(what) + ": " + (r && r->GetErrorString ? r->GetErrorString(e) : "RCCL error"));
+    return JB_ERR_DEVICE;
+}
+} // namespace
+
+struct Comm {
+    int n_ranks = 1, rank = 0, device = -1;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    uint64_t *counts_dev = nullptr; // [n_ranks] sample counts (ncclAllGather)
+    ~Comm()
+    {
+        if (device >= 0)
+            hipSetDevice(device);
+        if (comm && rccl())
+            rccl()->CommDestroy(comm);
+        if (counts_dev)
+            hipFree(counts_dev);
+        if (stream)
+            hipStreamDestroy(stream);
+    }
+};
+
+struct Gathered {
+    int device = -1, n_ranks = 0;
+    size_t elem = 8;
+    std::vector<void *> slab;     // [n_ranks] device pointers; the root's own entry aliases its batch's slab
+    std::vector<size_t> samples;  // [n_ranks]
+    std::vector<uint8_t> owned;   // [n_ranks] hipMalloc'ed here
+    ~Gathered()
+    {
+        if (device >= 0)
+            hipSetDevice(device);
+        for (size_t i = 0; i < slab.size(); i++)
+            if (owned[i] && slab[i])
+                hipFree(slab[i]);
+    }
+};
+} // namespace jb
+
+extern "C" {
+
+int jb_comm_unique_id(uint8_t *id, size_t cap)
+{
+    if (!id || cap < JB_COMM_ID_BYTES)
+        return JB_ERR_BUFFER;
+    static_assert(JB_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "jb_comm id = ncclUniqueId");
+    const jb::Rccl *r = jb::rccl();
+    if (!r) {
+        jb::set_error("RCCL (librccl.so.1) cannot be loaded");
+        return JB_ERR_DEVICE;
+    }
+    ncclUniqueId u;
+    ncclResult_t e = r->GetUniqueId(&u);
+    if (e != ncclSuccess)
+        return jb::rccl_fail(r, e, "ncclGetUniqueId");
+    memcpy(id, u.internal, JB_COMM_ID_BYTES);
+    return JB_OK;
+}
+
+int jb_comm_init(const uint8_t *id, int n_ranks, int rank, int32_t device, jb_comm **out)
+{
+    if (!out || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !id))
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        jb::set_error("no HIP device available (this library has no CPU path)");
+        return JB_ERR_DEVICE;
+    }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess)
+        return JB_ERR_DEVICE;
+    if (device >= ndev) {
+        jb::set_error("device ordinal out of range");
+        return JB_ERR_INVALID;
+    }
+    std::unique_ptr<jb::Comm> c(new jb::Comm());
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    c->device = device;
+    hipError_t he = hipSetDevice(device);
+    if (he == hipSuccess)
+        he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (he == hipSuccess)
+        he = hipMalloc((void **)&c->counts_dev, sizeof(uint64_t) * (size_t)n_ranks);
+    if (he != hipSuccess)
+        return jb::hip_fail(he, "jb_comm_init");
+    if (n_ranks > 1) { // a communicator of one never touches RCCL
+        const jb::Rccl *r = jb::rccl();
+        if (!r) {
+            jb::set_error("RCCL (librccl.so.1) cannot be loaded");
+            return JB_ERR_DEVICE;
+        }
+        ncclUniqueId u;
+        memcpy(u.internal, id, JB_COMM_ID_BYTES);
+        ncclResult_t e = r->CommInitRank(&c->comm, n_ranks, u, rank);
+        if (e != ncclSuccess)
+            return jb::rccl_fail(r, e, "ncclCommInitRank");
+    }
+    *out = (jb_comm *)c.release();
+    return JB_OK;
+}
+
+void jb_comm_free(jb_comm *c) { delete (jb::Comm *)c; }
+int jb_comm_rank(const jb_comm *c) { return c ? ((const jb::Comm *)c)->rank : -1; }
+int jb_comm_size(const jb_comm *c) { return c ? ((const jb::Comm *)c)->n_ranks : 0; }
+
+int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float *ms)
+{
+    jb::Comm *c = (jb::Comm *)hc;
+    jb::Batch *b = (jb::Batch *)hb;
+    if (out)
+        *out = nullptr;
+    if (!c || !b || !out || root < 0 || root >= c->n_ranks)
+        return JB_ERR_INVALID;
+    if (b->device != c->device) {
+        jb::set_error("the batch lives on another device than the communicator");
+        return JB_ERR_INVALID;
+    }
+    size_t ns = 0;
+    void *slab = jb_batch_device_pcm(hb, &ns); // waits for the run and its certification
+    if (!slab && ns)
+        return JB_ERR_DEVICE;
+    const size_t elem = (b->flags & JB_BATCH_PCM_I16) ? 2 : 8;
+    hipError_t he = hipSetDevice(c->device);
+    if (he != hipSuccess)
+        return jb::hip_fail(he, "hipSetDevice");
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> counts((size_t)c->n_ranks, 0);
+    counts[(size_t)c->rank] = ns;
+    const jb::Rccl *r = c->n_ranks > 1 ? jb::rccl() : nullptr;
+    if (c->n_ranks > 1) {
+        // every rank learns every slab's length (the root to size its receive buffers, the others
+        // nothing more than that the call is collective)
+        uint64_t mine = ns;
+        if ((he = hipMemcpyAsync(c->counts_dev + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+            return jb::hip_fail(he, "hipMemcpy(count)");
+        ncclResult_t e = r->AllGather(c->counts_dev + c->rank, c->counts_dev, 1, ncclUint64, c->comm, c->stream);
+        if (e != ncclSuccess)
+            return jb::rccl_fail(r, e, "ncclAllGather(counts)");
+        if ((he = hipMemcpyAsync(counts.data(), c->counts_dev, sizeof(uint64_t) * counts.size(), hipMemcpyDeviceToHost,
+                                 c->stream)) != hipSuccess ||
+            (he = hipStreamSynchronize(c->stream)) != hipSuccess)
+            return jb::hip_fail(he, "count exchange");
+    }
+    std::unique_ptr<jb::Gathered> g;
+    if (c->rank == root) {
+        g.reset(new jb::Gathered());
+        g->device = c->device;
+        g->n_ranks = c->n_ranks;
+        g->elem = elem;
+        g->slab.assign((size_t)c->n_ranks, nullptr);
+        g->owned.assign((size_t)c->n_ranks, 0);
+        g->samples.assign(counts.begin(), counts.end());
+        for (int p = 0; p < c->n_ranks; p++) {
+            if (p == root) {
+                g->slab[(size_t)p] = slab; // no copy: valid while the batch lives
+            } else if (counts[(size_t)p]) {
+                if ((he = hipMalloc(&g->slab[(size_t)p], counts[(size_t)p] * elem)) != hipSuccess)
+                    return jb::hip_fail(he, "hipMalloc(gather)");
+                g->owned[(size_t)p] = 1;
+            }
+        }
+    }
+    if (c->n_ranks > 1) {
+        ncclResult_t e = r->GroupStart();
+        if (e != ncclSuccess)
+            return jb::rccl_fail(r, e, "ncclGroupStart");
+        if (c->rank == root) {
+            for (int p = 0; p < c->n_ranks && e == ncclSuccess; p++)
+                if (p != root && counts[(size_t)p])
+                    e = r->Recv(g->slab[(size_t)p], counts[(size_t)p] * elem, ncclUint8, p, c->comm, c->stream);
+        } else if (ns) {
+            e = r->Send(slab, ns * elem, ncclUint8, root, c->comm, c->stream);
+        }
+        ncclResult_t e2 = r->GroupEnd();
+        if (e != ncclSuccess || e2 != ncclSuccess)
+            return jb::rccl_fail(r, e != ncclSuccess ? e : e2, "ncclSend/ncclRecv");
+        if ((he = hipStreamSynchronize(c->stream)) != hipSuccess)
+            return jb::hip_fail(he, "gather sync");
+    }
+    if (ms)
+        *ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *out = (jb_gathered *)g.release();
+    return JB_OK;
+}
+
+size_t jb_gathered_samples(const jb_gathered *g, int rank)
+{
+    const jb::Gathered *x = (const jb::Gathered *)g;
+    return (x && rank >= 0 && rank < x->n_ranks) ? x->samples[(size_t)rank] : 0;
+}
+
+void *jb_gathered_device(const jb_gathered *g, int rank)
+{
+    const jb::Gathered *x = (const jb::Gathered *)g;
+    return (x && rank >= 0 && rank < x->n_ranks) ? x->slab[(size_t)rank] : nullptr;
+}
+
+int jb_gathered_read(const jb_gathered *g, int rank, void *dst, size_t cap_bytes)
+{
+    const jb::Gathered *x = (const jb::Gathered *)g;
+    if (!x || rank < 0 || rank >= x->n_ranks)
+        return JB_ERR_INVALID;
+    const size_t nb = x->samples[(size_t)rank] * x->elem;
+    if (cap_bytes < nb)
+        return JB_ERR_BUFFER;
+    if (nb == 0)
+        return JB_OK;
+    if (!dst)
+        return JB_ERR_INVALID;
+    hipError_t he = hipSetDevice(x->device);
+    if (he == hipSuccess)
+        he = hipMemcpy(dst, x->slab[(size_t)rank], nb, hipMemcpyDeviceToHost);
+    return he == hipSuccess ? JB_OK : jb::hip_fail(he, "hipMemcpy(gathered)");
+}
+
+void jb_gathered_free(jb_gathered *g) { delete (jb::Gathered *)g; }
 
 } // extern "C"

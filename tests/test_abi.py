@@ -35,6 +35,14 @@ def test_version_and_no_gpu_error_path():
     assert L.jb_device_count() >= 0
 
 
+def test_no_link_time_dependency_on_rccl_or_torch():
+    """RCCL is bound with dlopen at the first gather; the library links neither it nor torch."""
+    import subprocess
+
+    out = subprocess.run(["ldd", str(_ffi.LIB_PATH)], capture_output=True, text=True).stdout
+    assert "rccl" not in out and "nccl" not in out and "torch" not in out and "libjbo_oracle" not in out, out
+
+
 def test_no_torch_or_oracle_in_product():
     """The product must not import torch types into its ABI nor touch oracle/."""
     for p in (ROOT / "jbonsai_amd").rglob("*"):

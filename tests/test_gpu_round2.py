@@ -337,3 +337,33 @@ def test_gang_formation_timeout_falls_back_to_the_sweeps(ctx):
     for g, a, w in zip(got, again, want):
         assert np.array_equal(g, a)
         assert rel_rms(g, w) <= 1e-10
+
+
+def test_native_gather_world_of_one(ctx):
+    """jb_comm_* / jb_gather_pcm (grouped ncclSend / ncclRecv over xGMI for N > 1).  One GPU here: a
+    communicator of one rank gathers its own slab without a copy and without loading RCCL; that RCCL can be
+    bound at run time is checked through jb_comm_unique_id.  N > 1 is the driver's to measure: RCCL refuses
+    two ranks on one device, so it cannot be rehearsed on this box."""
+    from jbonsai_amd import comm
+
+    eng, tab, vi = ctx
+    utts = [synth.synth_utterance(tab, T, 900 + i) for i, T in enumerate((700, 5, 1300))]
+    assert len(comm.unique_id()) == 128  # librccl.so.1 is loadable and answers
+    c = comm.Comm(None, 1, 0)
+    for i16 in (False, True):
+        with J.Batch(vi, utts, pcm_i16=i16) as b:
+            b.run()  # not synced: the gather waits for the run and its certification
+            g, ms = c.gather_pcm(b, root=0)
+            assert g is not None and ms >= 0.0 and g.samples(0) == b.total_samples == 2005 * 240
+            assert g.device_pointer(0) == b.device_pcm()[0]  # the root's own slab: no copy
+            whole = g.read(0)
+            for i in range(3):
+                o = b.pcm_offset(i)
+                part = b.pcm_i16(i) if i16 else b.pcm(i)
+                assert np.array_equal(whole[o:o + len(part)], part)
+            g.close()
+    with pytest.raises(J.JbError):
+        comm.Comm(None, 2, 0)  # more than one rank needs an id
+    with pytest.raises(J.JbError):
+        comm.Comm(None, 1, 3)
+    c.close()
