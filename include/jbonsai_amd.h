@@ -460,4 +460,32 @@ const char *jb_version(void);
 #ifdef __cplusplus
 }
 #endif
+
+/* Layout of every struct that crosses the boundary, as a binding in another language must declare it
+ * (LP64, natural alignment: what `#[repr(C)]` and ctypes.Structure give).  Checked here at compile time
+ * and against the ctypes mirror in tests/test_abi.py; INTEGRATION.md section 1 carries the same table. */
+#if defined(__cplusplus) || (defined(__STDC_VERSION__) && __STDC_VERSION__ >= 201112L)
+#ifdef __cplusplus
+#define JB_LAYOUT_ASSERT(c, m) static_assert(c, m)
+#else
+#define JB_LAYOUT_ASSERT(c, m) _Static_assert(c, m)
+#endif
+JB_LAYOUT_ASSERT(sizeof(jb_stream_desc) == 56 && offsetof(jb_stream_desc, win_width) == 16 &&
+                     offsetof(jb_stream_desc, win_coef) == 48, "jb_stream_desc");
+JB_LAYOUT_ASSERT(sizeof(jb_voice_desc) == 216 && offsetof(jb_voice_desc, alpha) == 24 &&
+                     offsetof(jb_voice_desc, stream) == 48, "jb_voice_desc");
+JB_LAYOUT_ASSERT(sizeof(jb_stream_states) == 64 && offsetof(jb_stream_states, gv_weight) == 48, "jb_stream_states");
+JB_LAYOUT_ASSERT(sizeof(jb_state_utt) == 208 && offsetof(jb_state_utt, durations) == 8 &&
+                     offsetof(jb_state_utt, stream) == 16, "jb_state_utt");
+JB_LAYOUT_ASSERT(sizeof(jb_batch_opts) == 32 && offsetof(jb_batch_opts, verify_tol) == 16 &&
+                     offsetof(jb_batch_opts, mlpg_cus_per_xcd) == 24, "jb_batch_opts");
+JB_LAYOUT_ASSERT(sizeof(jb_pdf_table) == 16 && offsetof(jb_pdf_table, n_rows) == 8, "jb_pdf_table");
+JB_LAYOUT_ASSERT(sizeof(jb_index_stream) == 112 && offsetof(jb_index_stream, weight) == 64 &&
+                     offsetof(jb_index_stream, gv_weight) == 96, "jb_index_stream");
+JB_LAYOUT_ASSERT(sizeof(jb_index_utt) == 360 && offsetof(jb_index_utt, stream) == 16 &&
+                     offsetof(jb_index_utt, lf0_offset) == 352, "jb_index_utt");
+JB_LAYOUT_ASSERT(sizeof(jb_track_utt) == 64 && offsetof(jb_track_utt, spectrum_width) == 24 &&
+                     offsetof(jb_track_utt, spectrum) == 40, "jb_track_utt");
+#undef JB_LAYOUT_ASSERT
+#endif
 #endif /* JBONSAI_AMD_H */

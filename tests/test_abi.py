@@ -35,6 +35,33 @@ def test_version_and_no_gpu_error_path():
     assert L.jb_device_count() >= 0
 
 
+def test_struct_layouts_header_vs_ctypes(tmp_path):
+    """Every struct that crosses the boundary: the header's compile-time layout table (sizes and key offsets,
+    `JB_LAYOUT_ASSERT` at the end of include/jbonsai_amd.h, compiled here as C11 and as C++17) against the
+    ctypes mirror the tests call through.  A Rust `#[repr(C)]` mirror has the same layout."""
+    import ctypes as C
+    import subprocess
+
+    src = tmp_path / "lay.c"
+    names = ["jb_stream_desc", "jb_voice_desc", "jb_stream_states", "jb_state_utt", "jb_batch_opts", "jb_pdf_table",
+             "jb_index_stream", "jb_index_utt", "jb_track_utt"]
+    src.write_text('#include "jbonsai_amd.h"\n#include <stdio.h>\nint main(void){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}\n")
+    sizes = None
+    for cc, std, lang in (("gcc", "-std=c11", "c"), ("g++", "-std=c++17", "c++")):
+        exe = tmp_path / ("lay_" + cc.replace("+", "p"))
+        subprocess.run([cc, std, "-x", lang, "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+        got = [int(x) for x in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+        assert sizes is None or sizes == got
+        sizes = got
+    mirror = [_ffi.StreamDesc, _ffi.VoiceDesc, _ffi.StreamStates, _ffi.StateUtt, _ffi.BatchOpts, _ffi.PdfTable,
+              _ffi.IndexStream, _ffi.IndexUtt, _ffi.TrackUtt]
+    assert sizes == [C.sizeof(m) for m in mirror] == [56, 216, 64, 208, 32, 16, 112, 360, 64]
+    assert _ffi.VoiceDesc.alpha.offset == 24 and _ffi.VoiceDesc.stream.offset == 48
+    assert _ffi.StateUtt.stream.offset == 16 and _ffi.IndexUtt.lf0_offset.offset == 352
+    assert _ffi.TrackUtt.spectrum.offset == 40 and _ffi.BatchOpts.verify_tol.offset == 16
+
+
 def test_no_link_time_dependency_on_rccl_or_torch():
     """RCCL is bound with dlopen at the first gather; the library links neither it nor torch."""
     import subprocess
