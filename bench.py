@@ -523,7 +523,10 @@ def run_config3(R, J, tab, vi, pset, args, steps, warmup):
     def run_passes(n):
         # n passes over this rank's sub-batches as one sequence.  The next sub-batch (of this pass or the
         # next one) is created -- index upload, device gather, work list -- on a helper thread while the GPU
-        # runs the current one: two sub-batches resident at most, every creation inside the timed region
+        # runs the current one: two sub-batches resident at most, every creation inside the timed region.
+        # (Enqueueing the next sub-batch's step behind the running one as well -- two in flight -- was
+        # measured and loses: 1027 against 910 ms per pass on one box; its kernels queue in front of the
+        # running sub-batch's certification and redo round.)
         seq = [k for _ in range(n) for k in range(len(subs))]
         nxt = {}
 
@@ -922,8 +925,8 @@ def run_rank(args):
     batch.close()
     if not args.no_extras:
         # BASELINE config 3 as ONE job beside the headline: the 4096-utterance list, this rank's share walked
-        # in sub-batches.  N > 1: one warm-up pass and two timed passes ("config3_strong"); N = 1: one of each
-        # ("config3_job": ~1 s per pass).  The job keeps two sub-batches alive: let the memory pool hold both
+        # in sub-batches: one warm-up pass and two timed passes ("config3_strong" at N > 1, "config3_job" at
+        # N = 1: ~0.9 s per pass).  The job keeps two sub-batches alive: let the memory pool hold both
         pset = None
         try:
             J.lib().jb_release_cached_memory()
@@ -931,7 +934,7 @@ def run_rank(args):
             pset = tab.pdf_set(R.local_rank)
         except Exception:
             pass  # run_config3 reports it: creating a batch over a missing set fails on this rank only
-        rec = run_config3(R, J, tab, vi, pset, args, 2 if R.world > 1 else 1, 1)
+        rec = run_config3(R, J, tab, vi, pset, args, 2, 1)
         if pset is not None:
             pset.close()
         if out is not None:
