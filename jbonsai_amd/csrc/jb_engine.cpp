@@ -359,7 +359,50 @@ static void blend(const Engine &e, const std::vector<double> &w, size_t len, dou
 
 // indexed == true: the stream Gaussians are NOT blended on the host; st.iutt carries the pdf rows
 // (tree search result) of every state and voice for the device-side gather (needs Engine::cat).
-static int build_states(const Engine &e, const char *const *lines, size_t n, States &st, bool indexed = false)
+// Runs fn(lo, hi) over [0, n) in `nt` contiguous pieces on host threads (in the calling thread when nt == 1);
+// a ModelError thrown by a piece is rethrown here.  The per-label work of the front half (tree searches with
+// string-predicate questions, pdf blend) is independent per label and read-only on the engine.
+template <class F> static void parallel_labels(size_t n, unsigned nt, F fn)
+{
+    nt = (unsigned)std::min<size_t>(nt ? nt : 1u, std::max<size_t>(n / 32, 1)); // at least 32 labels per thread
+    if (nt <= 1) {
+        fn((size_t)0, n);
+        return;
+    }
+    std::vector<std::string> errs(nt);
+    std::vector<uint8_t> failed(nt, 0);
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nt; t++)
+        pool.emplace_back([&, t] {
+            try {
+                fn(n * t / nt, n * (t + 1) / nt);
+            } catch (const ModelError &ex) {
+                failed[t] = 1;
+                errs[t] = ex.what();
+            }
+        });
+    for (auto &th : pool)
+        th.join();
+    for (unsigned t = 0; t < nt; t++)
+        if (failed[t])
+            throw ModelError(errs[t]);
+}
+
+// label_threads: host threads for the per-label work of ONE utterance (1 inside jb_synthesize_batch, whose
+// workers already take an utterance each; several for the single-utterance entries, where a 1,456-label text
+// otherwise spends 15-20 ms in tree searches before the device sees anything)
+// worker threads of the front half: JB_HOST_THREADS, default min(16, cores)
+static unsigned host_threads_default()
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    nt = nt ? std::min(nt, 16u) : 1u;
+    if (const char *ev = getenv("JB_HOST_THREADS"))
+        nt = (unsigned)std::max(1, atoi(ev));
+    return nt;
+}
+
+static int build_states(const Engine &e, const char *const *lines, size_t n, States &st, bool indexed = false,
+                        unsigned label_threads = 1)
 {
     const Condition &c = e.cond;
     const Voice &v0 = *e.voices[0];
@@ -372,16 +415,18 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
     try {
         // Models::duration (model/mod.rs:80-92)
         std::vector<MV> dp(S);
-        std::vector<double> tmp(2 * ns);
-        QuestionMemo memo; // question results of the current label, per model
-        for (size_t i = 0; i < nl; i++) {
-            memo.reset();
-            blend(e, c.w_duration, 2 * ns, tmp.data(),
-                  [&](const Voice &v) { return v.duration.get_parameter(2, pl.labels[i], &memo); });
-            for (size_t s = 0; s < ns; s++)
-                dp[i * ns + s] = {tmp[s], tmp[s + ns]};
-        }
-        if (S) {
+        parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
+            std::vector<double> tmp(2 * ns);
+            QuestionMemo memo; // question results of the current label, per model
+            for (size_t i = lo; i < hi; i++) {
+                memo.reset();
+                blend(e, c.w_duration, 2 * ns, tmp.data(),
+                      [&](const Voice &v) { return v.duration.get_parameter(2, pl.labels[i], &memo); });
+                for (size_t s = 0; s < ns; s++)
+                    dp[i * ns + s] = {tmp[s], tmp[s + ns]};
+            }
+        });
+            if (S) {
             if (c.phoneme_alignment) {
                 // create_with_alignment (duration.rs:41-65)
                 size_t frame_count = 0, next_state = 0, state = 0, nd = 0;
@@ -410,7 +455,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                 }
             }
         }
-        st.utt.num_states = (uint32_t)S;
+            st.utt.num_states = (uint32_t)S;
         st.utt.durations = st.dur.data();
         // Models::stream / gv (model/mod.rs:98-146)
         for (size_t si = 0; si < v0.streams.size() && si < (size_t)kMaxStream; si++) {
@@ -422,18 +467,22 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                 for (size_t v = 0; v < e.voices.size(); v++)
                     st.rows[si][v].assign(S, 0);
                 st.weights[si] = c.w_param[si];
-                for (size_t i = 0; i < nl; i++) {
-                    memo.reset();
-                    for (size_t s = 0; s < ns; s++)
-                        for (size_t v = 0; v < e.voices.size(); v++) {
-                            const Model &m = e.voices[v]->streams[si].stream;
-                            int tp, pi;
-                            m.get_index((int)(2 + s), pl.labels[i], tp, pi, &memo);
-                            if (tp < 0 || pi < 1 || pi > m.npdf[(size_t)tp])
-                                throw ModelError("index not found"); // reference: todo!() (voice/model.rs:76-79)
-                            st.rows[si][v][i * ns + s] = e.cat[v * nsx + si].tree_off[(size_t)tp] + (uint32_t)(pi - 1);
-                        }
-                }
+                parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
+                    QuestionMemo memo;
+                    for (size_t i = lo; i < hi; i++) {
+                        memo.reset();
+                        for (size_t s = 0; s < ns; s++)
+                            for (size_t v = 0; v < e.voices.size(); v++) {
+                                const Model &m = e.voices[v]->streams[si].stream;
+                                int tp, pi;
+                                m.get_index((int)(2 + s), pl.labels[i], tp, pi, &memo);
+                                if (tp < 0 || pi < 1 || pi > m.npdf[(size_t)tp])
+                                    throw ModelError("index not found"); // reference: todo!() (voice/model.rs:76-79)
+                                st.rows[si][v][i * ns + s] =
+                                    e.cat[v * nsx + si].tree_off[(size_t)tp] + (uint32_t)(pi - 1);
+                            }
+                    }
+                });
                 jb_index_stream &io = st.iutt.stream[si];
                 for (size_t v = 0; v < e.voices.size(); v++)
                     io.row[v] = st.rows[si][v].data();
@@ -442,22 +491,25 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
             st.mean[si].assign(S * WL, 0.0);
             st.var[si].assign(S * WL, 0.0);
             st.msd[si].assign(S, DBL_MAX);
-            std::vector<double> buf(plen);
-            for (size_t i = 0; i < nl; i++) {
-                memo.reset();
-                for (size_t s = 0; s < ns; s++) {
-                    blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
-                        return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i], &memo);
-                    });
-                    const size_t row = i * ns + s;
-                    std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
-                    std::copy(buf.begin() + WL, buf.begin() + 2 * WL, st.var[si].begin() + row * WL);
-                    if (sm.is_msd)
-                        st.msd[si][row] = buf[2 * WL];
+            parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
+                std::vector<double> buf(plen);
+                QuestionMemo memo;
+                for (size_t i = lo; i < hi; i++) {
+                    memo.reset();
+                    for (size_t s = 0; s < ns; s++) {
+                        blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
+                            return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i], &memo);
+                        });
+                        const size_t row = i * ns + s;
+                        std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
+                        std::copy(buf.begin() + WL, buf.begin() + 2 * WL, st.var[si].begin() + row * WL);
+                        if (sm.is_msd)
+                            st.msd[si][row] = buf[2 * WL];
+                    }
                 }
+            });
             }
-            }
-            jb_stream_states &o = st.utt.stream[si];
+                    jb_stream_states &o = st.utt.stream[si];
             o.mean = st.mean[si].data();
             o.var = st.var[si].data();
             o.msd = sm.is_msd ? st.msd[si].data() : nullptr;
@@ -481,7 +533,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                 o.gv_var = st.gvv[si].data();
                 o.gv_switch = st.gsw[si].data();
             }
-            if (indexed) {
+                    if (indexed) {
                 jb_index_stream &io = st.iutt.stream[si];
                 io.gv_mean = o.gv_mean;
                 io.gv_var = o.gv_var;
@@ -806,7 +858,7 @@ int jb_engine_states(const jb_engine *e, const char *const *lines, size_t n, jb_
         return JB_ERR_INVALID;
     *out = nullptr;
     std::unique_ptr<jb::States> st(new jb::States());
-    int rc = build_states(*CENG(e), lines, n, *st);
+    int rc = build_states(*CENG(e), lines, n, *st, false, host_threads_default());
     if (rc)
         return rc;
     *out = (jb_states *)st.release();
@@ -888,12 +940,9 @@ int jb::synthesize_batch_impl(const jb_engine *e, const char *const *lines, cons
     // duration.rs) is independent per utterance and read-only on the engine: host threads, one
     // utterance at a time each (JB_HOST_THREADS, default min(16, cores)).  It is ~13 ms per 128 s
     // utterance and thread against ~0.7 ms of GPU time.
-    unsigned nt = std::thread::hardware_concurrency();
-    nt = nt ? std::min(nt, 16u) : 1u;
-    if (host_threads) // a multi-device call shares the host cores between its device threads
+    unsigned nt = host_threads_default();
+    if (host_threads && !getenv("JB_HOST_THREADS")) // a multi-device call shares the host cores between its device threads
         nt = host_threads;
-    if (const char *ev = getenv("JB_HOST_THREADS"))
-        nt = (unsigned)std::max(1, atoi(ev));
     // device-side gather + blend unless JB_HOST_BLEND=1 (A/B: both produce the same bits)
     const bool host_blend = getenv("JB_HOST_BLEND") && atoi(getenv("JB_HOST_BLEND")) != 0;
     const jb_pdf_set *pset = nullptr;
@@ -940,9 +989,13 @@ int jb::synthesize_batch_impl(const jb_engine *e, const char *const *lines, cons
         std::vector<int> rcs(hi - lo, JB_OK);
         std::vector<std::string> errs(hi - lo);
         std::atomic<size_t> next{lo};
+        // fewer utterances than threads (a single long text through jb_synthesize): the spare threads split
+        // each utterance's labels
+        const unsigned per_utt = (unsigned)std::max<size_t>(1, nt / std::max<size_t>(1, hi - lo));
         auto work = [&]() {
             for (size_t u; (u = next.fetch_add(1)) < hi;) {
-                rcs[u - lo] = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u], indexed);
+                rcs[u - lo] = build_states(*CENG(e), lines + line_off[u], line_off[u + 1] - line_off[u], *sts[u], indexed,
+                                           per_utt);
                 if (rcs[u - lo])
                     errs[u - lo] = jb::g_err; // the worker's thread-local message
             }
@@ -1139,7 +1192,7 @@ int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_
         return JB_ERR_INVALID;
     *out = nullptr;
     jb::States st;
-    int rc = build_states(*CENG(e), lines, n, st);
+    int rc = build_states(*CENG(e), lines, n, st, false, host_threads_default());
     if (rc)
         return rc;
     std::unique_ptr<jb::Generator> g(new jb::Generator());

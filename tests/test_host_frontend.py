@@ -198,3 +198,26 @@ def test_synthesize_fails_loudly_without_gpu(engine):
     with pytest.raises(J.JbError) as ei:
         engine.synthesize(SAMPLE_SENTENCE_1)
     assert ei.value.code == -3
+
+
+def test_threaded_label_loops_do_not_change_the_states(monkeypatch):
+    """A single long utterance splits its per-label work (tree searches, pdf blend) over host threads
+    (JB_HOST_THREADS): the states must not depend on the thread count, and a model error in one piece
+    must surface."""
+    from tests.golden.labels import GENJI
+
+    e = J.Engine.load([VOICE])
+    outs = []
+    for nt in ("1", "3", "8"):
+        monkeypatch.setenv("JB_HOST_THREADS", nt)
+        outs.append(e.states(GENJI))
+    for o in outs[1:]:
+        assert np.array_equal(o.durations, outs[0].durations)
+        for a, b in zip(o.streams, outs[0].streams):
+            assert np.array_equal(a.mean, b.mean) and np.array_equal(a.var, b.var)
+            assert (a.msd is None) == (b.msd is None) and (a.msd is None or np.array_equal(a.msd, b.msd))
+    bad = list(GENJI)
+    bad[1000] = "not a label"
+    with pytest.raises(J.JbError) as ei:
+        e.states(bad)
+    assert ei.value.code == -5
