@@ -113,7 +113,8 @@ typedef struct jb_batch_opts {
 
 #define JB_BATCH_KEEP_TRACKS 1u  /* keep MLPG parameter tracks readable (tests) */
 #define JB_BATCH_GENERIC_MLPG 2u /* un-fused, reference-shaped MLPG kernels (A/B parity tests) */
-#define JB_BATCH_SERIAL 4u       /* one wave per utterance, no time-chunking (reference-shaped recursion) */
+#define JB_BATCH_SERIAL 4u       /* one wave per utterance, no time-chunking (reference-shaped recursion): an utterance's
+                                    audio is then bitwise independent of the rest of the batch */
 #define JB_BATCH_WAVE_KERNEL 8u  /* always the wave-per-chunk vocoder kernel (A/B tests) */
 #define JB_BATCH_LANE_KERNEL 16u /* always the lane-triple throughput kernel, whatever the batch size (A/B tests) */
 #define JB_BATCH_PCM_I16 64u     /* fused 16-bit sink: the vocoder writes clamped i16 PCM (value.min(32767).max(-32768)
@@ -354,6 +355,16 @@ int jb_engine_set_gv_weight(jb_engine *e, size_t stream, double v);
 double jb_engine_get_gv_weight(const jb_engine *e, size_t stream);
 int jb_engine_set_phoneme_alignment_flag(jb_engine *e, int flag);
 int jb_engine_get_phoneme_alignment_flag(const jb_engine *e);
+/* New (no reference counterpart; the reference has no batches).  By default an utterance's audio depends,
+ * to about 1e-10 relative, on what else is in its batch: the time-chunked vocoder picks its chunk length from
+ * the batch's total length and hand-offs are certified to 1e-9 of the filter state, not to the last bit
+ * (README.md:124 of the reference advertises bitwise-identical audio between builds).  With this flag every
+ * batch of the engine runs with JB_BATCH_SERIAL | JB_BATCH_SERIAL_GV -- one wave per utterance, the
+ * reference-shaped recursion from zero state, and the GV sums in the reference's serial order (parameter tracks
+ * bit-exact against the CPU path) -- and the same labels give the SAME BITS alone, in any batch, through the
+ * generator and on any device count; throughput drops to one SIMD per utterance. */
+int jb_engine_set_batch_invariant(jb_engine *e, int flag);
+int jb_engine_get_batch_invariant(const jb_engine *e);
 int jb_engine_set_speed(jb_engine *e, double v);
 double jb_engine_get_speed(const jb_engine *e);
 int jb_engine_set_alpha(jb_engine *e, double v);

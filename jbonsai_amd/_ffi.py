@@ -138,7 +138,8 @@ SYMBOLS = [
     "jb_engine_set_fperiod", "jb_engine_get_fperiod", "jb_engine_set_volume", "jb_engine_get_volume",
     "jb_engine_set_msd_threshold", "jb_engine_get_msd_threshold", "jb_engine_set_gv_weight",
     "jb_engine_get_gv_weight", "jb_engine_set_phoneme_alignment_flag",
-    "jb_engine_get_phoneme_alignment_flag", "jb_engine_set_speed", "jb_engine_get_speed",
+    "jb_engine_get_phoneme_alignment_flag", "jb_engine_set_batch_invariant", "jb_engine_get_batch_invariant",
+    "jb_engine_set_speed", "jb_engine_get_speed",
     "jb_engine_set_alpha", "jb_engine_get_alpha", "jb_engine_set_beta", "jb_engine_get_beta",
     "jb_engine_set_additional_half_tone", "jb_engine_get_additional_half_tone",
     "jb_engine_num_voices", "jb_engine_num_streams", "jb_engine_num_states",

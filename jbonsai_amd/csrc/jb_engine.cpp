@@ -39,6 +39,7 @@ struct Condition {
     double volume = 1.0;
     std::vector<double> msd_threshold, gv_weight;
     bool phoneme_alignment = false;
+    bool batch_invariant = false; // jb_engine_set_batch_invariant: JB_BATCH_SERIAL | JB_BATCH_SERIAL_GV for every batch of this engine
     double speed = 1.0;
     size_t stage = 0;
     bool use_log_gain = false;
@@ -709,6 +710,12 @@ int jb_engine_set_phoneme_alignment_flag(jb_engine *e, int f)
     return JB_OK;
 }
 int jb_engine_get_phoneme_alignment_flag(const jb_engine *e) { return CENG(e)->cond.phoneme_alignment; }
+int jb_engine_set_batch_invariant(jb_engine *e, int f)
+{
+    ENG(e)->cond.batch_invariant = f != 0;
+    return JB_OK;
+}
+int jb_engine_get_batch_invariant(const jb_engine *e) { return CENG(e)->cond.batch_invariant; }
 int jb_engine_set_speed(jb_engine *e, double v)
 {
     ENG(e)->cond.speed = std::max(v, 1.0E-06);
@@ -1023,7 +1030,7 @@ int jb::synthesize_batch_impl(const jb_engine *e, const char *const *lines, cons
         const size_t lo = glo[g], hi = glo[g + 1];
         jb_batch_opts opts{};
         opts.device = device;
-        opts.flags = elem == 2 ? JB_BATCH_PCM_I16 : 0;
+        opts.flags = (elem == 2 ? JB_BATCH_PCM_I16 : 0) | (CENG(e)->cond.batch_invariant ? (JB_BATCH_SERIAL | JB_BATCH_SERIAL_GV) : 0);
         jb::Batch *b = nullptr;
         int rc;
         if (indexed) {
@@ -1198,6 +1205,7 @@ int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_
     std::unique_ptr<jb::Generator> g(new jb::Generator());
     jb_batch_opts opts{};
     opts.device = -1;
+    opts.flags = CENG(e)->cond.batch_invariant ? (JB_BATCH_SERIAL | JB_BATCH_SERIAL_GV) : 0;
     jb::Batch *b = nullptr;
     if ((rc = jb::Batch::create(&CENG(e)->desc, &st.utt, 1, &opts, &b)))
         return rc;

@@ -42,6 +42,8 @@ def _bind(L):
         getattr(L, "jb_engine_get_" + n).restype = C.c_double
     L.jb_engine_set_phoneme_alignment_flag.argtypes = [vp, C.c_int]
     L.jb_engine_get_phoneme_alignment_flag.argtypes = [vp]
+    L.jb_engine_set_batch_invariant.argtypes = [vp, C.c_int]
+    L.jb_engine_get_batch_invariant.argtypes = [vp]
     for n in ("num_voices", "num_streams", "num_states"):
         getattr(L, "jb_engine_" + n).argtypes = [vp]
         getattr(L, "jb_engine_" + n).restype = sz
@@ -117,6 +119,8 @@ class _Condition:
     def get_speed(self): return self._L().jb_engine_get_speed(self._h())
     def set_phoneme_alignment_flag(self, b): F.check(self._L().jb_engine_set_phoneme_alignment_flag(self._h(), int(bool(b))))
     def get_phoneme_alignment_flag(self): return bool(self._L().jb_engine_get_phoneme_alignment_flag(self._h()))
+    def set_batch_invariant(self, b): F.check(self._L().jb_engine_set_batch_invariant(self._h(), int(bool(b))))
+    def get_batch_invariant(self): return bool(self._L().jb_engine_get_batch_invariant(self._h()))
     def set_alpha(self, f): F.check(self._L().jb_engine_set_alpha(self._h(), float(f)))
     def get_alpha(self): return self._L().jb_engine_get_alpha(self._h())
     def set_beta(self, f): F.check(self._L().jb_engine_set_beta(self._h(), float(f)))

@@ -303,3 +303,23 @@ def test_synthesize_batch_in_groups_equals_one_batch(engine, monkeypatch):
     for a, b in zip(i16, one):
         assert np.array_equal(a, np.clip(b, -32768.0, 32767.0).astype(np.int16)) or \
             np.max(np.abs(a.astype(np.float64) - np.clip(b, -32768.0, 32767.0))) <= 1.0
+
+
+def test_batch_invariant_option_gives_the_same_bits_alone_and_in_any_batch():
+    """By default an utterance's audio depends (to ~1e-10) on what else is in its batch: the chunk length of
+    the time-chunked vocoder follows the batch's total length.  jb_engine_set_batch_invariant (JB_BATCH_SERIAL
+    for every batch of the engine) makes it the same bits alone, in a small and in a larger batch, and through
+    the streaming generator."""
+    e = J.Engine.load([VOICE])
+    assert not e.condition.get_batch_invariant()
+    e.condition.set_batch_invariant(True)
+    assert e.condition.get_batch_invariant()
+    alone = e.synthesize(SAMPLE_SENTENCE_2)
+    assert abs(alone[30000] - 2566.2058730889985) < EPS  # src/lib.rs:130
+    small = e.synthesize_batch([SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2])
+    big = e.synthesize_batch([list(SAMPLE_SENTENCE_2) * 30, SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2, []] * 3)
+    assert np.array_equal(small[1], alone) and np.array_equal(big[2], alone) and np.array_equal(big[10], alone)
+    assert np.array_equal(small[0], big[1])
+    assert np.array_equal(e.generator(SAMPLE_SENTENCE_2).generate_all(), alone)
+    k = e.clone()
+    assert k.condition.get_batch_invariant()
