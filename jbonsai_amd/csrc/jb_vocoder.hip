@@ -312,8 +312,8 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
 // when that frame was voiced.
 // A sample whose window holds no pulse does not depend on the LF0 track: k_excite_noise4 computes
 // EVERY sample that way from the MSD voiced flags and the LPF taps alone (it can start with the
-// step); after the pulse walk, k_excite_fix recomputes the samples behind each pulse.  Together
-// they are bit-identical to k_excite.
+// step); after the pulse walk, k_excite_fix adds the pulse terms.  Together they equal k_excite up to the
+// order of the additions (~1e-16 relative).
 constexpr int kExw = 4;           // samples per lane
 constexpr int kExwHalo = 32;      // staged history, multiple of kExw, >= nlpf-1
 constexpr int kExwQ = (256 + kExwHalo) / kExw; // LDS row pitch (q = (m + halo) / 4)
@@ -501,14 +501,27 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
     }
 }
 
-// Second half of the split excitation: one wave per frame; frames without a pulse leave at
-// once.  For every pulse (sample p of the frame) lanes 0..NLPF-1 recompute the NLPF samples
-// p .. p+NLPF-1 that see it, from the complete e[] (all pulses, both neighbouring frames) in tap
-// order -- the same chain of FMAs as the pulse-free pass's two passes, so the two kernels together are
-// bit-identical to the one-pass form.  Samples covered by two pulses are written twice with the
-// same value.
+// Second half of the split excitation.  The pulse-free pass computed every sample with e = -noise in voiced
+// frames; what is missing is the pulse term of the ring buffer's FIR (excitation.rs:48-64):
+//     x[n] += a(g, p) * lpf_g[n - n_p]     for every pulse p of frame g with 0 <= n - n_p <= NLPF-1,
+// a = sqrt(pitch_of_curr_point at the pulse) -- ADDED to what the first pass left (one rounding later than in
+// tap order: ~1e-16 relative; the pulse positions and amplitudes are the exact ones).
+// One wave per frame, the frame's samples four per lane as in the first pass, so every sample has exactly one
+// owner: the wave of ITS frame applies the pulses of that frame and the tail of the previous frame's pulses
+// that reaches into it, in ascending time.  Overlapping pulses (periods below NLPF samples: the lf0 clamp
+// allows them) accumulate in registers, in order; no wave writes another frame's samples, so there is no
+// ordering between waves to keep.  A frame costs ONE memory round trip whatever its pulse count (round 2's
+// form recomputed the NLPF samples behind every pulse from a rebuilt window of e: NLPF^2 multiply-adds and a
+// round trip per pulse, 3.0 ms alone on config 2 and the kernel the vocoder waited for).  Frames that no
+// pulse reaches leave without touching memory; of the others only the lanes a pulse reaches load and store.
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 constexpr int kFixFrames = 8;
-#define JB_FIX_UNROLL 8 // (a pragma operand must be a literal)
 
 template <int NLPF>
 __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
@@ -520,136 +533,164 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     const uint64_t base = u->frame_off;
     const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
     constexpr int H = NLPF - 1;
-    static_assert(2 * H + 1 <= 64, "window must fit one wave");
-    const int anti = H / 2;
-    const long N = (long)T * (long)fp;
-    __shared__ double es_s[4][2 * H + 1]; // e[p-H .. p+H] of the current pulse
-    __shared__ double tp_s[4][3][NLPF];   // taps of frames fr-1, fr, fr+1
-    double *es = es_s[wv];
-    double(*tp3)[NLPF] = tp_s[wv];
-    // A wave walks kFixFrames frames, frame index = (block * kFixFrames + jf) * 4 + wave (most leave at
-    // once: 8x fewer workgroups for the dispatcher).  What decides whether a frame has work -- its pulse
-    // mask words -- is fetched for all of them in ONE request (lane = frame x word), where the loop used to
-    // pay a round trip for the voiced flag and another for the mask of every frame: the kernel's time is
-    // (waves in flight) x (round trips per wave), beside the resident GV kernel with a quarter of the waves.
+    __shared__ double tap_s[4][2][NLPF]; // taps of the previous frame [0] and of this one [1]
+    double(*tap2)[NLPF] = tap_s[wv];
+    // A wave walks kFixFrames frames, frame index = (block * kFixFrames + jf) * 4 + wave.  What decides whether a
+    // frame has work -- the voiced flags and pulse mask words of the frame and of its predecessor -- is fetched
+    // for all of them in ONE request: lanes 0..31 = (frame jf, word q) of the frame itself, lanes 32..63 the same
+    // of the frame before it.  (The masks of unvoiced frames are never written: gated by the flags.)
+    static_assert(kFixFrames * 4 <= 32, "one lane per (frame, mask word), twice");
     unsigned long long mword = 0ull;
-    uint32_t vfl = 0; // voiced flag of frame jf in lane jf (the masks of unvoiced frames are never written)
+    uint32_t vfl = 0;
     {
-        const uint32_t frv = (blockIdx.x * (uint32_t)kFixFrames + (uint32_t)lane) * 4u + (uint32_t)wv;
-        if (lane < kFixFrames && frv < T)
-            vfl = vd.voiced[base + frv];
-    }
-    {
-        const int jf = lane / 4, q = lane & 3; // up to four mask words per frame (kFixFrames * 4 <= 64)
-        const uint32_t frl = (blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv;
-        if (jf < kFixFrames && q < nblk && frl < T)
-            mword = vd.pmask[(base + frl) * (uint64_t)nblk + (uint64_t)q];
-    }
-    static_assert(kFixFrames * 4 <= 64, "one lane per (frame, mask word)");
-    const bool wide = nblk > 4; // (fperiod > 4 * bs: the words beyond the fourth are fetched in the loop)
-    for (int jf = 0; jf < kFixFrames; jf++) {
-        const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
-            (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
-        if (fr >= T)
-            break;
-        const uint64_t f = base + fr;
-        if (__builtin_amdgcn_readlane((int)vfl, jf) == 0)
-            continue;
-        unsigned long long any = 0ull;
-        for (int q = 0; q < 4; q++) {
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, jf * 4 + q);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), jf * 4 + q);
-            any |= ((unsigned long long)hi << 32) | lo;
+        const int half = lane >> 5, jf = (lane & 31) / 4, q = lane & 3;
+        const long frl = (long)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv) - half;
+        if (frl >= 0 && frl < (long)T) {
+            if (q == 0)
+                vfl = vd.voiced[base + (uint64_t)frl];
+            if (q < nblk)
+                mword = vd.pmask[(base + (uint64_t)frl) * (uint64_t)nblk + (uint64_t)q];
         }
-        if (wide)
-            for (int q = 4; q < nblk; q++)
-                any |= vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
-        if (any == 0ull)
-            continue;
-        const long n0 = (long)fr * (long)fp;
-        // taps of the three frames a window can touch, parked at once: held in registers until the first window
-        // is staged they cost six VGPRs, and at 52 only ONE wave of this kernel fits a SIMD beside the resident
-        // GV kernel's two of 208 (at 48, two)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier(); // the previous frame's reads of tp3 are done
-        if (lane < NLPF) {
+    }
+    auto word_of = [&](int half, int jf, int q, uint64_t f) -> unsigned long long { // wave-uniform
+        if (q < 4) {
+            const int src = half * 32 + jf * 4 + q;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
+            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src);
+            return ((unsigned long long)hi << 32) | lo;
+        }
+        unsigned long long w = vd.pmask[f * (uint64_t)nblk + (uint64_t)q]; // frame periods above 4 blocks
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+    };
+    const int s0 = lane * kExw; // this lane's samples s0 .. s0+3 of the frame
+    const bool own = s0 < fp;
+    const int tail0 = fp - H; // first sample of the previous frame whose pulse reaches into this one
+    // pulses that reach frame jf, in ascending time: fn(position relative to the frame's first sample, 0 = of the
+    // previous frame / 1 = its own, sample index in the pulse's own frame); wave-uniform
+    auto each_pulse = [&](int jf, uint64_t f, bool vprev, bool vcur, auto fn) {
+        if (vprev)
+            for (int q = tail0 / bs; q < nblk; q++) {
+                unsigned long long w = word_of(1, jf, q, f - 1);
+                const int lo = tail0 - q * bs; // bits below `lo` of the first word: samples before the tail
+                if (lo > 0)
+                    w &= ~0ull << lo;
+                while (w) {
+                    const int j = __builtin_ctzll(w);
+                    w &= w - 1ull;
+                    fn(q * bs + j - fp, 0, q * bs + j);
+                }
+            }
+        if (vcur)
+            for (int q = 0; q < nblk; q++) {
+                unsigned long long w = word_of(0, jf, q, f);
+                while (w) {
+                    const int j = __builtin_ctzll(w);
+                    w &= w - 1ull;
+                    fn(q * bs + j, 1, q * bs + j);
+                }
+            }
+    };
+    // Frames in groups of kFixGroup: FIRST everything the group reads from memory is requested (taps, amplitude
+    // parameters, the samples of the lanes a pulse reaches), THEN the frames are worked off.  Frame after frame
+    // with a load -> add -> store chain each, a wave lived through nine dependent round trips (26 us; the kernel
+    // runs at full occupancy and was bound by exactly that).
+    constexpr int kFixGroup = 4;
+    static_assert(kFixFrames % kFixGroup == 0, "whole groups");
+    for (int j0 = 0; j0 < kFixFrames; j0 += kFixGroup) {
+        bool work[kFixGroup], touched[kFixGroup];
+        double tv[kFixGroup], pv[kFixGroup], x[kFixGroup][kExw];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const long ff = (long)fr - 1 + j;
-                tp3[j][lane] = (ff >= 0 && ff < (long)T) ? vd.lpf[(base + (uint64_t)ff) * (uint64_t)NLPF + lane] : 0.0;
-            }
-        }
-        for (int q = 0; q < nblk; q++) {
-            unsigned long long word;
-            if (q < 4) {
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, jf * 4 + q);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), jf * 4 + q);
-                word = ((unsigned long long)hi << 32) | lo;
-            } else {
-                word = vd.pmask[f * (uint64_t)nblk + (uint64_t)q];
-                // wave-uniform by construction; tell the compiler
-                word = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(word >> 32)) << 32) |
-                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)word);
-            }
-            while (word) {
-                const int j = __builtin_ctzll(word);
-                word &= word - 1ull;
-                const int p = q * bs + j;
-                // ---- e over the window m = p-H+lane (frame-relative), lanes 0..2H; the start value of
-                // the targets n = n0 + p + lane, lanes 0..H, in the same request ----
-                const long n = n0 + p + lane;
-                const bool tgt = lane <= H && n < N;
-                const double x0 = (tgt && n >= anti) ? vd.noise[n - anti] : 0.0;
-                double ev = 0.0;
-                if (lane <= 2 * H) {
-                    const int m = p - H + lane;
-                    const long g = n0 + m;
-                    const bool in = g >= 0 && g < N;
-                    // unconditional loads at clamped positions, selected afterwards (loads nested in
-                    // the edge / voicing tests would be waited for one after the other)
-                    const long gc = in ? g : n0;
-                    const int df = !in ? 0 : (m < 0 ? -1 : (m >= fp ? 1 : 0));
-                    const uint64_t ff = (uint64_t)((long)f + df);
-                    const int i = in ? m - df * fp : 0;
-                    const bool vo = vd.voiced[ff] != 0;
-                    const unsigned long long pm = vd.pmask[ff * (uint64_t)nblk + (uint64_t)(i / bs)];
-                    const double pinc = vd.pinc[ff], cur = vd.cur_start[ff], nv = vd.noise[gc];
-                    if (in && vo) {
-                        double pulse = 0.0;
-                        if ((pm >> (i % bs)) & 1ull)
-                            pulse = sqrt(fma((double)i, pinc, cur));
-                        ev = pulse - nv;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier(); // the previous pulse's reads of es[] are done
-                if (lane <= 2 * H)
-                    es[lane] = ev;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (tgt) {
-                    double x = x0;
-                    // (eight taps at a time: fully unrolled, the compiler fetches all operands first and
-                    // the kernel needs 52 VGPRs -- with 48 two of its waves fit a SIMD beside the resident
-                    // GV kernel's two of 208, with 52 one)
-#pragma unroll JB_FIX_UNROLL
-                    for (int k = 0; k < NLPF; k++) {
-                        const int ms = p + lane - k; // frame-relative source sample
-                        const int sel = ms < 0 ? 0 : (ms >= fp ? 2 : 1);
-                        x = fma(es[lane + H - k], tp3[sel][k], x);
-                    }
-                    const uint64_t o = base * (uint64_t)fp + (uint64_t)n;
-                    vd.xin[o] = x;
-                    if (vd.exc)
-                        vd.exc[o] = x;
+        for (int g = 0; g < kFixGroup; g++) {
+            const int jf = j0 + g;
+            const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
+            work[g] = touched[g] = false;
+            tv[g] = pv[g] = 0.0;
+#pragma unroll
+            for (int r = 0; r < kExw; r++)
+                x[g][r] = 0.0;
+            if (fr >= T)
+                continue;
+            const uint64_t f = base + fr;
+            const bool vcur = __builtin_amdgcn_readlane((int)vfl, jf * 4) != 0;
+            const bool vprev = fr > 0 && __builtin_amdgcn_readlane((int)vfl, 32 + jf * 4) != 0;
+            bool any_p = false, any_c = false, tch = false;
+            each_pulse(jf, f, vprev, vcur, [&](int p, int own_frame, int) {
+                any_p = any_p || !own_frame;
+                any_c = any_c || own_frame;
+                tch = tch || (s0 + kExw - 1 >= p && s0 <= p + H);
+            });
+            if (!any_p && !any_c)
+                continue;
+            work[g] = true;
+            touched[g] = tch && own;
+            {
+                // taps of the previous frame (lanes 0..31; only if one of its last H samples holds a pulse: one
+                // frame in eight) and of this one (lanes 32..63), lane = tap
+                const int hw = lane >> 5, k = lane & 31;
+                if (k < NLPF && (hw ? any_c : any_p))
+                    tv[g] = vd.lpf[(f - 1 + (uint64_t)hw) * (uint64_t)NLPF + (uint64_t)k];
+                // amplitude parameters: lanes 0,1 = cur_start, pinc of the previous frame; 2,3 = of this one
+                if (lane < 4 && ((lane >> 1) ? any_c : any_p)) {
+                    const uint64_t ff = f - 1 + (uint64_t)(lane >> 1);
+                    pv[g] = (lane & 1) ? vd.pinc[ff] : vd.cur_start[ff];
                 }
             }
+            if (touched[g]) {
+                const uint64_t o = f * (uint64_t)fp + (uint64_t)s0;
+                const double2 xa = *reinterpret_cast<const double2 *>(vd.xin + o);
+                const double2 xb = *reinterpret_cast<const double2 *>(vd.xin + o + 2);
+                x[g][0] = xa.x;
+                x[g][1] = xa.y;
+                x[g][2] = xb.x;
+                x[g][3] = xb.y;
+            }
         }
-        // the next frame with pulses overwrites tp3: this frame's reads of it are done
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    } // frames of this wave
+#pragma unroll
+        for (int g = 0; g < kFixGroup; g++) {
+            if (!work[g])
+                continue;
+            const int jf = j0 + g;
+            const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
+                (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
+            const uint64_t f = base + fr;
+            const bool vcur = __builtin_amdgcn_readlane((int)vfl, jf * 4) != 0;
+            const bool vprev = fr > 0 && __builtin_amdgcn_readlane((int)vfl, 32 + jf * 4) != 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier(); // the previous frame's reads of tap2 are done
+            if ((lane & 31) < NLPF)
+                tap2[lane >> 5][lane & 31] = tv[g];
+            const double cs_p = readlane_f64(pv[g], 0), pi_p = readlane_f64(pv[g], 1);
+            const double cs_c = readlane_f64(pv[g], 2), pi_c = readlane_f64(pv[g], 3);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // the pulse terms, in ascending time
+            each_pulse(jf, f, vprev, vcur, [&](int p, int gsel, int i) {
+                // voiced branch of Excitation::get (excitation.rs:73-81): pulse = sqrt(pitch_of_curr_point), which
+                // has advanced by i increments when sample i of its frame is drawn
+                const double amp = sqrt(gsel ? fma((double)i, pi_c, cs_c) : fma((double)i, pi_p, cs_p));
+#pragma unroll
+                for (int r = 0; r < kExw; r++) {
+                    const int k = s0 + r - p;
+                    const bool in = k >= 0 && k <= H;
+                    const double tk = tap2[gsel][in ? k : 0];
+                    if (in)
+                        x[g][r] = fma(amp, tk, x[g][r]);
+                }
+            });
+            if (touched[g]) {
+                const uint64_t o = f * (uint64_t)fp + (uint64_t)s0;
+                *reinterpret_cast<double2 *>(vd.xin + o) = make_double2(x[g][0], x[g][1]);
+                *reinterpret_cast<double2 *>(vd.xin + o + 2) = make_double2(x[g][2], x[g][3]);
+                if (vd.exc) {
+                    *reinterpret_cast<double2 *>(vd.exc + o) = make_double2(x[g][0], x[g][1]);
+                    *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[g][2], x[g][3]);
+                }
+            }
+        }
+    } // groups of frames
 }
 
 // --------------------------------------------------------------------------
@@ -665,12 +706,6 @@ __device__ __forceinline__ double dpp_f64(double v)
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
               DPP_ROW_SHR8 = 0x118, DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142;
 
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
-}
 
 // PCM sink of the reference's callers (examples/is-bonsai/main.rs:44-48, hound 16-bit WAV):
 // value.min(i16::MAX).max(i16::MIN) as i16 -- clamp, then truncate toward zero.
