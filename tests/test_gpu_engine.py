@@ -323,3 +323,25 @@ def test_batch_invariant_option_gives_the_same_bits_alone_and_in_any_batch():
     assert np.array_equal(e.generator(SAMPLE_SENTENCE_2).generate_all(), alone)
     k = e.clone()
     assert k.condition.get_batch_invariant()
+
+
+def test_examples_run(tmp_path):
+    """examples/is_bonsai.py and examples/genji.py (the reference's two examples) run end to end and write
+    16-bit mono WAV files of the expected lengths."""
+    import subprocess
+    import sys
+    import wave
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    for script, n_expected in (("is_bonsai.py", 100800), ("genji.py", None)):
+        out = tmp_path / (script + ".wav")
+        args = [sys.executable, str(root / "examples" / script)] + ([str(VOICE)] if script == "is_bonsai.py" else []) + [str(out)]
+        r = subprocess.run(args, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-1500:]
+        with wave.open(str(out), "rb") as w:
+            assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 48000)
+            assert w.getnframes() % 240 == 0 and w.getnframes() > 0
+            if n_expected:
+                assert w.getnframes() == n_expected
+        assert "samples in total" in r.stdout
