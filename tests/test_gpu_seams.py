@@ -159,3 +159,27 @@ def test_mlpg_only_batch_has_no_pcm(oracle_voice, vi):
         with pytest.raises(J.JbError):
             b.pcm(0)
         assert b.device_pcm()[0] is None
+
+
+def test_tracks_entry_with_stage_nonzero_and_lsp_postfilter():
+    """jb_vocode_tracks_batch for a Stage::NonZero vocoder (spectrum = [gain, LSP...], MGLSA cascade;
+    vocoder/mod.rs:90-107,142-176): the tracks of a state-level batch, handed back through the tracks entry,
+    give that batch's audio (same kernels behind the frame prologue; the conversion from the LSP track is
+    ill-conditioned, so the comparison is the library against itself)."""
+    from tests.test_gpu_stage import stable_utterance, stage_voice
+
+    eng = J.Engine.load([VOICE])
+    tab, vi0 = synth.VoiceTables(eng), eng.voice_info()
+    for stage, log_gain, beta in ((2, False, 0.0), (3, False, 0.2)):
+        v2 = stage_voice(vi0, stage, log_gain, beta)
+        # random LSP sets can give an unstable filter: stable_utterance picks seeds whose output stays bounded
+        utts = [stable_utterance(tab, vi0, v2, T, 900 + 10 * i, stage, log_gain, beta) for i, T in enumerate((300, 1100))]
+        with J.Batch(v2, utts, keep_tracks=True) as b:
+            b.run()
+            b.sync()
+            want = [b.pcm(i) for i in range(2)]
+            trk = [[b.track(i, s) for s in range(3)] for i in range(2)]
+        got = J.vocode_tracks_batch(v2, [J.TrackUtterance(*t) for t in trk])
+        for g, w in zip(got, want):
+            assert len(g) == len(w) and np.all(np.isfinite(g))
+            assert rel_rms(g, w) <= 1e-10, (stage, rel_rms(g, w))
