@@ -30,11 +30,23 @@ namespace jb {
 
 // --------------------------------------------------------------------------
 // A1/A2 in two steps.  The MSD flag is constant within a state, so run boundaries,
-// compaction offsets and boundary distances are decided per STATE (serial over S,
-// one lane per utterance: S ~ 7.5k for 128 s), then expanded per FRAME in parallel.
-// One wave per utterance: 64 states are loaded per instruction (coalesced); the walk itself
-// (run starts, compaction offsets) is inherently serial but runs on scalars extracted with
-// ballot/readlane, ~15 instructions per state instead of three dependent global loads.
+// compaction offsets and boundary distances are decided per STATE, then expanded per FRAME in parallel.
+// One wave per utterance, 64 states per step.  The walk of mask.rs:20-82 is serial as written -- start
+// frame, compaction offset, start and end of the voiced run a state lies in, where a state of duration 0
+// is invisible to its neighbours -- but every one of its values is a prefix sum or "the value at the nearest
+// lane with a property": wave scans, ballots and one bpermute per value, ~25 us for a 128 s utterance (7.5 k
+// states) where the state-by-state walk on readlane scalars took 1.4-2 ms at the head of the LF0 chain.
+__device__ __forceinline__ uint32_t ps_scan_incl(uint32_t v, int lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o)
+            v += u;
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, int si)
 {
     if ((int)blockIdx.x >= bd.B)
@@ -46,6 +58,8 @@ __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, i
     const uint32_t S = up->S;
     const uint32_t *dur = up->dur;
     const uint64_t sb = up->state_off;
+    const unsigned long long below = (1ull << lane) - 1ull;           // lanes < lane
+    const unsigned long long upto = below | (1ull << lane);           // lanes <= lane
     uint32_t t = 0, k = 0, gl = 0, run_start = 0, nrun = 0;
     bool prev_v = false;
     // forward: state start frame, compaction offset, start of the voiced run
@@ -57,43 +71,44 @@ __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, i
         const double msd = (ok && st.msd) ? st.msd[s] : 1.7976931348623157e308;
         const bool v = ok && msd > st.msd_threshold;
         const bool g = v && st.gv_switch && st.gv_switch[s];
-        const unsigned long long vm = __ballot(v), gm = __ballot(g);
-        uint32_t my_start = 0, my_vpre = 0, my_rstart = 0;
-        const uint32_t cnt = S - s0 < 64u ? S - s0 : 64u;
-        for (uint32_t u = 0; u < cnt; u++) {
-            const uint32_t du = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)u);
-            const bool vu = (vm >> u) & 1ull;
-            if (vu && !prev_v) {
-                run_start = t;
-                // compact list of run starts for the pulse scheduler (a zero-length voiced
-                // state may repeat an entry; k_pulse tolerates duplicates)
-                if (lane == 0)
-                    sd.run_list[sb + nrun] = t;
-                nrun++;
-            }
-            if ((uint32_t)lane == u) {
-                my_start = t;
-                my_vpre = k;
-                my_rstart = run_start;
-            }
-            if (vu) {
-                k += du;
-                if ((gm >> u) & 1ull)
-                    gl += du;
-            }
-            if (du > 0)
-                prev_v = vu;
-            t += du;
-        }
+        const uint32_t dv = v ? d : 0u;
+        const uint32_t it = ps_scan_incl(d, lane), ik = ps_scan_incl(dv, lane);
+        uint32_t gs = g ? d : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            gs += (uint32_t)__shfl_xor((int)gs, o);
+        const uint32_t my_start = t + it - d, my_vpre = k + ik - dv;
+        // voicing of the nearest earlier state that has frames (a state without frames leaves prev_v alone)
+        const unsigned long long dm = __ballot(d > 0), vm = __ballot(v);
+        const unsigned long long lo = dm & below;
+        const bool pv = lo ? ((vm >> (63 - __clzll((long long)lo))) & 1ull) != 0 : prev_v;
+        const bool isstart = v && !pv;
+        const unsigned long long sm = __ballot(isstart);
+        // compact list of run starts for the pulse scheduler (a zero-length voiced state may repeat an
+        // entry; k_pulse_queue tolerates duplicates)
+        if (isstart)
+            sd.run_list[sb + nrun + (uint32_t)__popcll(sm & below)] = my_start;
+        // start of the run the state lies in: the nearest run start at or before it
+        const unsigned long long sl = sm & upto;
+        const int src = sl ? 63 - __clzll((long long)sl) : 0;
+        const uint32_t from = (uint32_t)__shfl((int)my_start, src);
+        const uint32_t my_rstart = sl ? from : run_start;
         if (ok) {
             sd.s_start[sb + s] = my_start;
             sd.s_vpre[sb + s] = my_vpre;
             sd.s_rstart[sb + s] = my_rstart;
             sd.s_voiced[sb + s] = v;
         }
+        t += (uint32_t)__shfl((int)it, 63);
+        k += (uint32_t)__shfl((int)ik, 63);
+        gl += gs;
+        nrun += (uint32_t)__popcll(sm);
+        run_start = (uint32_t)__shfl((int)my_rstart, 63);
+        if (dm)
+            prev_v = ((vm >> (63 - __clzll((long long)dm))) & 1ull) != 0;
     }
-    // backward: last frame of the voiced run (mask.rs:66-79)
-    uint32_t run_end = 0, tt = t;
+    // backward: last frame of the voiced run (mask.rs:66-79) -- the nearest run end at or after the state
+    uint32_t run_end = 0;
     bool next_v = false;
     const uint32_t nch = (S + 63) / 64;
     for (uint32_t c = nch; c-- > 0;) {
@@ -102,22 +117,22 @@ __global__ __launch_bounds__(64) void k_prep_states(BatchDev bd, StreamDev sd, i
         const bool ok = s < S;
         const uint32_t d = ok ? dur[s] : 0u;
         const bool v = ok && sd.s_voiced[sb + s];
-        const unsigned long long vm = __ballot(v);
-        uint32_t my_rend = 0;
-        const uint32_t cnt = S - s0 < 64u ? S - s0 : 64u;
-        for (uint32_t u = cnt; u-- > 0;) {
-            const uint32_t du = (uint32_t)__builtin_amdgcn_readlane((int)d, (int)u);
-            tt -= du;
-            const bool vu = (vm >> u) & 1ull;
-            if (vu && !next_v)
-                run_end = tt + du - 1;
-            if ((uint32_t)lane == u)
-                my_rend = run_end;
-            if (du > 0)
-                next_v = vu;
-        }
+        const uint32_t my_start = ok ? sd.s_start[sb + s] : 0u;
+        const unsigned long long dm = __ballot(d > 0), vm = __ballot(v);
+        const unsigned long long hi = dm & ~upto; // lanes > lane
+        const bool nv = hi ? ((vm >> __builtin_ctzll(hi)) & 1ull) != 0 : next_v;
+        const bool isend = v && !nv;
+        const unsigned long long em = __ballot(isend);
+        const uint32_t tend = my_start + d - 1u; // (wraps for a state without frames at frame 0, as the walk's does)
+        const unsigned long long eh = em & ~below; // lanes >= lane
+        const int src = eh ? __builtin_ctzll(eh) : 0;
+        const uint32_t from = (uint32_t)__shfl((int)tend, src);
+        const uint32_t my_rend = eh ? from : run_end;
         if (ok)
             sd.s_rend[sb + s] = my_rend;
+        run_end = (uint32_t)__shfl((int)my_rend, 0);
+        if (dm)
+            next_v = ((vm >> __builtin_ctzll(dm)) & 1ull) != 0;
     }
     if (lane == 0) {
         sd.Tv[b] = k;

@@ -9,11 +9,11 @@ d = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/kstats"
 f = glob.glob(d + "/**/k_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# the last step starts at the last k_prep_states_dense / k_prep_states launch group
-voc = [i for i, r in enumerate(rows) if "k_vocoder_l" in r["Kernel_Name"]]
-if len(voc) < 2:
+# a step starts with its first k_prep_states* launch (one k_pitch per step tells the steps apart)
+pitch = [i for i, r in enumerate(rows) if "k_pitch" in r["Kernel_Name"]]
+if len(pitch) < 2:
     raise SystemExit("need two steps in the trace")
-lo = voc[-2] + 1
+lo = next(i for i in range(pitch[-2] + 1, len(rows)) if "k_prep_states" in rows[i]["Kernel_Name"])
 t0 = int(rows[lo]["Start_Timestamp"])
 for r in rows[lo:]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
