@@ -1071,7 +1071,13 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
-    vd.ckpt_frames = ch >= 2 * kVocCkptFrames ? kVocCkptFrames : (ch >= kVocCkptFramesShort + 12 ? kVocCkptFramesShort : 0);
+    // the checkpoint a failed chunk is first recomputed to (finish_verify): 48 frames into chunks of 96 and more, 24 into
+    // chunks of 36 and more, 16 into chunks of 24 and more (a single 128 s utterance, 799 chunks of 32 frames: all six
+    // failing hand-offs settle there and the redo is one round of 16 frames, 10.2 -> 9.2 ms per call; 8 frames into
+    // 16-frame chunks settle three in four but the rest still take their rounds: same time, not done)
+    vd.ckpt_frames = ch >= 2 * kVocCkptFrames ? kVocCkptFrames
+                     : ch >= kVocCkptFramesShort + 12 ? kVocCkptFramesShort
+                     : ch >= kVocCkptFramesTiny + 8 ? kVocCkptFramesTiny : 0;
     work.clear();
     const int stride = vd.state_stride;
     for (int i = 0; i < B; i++) {
@@ -1120,7 +1126,7 @@ int Batch::build_work(const jb_batch_opts *opts)
             // redo round lasts as long as its longest item: when only chunks of twice the checkpoint had one, the
             // short last chunk of an utterance -- up to 95 frames recomputed to their end -- made the round of a
             // batch of distinct utterances 5.7 ms instead of the 2.9 ms of 48 frames.)
-            const uint32_t need = vd.ckpt_frames + 12;
+            const uint32_t need = vd.ckpt_frames + (vd.ckpt_frames < kVocCkptFramesShort ? 8u : 12u);
             w.save_ckpt = (!first && vd.ckpt_frames && w.t_end - w.t_out >= need) ? ckpt_state + (size_t)k * stride
                                                                                    : nullptr;
         }

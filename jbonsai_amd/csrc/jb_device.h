@@ -168,7 +168,7 @@ struct VocWork {
 // A failing chunk is first recomputed only up to VocDev::ckpt_frames frames past its start; if the
 // recomputed state meets the checkpoint the original chunk left there, the rest of the chunk stands.
 // 48 frames for chunks of 96 frames and more, 24 for chunks of 40 to 95, none below.
-constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24;
+constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16;
 
 struct BatchDev {
     int B;

@@ -218,6 +218,16 @@ def test_partial_redo_at_checkpoint(ctx_long, have_gpu):
         print(kern, "hand-offs failing", info["n_redo"], "settled at checkpoint", n_part, "to the end", n_full,
               "rel RMS vs serial", e)
         assert e <= 1e-9
+    # the shorter checkpoints: 24 frames into chunks of 36-95 frames, 16 into chunks of 24-35 (a few long utterances)
+    for chunk in (40, 32):
+        with J.Batch(vi, [u], chunk_frames=chunk, warmup_frames=10, verify_tol=1e-9, kernel="wave") as b:
+            b.run()
+            b.sync()
+            info, (n_part, n_full) = b.info(), b.redo_stats()
+            e = rel_rms(b.pcm(0), ser[0])
+        print("chunk", chunk, "hand-offs failing", info["n_redo"], "settled at checkpoint", n_part, "to the end", n_full,
+              "rel RMS vs serial", e)
+        assert info["n_redo"] >= 5 and n_part >= 1 and n_part + n_full == info["n_redo"] and e <= 1e-9
     # 32-frame warm-up, the default-like case: whatever fails, the result stays certified
     with J.Batch(vi, [u], chunk_frames=136, warmup_frames=32, kernel="triple") as b:
         b.run()
