@@ -539,7 +539,15 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     // frame has work -- the voiced flags and pulse mask words of the frame and of its predecessor -- is fetched
     // for all of them in ONE request: lanes 0..31 = (frame jf, word q) of the frame itself, lanes 32..63 the same
     // of the frame before it.  (The masks of unvoiced frames are never written: gated by the flags.)
+    // The kernel's scalar unit is what it is bound by (one per CU: 182 scalar instructions per frame took 2.2 of
+    // its 2.5 ms when every frame's eight words were fetched with readlane pairs and scanned, twice): so the words
+    // are gated and trimmed in the lanes that loaded them -- a word counts if its frame is voiced, the previous
+    // frame's only from the first sample whose pulse reaches into this frame -- and ONE ballot says which of the
+    // 64 are non-zero; the per-frame loops then visit exactly the words that hold a pulse.
     static_assert(kFixFrames * 4 <= 32, "one lane per (frame, mask word), twice");
+    const int s0 = lane * kExw; // this lane's samples s0 .. s0+3 of the frame
+    const bool own = s0 < fp;
+    const int tail0 = fp - H; // first sample of the previous frame whose pulse reaches into this one
     unsigned long long mword = 0ull;
     uint32_t vfl = 0;
     {
@@ -551,45 +559,40 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             if (q < nblk)
                 mword = vd.pmask[(base + (uint64_t)frl) * (uint64_t)nblk + (uint64_t)q];
         }
-    }
-    auto word_of = [&](int half, int jf, int q, uint64_t f) -> unsigned long long { // wave-uniform
-        if (q < 4) {
-            const int src = half * 32 + jf * 4 + q;
-            const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
-            const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src);
-            return ((unsigned long long)hi << 32) | lo;
+        // the flag of the quad's first lane for all four words of the frame (quad_perm [0,0,0,0])
+        const uint32_t vq = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vfl, 0x00, 0xf, 0xf, true);
+        if (!vq)
+            mword = 0ull;
+        if (half) {
+            const int qt = tail0 / bs, lo = tail0 - qt * bs;
+            if (q < qt)
+                mword = 0ull;
+            else if (q == qt && lo > 0)
+                mword &= ~0ull << lo;
         }
-        unsigned long long w = vd.pmask[f * (uint64_t)nblk + (uint64_t)q]; // frame periods above 4 blocks
-        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
-               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)w);
+    }
+    const unsigned long long nz = __ballot(mword != 0ull);
+    // words of frame jf that hold a pulse reaching it: bits 0..3 = words of the previous frame, 4..7 = its own
+    auto words_of = [&](int jf) -> uint32_t {
+        return (uint32_t)((nz >> (32 + 4 * jf)) & 0xFull) | ((uint32_t)((nz >> (4 * jf)) & 0xFull) << 4);
     };
-    const int s0 = lane * kExw; // this lane's samples s0 .. s0+3 of the frame
-    const bool own = s0 < fp;
-    const int tail0 = fp - H; // first sample of the previous frame whose pulse reaches into this one
     // pulses that reach frame jf, in ascending time: fn(position relative to the frame's first sample, 0 = of the
     // previous frame / 1 = its own, sample index in the pulse's own frame); wave-uniform
-    auto each_pulse = [&](int jf, uint64_t f, bool vprev, bool vcur, auto fn) {
-        if (vprev)
-            for (int q = tail0 / bs; q < nblk; q++) {
-                unsigned long long w = word_of(1, jf, q, f - 1);
-                const int lo = tail0 - q * bs; // bits below `lo` of the first word: samples before the tail
-                if (lo > 0)
-                    w &= ~0ull << lo;
-                while (w) {
-                    const int j = __builtin_ctzll(w);
-                    w &= w - 1ull;
-                    fn(q * bs + j - fp, 0, q * bs + j);
-                }
+    auto each_pulse = [&](int jf, uint32_t m8, auto fn) {
+        while (m8) {
+            const int idx = __builtin_ctz(m8);
+            m8 &= m8 - 1u;
+            const int ownf = idx >> 2, q = idx & 3;
+            const int src = (ownf ? 0 : 32) + jf * 4 + q;
+            const uint32_t wl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mword, src);
+            const uint32_t wh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mword >> 32), src);
+            unsigned long long w = ((unsigned long long)wh << 32) | wl;
+            while (w) {
+                const int j = __builtin_ctzll(w);
+                w &= w - 1ull;
+                fn(ownf ? q * bs + j : q * bs + j - fp, ownf, q * bs + j);
             }
-        if (vcur)
-            for (int q = 0; q < nblk; q++) {
-                unsigned long long w = word_of(0, jf, q, f);
-                while (w) {
-                    const int j = __builtin_ctzll(w);
-                    w &= w - 1ull;
-                    fn(q * bs + j, 1, q * bs + j);
-                }
-            }
+        }
     };
     // Frames in groups of kFixGroup: FIRST everything the group reads from memory is requested (taps, amplitude
     // parameters, the samples of the lanes a pulse reaches), THEN the frames are worked off.  Frame after frame
@@ -613,16 +616,12 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             if (fr >= T)
                 continue;
             const uint64_t f = base + fr;
-            const bool vcur = __builtin_amdgcn_readlane((int)vfl, jf * 4) != 0;
-            const bool vprev = fr > 0 && __builtin_amdgcn_readlane((int)vfl, 32 + jf * 4) != 0;
-            bool any_p = false, any_c = false, tch = false;
-            each_pulse(jf, f, vprev, vcur, [&](int p, int own_frame, int) {
-                any_p = any_p || !own_frame;
-                any_c = any_c || own_frame;
-                tch = tch || (s0 + kExw - 1 >= p && s0 <= p + H);
-            });
-            if (!any_p && !any_c)
+            const uint32_t m8 = words_of(jf);
+            if (!m8)
                 continue;
+            const bool any_p = (m8 & 0xFu) != 0, any_c = (m8 >> 4) != 0;
+            bool tch = false;
+            each_pulse(jf, m8, [&](int p, int, int) { tch = tch || (s0 + kExw - 1 >= p && s0 <= p + H); });
             work[g] = true;
             touched[g] = tch && own;
             {
@@ -655,8 +654,6 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
             const uint64_t f = base + fr;
-            const bool vcur = __builtin_amdgcn_readlane((int)vfl, jf * 4) != 0;
-            const bool vprev = fr > 0 && __builtin_amdgcn_readlane((int)vfl, 32 + jf * 4) != 0;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier(); // the previous frame's reads of tap2 are done
             if ((lane & 31) < NLPF)
@@ -667,7 +664,7 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             // the pulse terms, in ascending time
-            each_pulse(jf, f, vprev, vcur, [&](int p, int gsel, int i) {
+            each_pulse(jf, words_of(jf), [&](int p, int gsel, int i) {
                 // voiced branch of Excitation::get (excitation.rs:73-81): pulse = sqrt(pitch_of_curr_point), which
                 // has advanced by i increments when sample i of its frame is drawn
                 const double amp = sqrt(gsel ? fma((double)i, pi_c, cs_c) : fma((double)i, pi_p, cs_p));
@@ -1421,7 +1418,10 @@ hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
 // the split form (k_excite_noise4 + k_excite_fix) is built for these shapes; everything else takes k_excite
 bool excite_is_split(const VocDev &vd)
 {
-    return vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo && (vd.nlpf == 31 || vd.nlpf == 15);
+    // (fperiod = 4m with m <= 64: one of m, 2m, 4m is the block size, so a frame has at most four mask words --
+    // what k_excite_fix holds per frame; checked all the same)
+    return vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo && (vd.nlpf == 31 || vd.nlpf == 15) &&
+           vd.nblk <= 4;
 }
 
 hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
