@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <numeric>
 #include <thread>
 
@@ -244,6 +245,32 @@ void stream_release(int device, hipStream_t st)
     }
     hipStreamDestroy(st);
 }
+
+// CU-masked streams (jb_batch_opts.mlpg_cus_per_xcd) are kept too, per (device, CUs per XCD, side), and NEVER
+// destroyed: hipStreamDestroy of a stream made by hipExtStreamCreateWithCUMask does not return every time on
+// this stack (ROCm 7.2: the close of a partitioned batch hung in it in 7 of 14 runs of one test; the work on the
+// stream had long finished).  A process uses a handful of splits at most; the queues die with it.
+std::map<std::tuple<int, int, int>, std::vector<hipStream_t>> g_masked_streams; // guarded by g_pool_mu
+
+hipError_t masked_stream_acquire(int device, int cus, int side, const uint32_t *mask, hipStream_t *st)
+{
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto &v = g_masked_streams[std::make_tuple(device, cus, side)];
+        if (!v.empty()) {
+            *st = v.back();
+            v.pop_back();
+            return hipSuccess;
+        }
+    }
+    return hipExtStreamCreateWithCUMask(st, 8, mask);
+}
+
+void masked_stream_release(int device, int cus, int side, hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_masked_streams[std::make_tuple(device, cus, side)].push_back(st);
+}
 } // namespace
 
 void release_cached_memory()
@@ -308,17 +335,19 @@ Batch::~Batch()
     for (hipEvent_t ev : {ev_mlpg_done, ev_voc_done})
         if (ev)
             hipEventDestroy(ev);
-    auto drop = [&](hipStream_t st) {
+    auto drop = [&](hipStream_t st, int side) {
         if (cu_split)
-            hipStreamDestroy(st); // CU-masked streams are not pooled
+            masked_stream_release(device, cu_split, side, st);
         else
             stream_release(device, st);
     };
-    for (hipStream_t st : {stream_lf0, stream_lpf, stream_voc})
+    for (hipStream_t st : {stream_lf0, stream_lpf})
         if (st && st != stream)
-            drop(st);
+            drop(st, 0);
+    if (stream_voc && stream_voc != stream)
+        drop(stream_voc, 1);
     if (stream)
-        drop(stream);
+        drop(stream, 0);
 }
 
 template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
@@ -695,7 +724,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     for (uint32_t i = 0; i < 256; i++)
         ((i / 8 >= 32 - b->cu_split) ? mask_pg : mask_voc)[i / 32] |= 1u << (i % 32);
     auto mkstream = [&](hipStream_t *st, const uint32_t *mask) {
-        return b->cu_split ? hipExtStreamCreateWithCUMask(st, 8, mask) : stream_acquire(b->device, st);
+        return b->cu_split ? masked_stream_acquire(b->device, b->cu_split, 0, mask, st) : stream_acquire(b->device, st);
     };
     e = mkstream(&b->stream, mask_pg);
     if (e != hipSuccess)
@@ -708,7 +737,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                (e = mkstream(&b->stream_lpf, mask_pg)) != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
     if (b->cu_split) {
-        if ((e = hipExtStreamCreateWithCUMask(&b->stream_voc, 8, mask_voc)) != hipSuccess)
+        if ((e = masked_stream_acquire(b->device, b->cu_split, 1, mask_voc, &b->stream_voc)) != hipSuccess)
             return hip_fail(e, "hipExtStreamCreateWithCUMask");
     } else {
         b->stream_voc = b->stream;
