@@ -1030,10 +1030,9 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
     double d[NS][M + 1];
     double u[NS]; // slot inputs (d22[stage])
     double gain = 1.0;
-    double e11[6], e12[6]; // df1 state (every lane of the triple keeps an identical copy)
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-        e11[i] = e12[i] = 0.0;
+    // df1 state, spread over the triple like df2's: this lane's two stages (d11, pt1 of stages s0+1, s0+2) and the
+    // input of its first one (pt1[s0]: the lead lane's is pt1[0], the others' comes from the lane before)
+    double e11[NS] = {0.0, 0.0}, e12[NS] = {0.0, 0.0}, ein = 0.0;
 #pragma unroll
     for (int q = 0; q < NS; q++) {
         u[q] = 0.0;
@@ -1056,10 +1055,14 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             }
         }
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            e11[i] = sp[64 * TPLW + 64 + i];
-            e12[i] = sp[64 * TPLW + 70 + i];
+        for (int q = 0; q < NS; q++) {
+            const int st = s0 + 1 + q; // df1 stage 1..5 (k_vocoder's dump: d11[i] at +64+i, pt1[i] at +70+i)
+            if (st <= kPade) {
+                e11[q] = sp[64 * TPLW + 64 + st];
+                e12[q] = sp[64 * TPLW + 70 + st];
+            }
         }
+        ein = sp[64 * TPLW + 70 + s0];
     }
     auto save_state = [&](double *sp) {
 #pragma unroll
@@ -1072,12 +1075,17 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                     sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW] = d[q][j];
             }
         }
-        if (pos == 0) {
 #pragma unroll
-            for (int i = 0; i < 6; i++) {
-                sp[64 * TPLW + 64 + i] = e11[i];
-                sp[64 * TPLW + 70 + i] = e12[i];
+        for (int q = 0; q < NS; q++) {
+            const int st = s0 + 1 + q;
+            if (st <= kPade) {
+                sp[64 * TPLW + 64 + st] = e11[q];
+                sp[64 * TPLW + 70 + st] = e12[q];
             }
+        }
+        if (pos == 0) {
+            sp[64 * TPLW + 64] = 0.0; // d11[0] is never written by the recursion
+            sp[64 * TPLW + 70] = ein; // pt1[0]
         }
     };
 
@@ -1166,21 +1174,24 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                     asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(xn) : "v"(xq + nx) : "memory");
             }
             const double fi = (double)i;
-            // ---- V6 df1 (mlsa.rs:54-66): every lane runs it, the lead lane's copy is kept ----
+            // ---- V6 df1 (mlsa.rs:54-66), its five stages over the triple like df2's (every stage reads the
+            // PREVIOUS sample's output of the stage before it): this lane's second stage first, then its first.
+            // The alternating sum is folded to the lead lane here (it is pt1[0], the first stage's next input);
+            // the plain sum joins df2's alternating one below, where both are added to the same value.
+            double db1;
             {
                 const double2 c1p = cc[0][ci];
                 const double c1 = fma(fi, c1p.y, c1p.x);
-                double out = 0.0;
-#pragma unroll
-                for (int ii = 5; ii >= 1; ii--) {
-                    e11[ii] = fma(iaa, e12[ii - 1], a * e11[ii]);
-                    e12[ii] = e11[ii] * c1;
-                    // x +/- P*d12 and out + P*d12 as FMAs (one rounding less than mul + add each)
-                    x = fma((ii & 1) ? kPPade[ii] : -kPPade[ii], e12[ii], x);
-                    out = fma(kPPade[ii], e12[ii], out);
-                }
-                e12[0] = x;
-                x += out;
+                e11[1] = fma(iaa, e12[0], a * e11[1]);
+                e11[0] = fma(iaa, ein, a * e11[0]);
+                e12[1] = e11[1] * c1;
+                e12[0] = e11[0] * c1;
+                const double dv0 = w0 * e12[0], dv1 = w1 * e12[1];
+                const double da = dv0 - dv1;
+                db1 = dv0 + dv1;
+                x += da + dpp_f64<DPP_WAVE_SHL1>(da + dpp_f64<DPP_WAVE_SHL1>(da)); // pt1[0] (valid on the lead lane)
+                const double eprev = dpp_f64<DPP_WAVE_SHR1>(e12[1]);
+                ein = pos == 0 ? x : eprev;
             }
             // ---- V7 df2: fir() of this lane's stage slots, taps outermost (mlsa.rs:127-163) ----
             double r[NS], y[NS];
@@ -1261,7 +1272,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
 #undef JB_LDS_RD
             // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, gathered on the lead lane ----
             const double v0 = w0 * y[0], v1 = w1 * y[1];
-            const double sb = v0 + v1, sa = v0 - v1;
+            const double sb = v0 + v1, sa = (v0 - v1) + db1; // (df1's plain sum rides on df2's alternating one)
             // fold position 2 into 1, then 1 into 0: sum(pos 0) = s0 + (s1 + s2)
             const double ssum = sa + dpp_f64<DPP_WAVE_SHL1>(sa + dpp_f64<DPP_WAVE_SHL1>(sa));
             const double psum = sb + dpp_f64<DPP_WAVE_SHL1>(sb + dpp_f64<DPP_WAVE_SHL1>(sb));
