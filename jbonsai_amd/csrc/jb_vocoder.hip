@@ -1186,9 +1186,11 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 e11[0] = fma(iaa, ein, a * e11[0]);
                 e12[1] = e11[1] * c1;
                 e12[0] = e11[0] * c1;
-                const double dv0 = w0 * e12[0], dv1 = w1 * e12[1];
-                const double da = dv0 - dv1;
-                db1 = dv0 + dv1;
+                // w0*pt1[s0+1] -/+ w1*pt1[s0+2], each as one product and one FMA (an instruction less than two
+                // products, a difference and a sum)
+                const double dv1 = w1 * e12[1];
+                const double da = fma(w0, e12[0], -dv1);
+                db1 = fma(w0, e12[0], dv1);
                 x += da + dpp_f64<DPP_WAVE_SHL1>(da + dpp_f64<DPP_WAVE_SHL1>(da)); // pt1[0] (valid on the lead lane)
                 const double eprev = dpp_f64<DPP_WAVE_SHR1>(e12[1]);
                 ein = pos == 0 ? x : eprev;
@@ -1271,8 +1273,8 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             }
 #undef JB_LDS_RD
             // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, gathered on the lead lane ----
-            const double v0 = w0 * y[0], v1 = w1 * y[1];
-            const double sb = v0 + v1, sa = (v0 - v1) + db1; // (df1's plain sum rides on df2's alternating one)
+            const double v1 = w1 * y[1];
+            const double sb = fma(w0, y[0], v1), sa = fma(w0, y[0], db1 - v1); // (df1's plain sum rides on df2's alternating one)
             // fold position 2 into 1, then 1 into 0: sum(pos 0) = s0 + (s1 + s2)
             const double ssum = sa + dpp_f64<DPP_WAVE_SHL1>(sa + dpp_f64<DPP_WAVE_SHL1>(sa));
             const double psum = sb + dpp_f64<DPP_WAVE_SHL1>(sb + dpp_f64<DPP_WAVE_SHL1>(sb));
