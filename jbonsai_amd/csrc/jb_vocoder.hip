@@ -1198,10 +1198,9 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             // ---- V7 df2: fir() of this lane's stage slots, taps outermost (mlsa.rs:127-163) ----
             double r[NS], y[NS];
 #pragma unroll
-            for (int q = 0; q < NS; q++) {
+            for (int q = 0; q < NS; q++)
                 r[q] = u[q];
-                y[q] = 0.0;
-            }
+            static_assert(M >= 2, "the dot products start at tap 2");
             // Coefficient reads run kLtPf taps ahead of their use in rotating registers so that
             // their LDS latency overlaps the arithmetic in between.  hipcc sinks ordinary LDS loads
             // next to their use, so they are issued with inline asm and counted s_waitcnt
@@ -1247,7 +1246,19 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 static_assert(NS == 2, "the block below is written for two stage slots per lane");
                 {
                     double rn0, rn1;
-                    if (j >= 2) {
+                    if (j == 2) {
+                        // the first term of the dot products: a product, not an FMA onto a zero that a
+                        // v_mov would have to make first
+                        asm("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                            "v_fma_f64 %[rn1], %[na], %[r1], %[d1]\n\t"
+                            "v_fma_f64 %[d0], %[a], %[rn0], %[r0]\n\t"
+                            "v_fma_f64 %[d1], %[a], %[rn1], %[r1]\n\t"
+                            "v_mul_f64 %[y0], %[c], %[d0]\n\t"
+                            "v_mul_f64 %[y1], %[c], %[d1]"
+                            : [rn0] "=&v"(rn0), [rn1] "=&v"(rn1), [d0] "+v"(d[0][j]), [d1] "+v"(d[1][j]),
+                              [y0] "=&v"(y[0]), [y1] "=&v"(y[1])
+                            : [na] "s"(na), [a] "s"(a), [r0] "v"(r[0]), [r1] "v"(r[1]), [c] "v"(cj));
+                    } else if (j > 2) {
                         // (the interpolation c_j = c0 + i*cinc stays outside: inside the block it
                         // doubles the padding at the asm boundaries, measured +1 ms)
                         asm("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
