@@ -35,6 +35,9 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
+# more hardware queues than HIP's default 4, before anything initialises HIP (torch may come first): batches in
+# flight overlap only on queues of their own
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 sys.path.insert(0, str(ROOT))
 
 B_ALG = 8.67          # algorithmic bytes per output sample, f64 PCM

@@ -213,6 +213,18 @@ void pool_free(int device, void *p, size_t bytes)
 }
 } // namespace
 
+// The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that
+// share one run one after the other.  A batch has three streams; two batches in flight, or a batch and a read-back,
+// need more than four queues to overlap at all: with 16, two config-2 batches in flight take 82.3 instead of 86.0 ms
+// per step and the config-3 job 865 instead of 880 ms per pass (one batch at a time: no difference).  So the
+// library asks for 16 when it is loaded, unless the variable is already set; it has to happen before the
+// process's first HIP call, which is why this is a load-time constructor and not something jb_engine_load does
+// (a host that initialises HIP before loading the library sets GPU_MAX_HW_QUEUES itself: INTEGRATION.md).
+__attribute__((constructor)) static void jb_ask_for_hw_queues()
+{
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+}
+
 // Streams are kept the same way: hipStreamCreateWithFlags / hipStreamDestroy take 2.4 / 1.9 ms each on
 // this stack, three of each per batch = 13 of the 24 ms of a one-sentence jb_synthesize call.
 namespace {
