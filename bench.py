@@ -524,39 +524,36 @@ def run_config3(R, J, tab, vi, pset, args, steps, warmup):
         err = repr(e)
 
     def run_passes(n):
-        # n passes over this rank's sub-batches as one sequence.  The next sub-batch (of this pass or the
-        # next one) is created -- index upload, device gather, work list -- on a helper thread while the GPU
-        # runs the current one: two sub-batches resident at most, every creation inside the timed region.
-        # (Enqueueing the next sub-batch's step behind the running one as well -- two in flight -- was
-        # measured and loses: 1027 against 910 ms per pass on one box; its kernels queue in front of the
-        # running sub-batch's certification and redo round.)
+        # n passes over this rank's sub-batches as one sequence, TWO in flight: while the GPU runs sub-batch i, the
+        # next one (of this pass or the next) is created -- index upload, device gather, work list -- and its step
+        # enqueued behind the running one, whose certification and redo round then run beside the next one's
+        # parameter generation.  Two sub-batches resident at most, every creation inside the timed region.
+        # (With the HIP runtime's default of four hardware queues this LOST -- 1027 against 910 ms per pass, the
+        # second sub-batch's kernels queued in front of the first one's redo round; with the 16 the library asks
+        # for now it wins: 834-855 against 895-938 ms per pass on one box.)
         seq = [k for _ in range(n) for k in range(len(subs))]
-        nxt = {}
 
         def make(i):
-            try:
-                nxt[i] = J.Batch(vi, subs[seq[i]], device=R.local_rank, pdf_set=pset)
-            except Exception as e:  # surfaces in the consuming iteration
-                nxt[i] = e
+            return J.Batch(vi, subs[seq[i]], device=R.local_rank, pdf_set=pset)
 
-        th = None
-        if seq:
-            make(0)
+        if not seq:
+            return
+        cur = make(0)
+        cur.run()
         for i in range(len(seq)):
-            b = nxt.pop(i)
-            if isinstance(b, Exception):
-                raise b
+            nb = None
             try:
-                b.run()
                 if i + 1 < len(seq):
-                    th = threading.Thread(target=make, args=(i + 1,))
-                    th.start()
-                b.sync()
+                    nb = make(i + 1)
+                    nb.run()
+                cur.sync()
+            except Exception:
+                if nb is not None:
+                    nb.close()
+                raise
             finally:
-                if th is not None:
-                    th.join()
-                    th = None
-                b.close()
+                cur.close()
+            cur = nb
 
     def passes(n):
         nonlocal err
