@@ -962,9 +962,9 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
 // only BETWEEN samples (stage i reads d22[i-1] of the previous sample, mlsa.rs:71-77), so a chunk
 // is split over three adjacent lanes, stages {1,2} {3,4} {5,-}, each stage with its (nmcp-1)-tap
 // state in architectural VGPRs (68 state doubles per lane), taps outermost so the two slots give
-// 2-way ILP; everything but the per-sample exchange is lane-local.  The interpolated coefficients
-// c(n) = c0 + i*cinc live in LDS as [tap][chunk] pairs (broadcast ds_read_b128).  ~14 VALU
-// instructions per chunk-sample instead of ~128.
+// 2-way ILP; everything but the per-sample exchange is lane-local.  df1's five stages (one tap each) are
+// spread the same way.  The interpolated coefficients c(n) = c0 + i*cinc live in LDS as [tap][chunk] pairs
+// (broadcast ds_read_b128).  ~13.5 VALU instructions per chunk-sample instead of ~128.
 // 21 triples over lanes 0..62 of the wave (lane 63 idle), so 21 chunks per wave; the exchange uses
 // the whole-wave DPP shifts (a triple may straddle a 16-lane DPP row): one wave_shr:1 (stage
 // outputs to the next lane) and, per Pade partial sum, two wave_shl:1 that fold positions
