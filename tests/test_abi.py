@@ -99,3 +99,21 @@ def test_wav_sink_roundtrip(tmp_path):
         assert np.array_equal(got, want)
     with pytest.raises(J.JbError):
         J.write_wav(tmp_path / "no_such_dir" / "x.wav", want, 48000)
+
+
+def test_library_asks_for_hardware_queues_in_a_fresh_process():
+    """Loading the library sets GPU_MAX_HW_QUEUES (16) unless the host has set it: streams that share one of the
+    HIP runtime's default four hardware queues run one after the other, and batches in flight need their own
+    (INTEGRATION.md section 5).  Checked in child processes: the C environment of this one is long set."""
+    import os
+    import subprocess
+    import sys
+
+    code = ("import ctypes, sys; ctypes.CDLL(sys.argv[1]); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "print(libc.getenv(b'GPU_MAX_HW_QUEUES'))")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", code, str(J.LIB_PATH)], capture_output=True, text=True, env=env, timeout=120)
+    assert r.returncode == 0 and "b'16'" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code, str(J.LIB_PATH)], capture_output=True, text=True,
+                       env=dict(env, GPU_MAX_HW_QUEUES="6"), timeout=120)
+    assert r.returncode == 0 and "b'6'" in r.stdout, r.stdout + r.stderr
