@@ -130,6 +130,11 @@ typedef struct jb_batch_opts {
                                     three parameter tracks (implies KEEP_TRACKS); no excitation, no PCM, and
                                     no device memory for them.  What jb_mlpg_batch sets */
 
+#define JB_BATCH_NO_EXC_TABLE 512u /* A/B tests: the pulse-free excitation of EVERY frame is computed per utterance
+                                    (what a voice whose LPF taps differ from frame to frame gets anyway) instead of
+                                    read from the table all utterances share where their taps are the batch's
+                                    canonical ones; same bits either way */
+
 #define JB_BATCH_TEST_GANG_TIMEOUT 256u /* test aid: the first run behaves as if the resident GV kernel had timed
                                     out in formation (possible without a fault when several such launches share a
                                     device), which makes jb_batch_sync redo the step with the multi-launch GV

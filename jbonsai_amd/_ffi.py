@@ -30,6 +30,7 @@ BATCH_SERIAL_GV = 32
 BATCH_PCM_I16 = 64
 BATCH_MLPG_ONLY = 128
 BATCH_TEST_GANG_TIMEOUT = 256
+BATCH_NO_EXC_TABLE = 512
 
 
 class JbError(RuntimeError):

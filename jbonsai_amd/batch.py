@@ -204,7 +204,7 @@ class Batch:
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
                  kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False,
                  mlpg_cus_per_xcd: int = 0, pdf_set: Optional[PdfSet] = None, mlpg_only: bool = False,
-                 test_gang_timeout: bool = False):
+                 test_gang_timeout: bool = False, no_exc_table: bool = False):
         L = F.lib()
         self._L = L
         self.voice = voice
@@ -221,6 +221,7 @@ class Batch:
                       | (F.BATCH_SERIAL if serial else 0) | (F.BATCH_SERIAL_GV if serial_gv else 0)
                       | (F.BATCH_PCM_I16 if pcm_i16 else 0) | (F.BATCH_MLPG_ONLY if mlpg_only else 0)
                       | (F.BATCH_TEST_GANG_TIMEOUT if test_gang_timeout else 0)
+                      | (F.BATCH_NO_EXC_TABLE if no_exc_table else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "triple": F.BATCH_LANE_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
         opts.mlpg_cus_per_xcd = mlpg_cus_per_xcd

@@ -341,7 +341,7 @@ Batch::~Batch()
         hipEventDestroy(ev2);
     if (ev3)
         hipEventDestroy(ev3);
-    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build, ev_mcpbuild})
+    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build, ev_mcpbuild, ev_ivar})
         if (ev)
             hipEventDestroy(ev);
     for (hipEvent_t ev : {ev_mlpg_done, ev_voc_done})
@@ -762,6 +762,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     hipEventCreateWithFlags(&b->ev_prep, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_build, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_mcpbuild, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_ivar, hipEventDisableTiming);
     hipEventCreate(&b->ev0);
     hipEventCreate(&b->ev1);
     hipEventCreate(&b->ev2);
@@ -1022,6 +1023,17 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     // frames whose excitation is the noise stream itself are not stored (not with the debug tap, which
     // wants every sample, nor with the one-pass kernel for other tap counts / frame periods)
     vd.skip_unvoiced = (!vd.exc && excite_is_split(vd)) ? 1 : 0;
+    if (excite_is_split(vd) && !mlpg_only) {
+        // shared pulse-free excitation (jb_device.h): the table, the per-frame source codes, the work list of the
+        // per-frame pass.  With the debug tap (every sample wanted as computed per utterance) and on request
+        // (JB_BATCH_NO_EXC_TABLE: A/B tests) every frame goes through the per-frame pass.
+        vd.exc_no_table = (vd.exc || (b->flags & JB_BATCH_NO_EXC_TABLE)) ? 1 : 0;
+        if ((rc = b->dalloc(&vd.exc_tab, std::max<size_t>((size_t)maxT * (size_t)vd.fperiod, 1), false)) ||
+            (rc = b->dalloc(&vd.exc_src, std::max<size_t>(nf, 1), true)) ||
+            (rc = b->dalloc(&vd.exc_gen, 2 * std::max<size_t>(nf, 1), false)) ||
+            (rc = b->dalloc(&vd.exc_gen_count, 1, true)))
+            return rc;
+    }
     vd.state_stride = vd.stage > 0 ? mglsa_state_doubles(vd.stage) : vocoder_state_doubles(vd.nmcp);
     if ((rc = b->dalloc(&vd.state, (size_t)vd.state_stride * n, true)))
         return rc;
@@ -1229,11 +1241,21 @@ int Batch::enqueue_vocoder()
 // of its traffic, the excitation pass beside it stretched both by more than its own time and ran on the
 // main stream between band solve and GV: 98.8 ms per step that way, 97.8 this way.  With JB_ONE_STREAM the
 // side streams are the main stream and the order is simply sequential.)
+#ifdef JB_DBG_GATES
+static int dbg_sched() { const char *s = getenv("JB_DBG_SCHED"); return s ? atoi(s) : 0; }
+#endif
 static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
 {
     Batch *b = (Batch *)ctx;
     hipError_t e;
     (void)stream;
+    // the LPF chain starts behind the MCP chain's inverse-variance pass: both stream at HBM rate, and side by
+    // side (with the LF0 band solve) the pass on the critical chain took 3.1 ms instead of 0.5 (-0.45 ms per step)
+    hipStreamWaitEvent(b->stream_lpf, b->ev_ivar, 0);
+#ifdef JB_DBG_GATES
+    if (dbg_sched() & 2)
+        hipStreamWaitEvent(b->stream_lpf, b->ev_mcpbuild, 0);
+#endif
     if (b->voice.nstream > 2) {
         if ((e = launch_prep(b->bd, b->sd[2], 2, b->stream_lpf)) != hipSuccess)
             return e;
@@ -1334,7 +1356,7 @@ int Batch::enqueue_paramgen()
     // the LPF chain (side stream) and the pulse-free excitation pass (main stream)
     if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess)
         return hip_fail(e, "k_prep(mcp)");
-    if ((e = launch_mlpg(bd, sd[0], 0, stream, ev_mcpbuild, excite_noise_hook, this)) != hipSuccess)
+    if ((e = launch_mlpg(bd, sd[0], 0, stream, ev_mcpbuild, excite_noise_hook, this, ev_ivar)) != hipSuccess)
         return hip_fail(e, "k_mlpg(mcp) / k_excite(noise)");
     if (vd.stage > 0)
         e = launch_stage_coef(bd, vd, stream); // Stage::NonZero: LSP track -> MGLSA coefficients

@@ -137,6 +137,21 @@ struct VocDev {
     // entry in xin: their excitation IS the shared noise stream, x[n] = noise[n - (nlpf-1)/2]
     // (excitation.rs:43-45,83-86), and the vocoder kernels read it there (exc_frame_ptr)
     int skip_unvoiced;
+    // Shared pulse-free excitation (split form only; null otherwise).  Before its pulses are added, the
+    // excitation of a voiced frame behind a voiced frame depends on nothing but the frame's position, the
+    // shared noise stream and the LPF taps of the two frames; where both rows of taps equal the canonical
+    // taps (those of the batch's first frame: HTS voices carry ONE low-pass filter, the nitech voice too),
+    // it is the same for every utterance of the batch.  exc_tab[n] holds that excitation for every sample
+    // position (k_exc_table, once per run, the arithmetic of the per-frame pass); the per-frame pass
+    // (k_exc_general) then only computes the frames of exc_gen (frames at a voiced/unvoiced boundary, frames
+    // whose taps differ, first frames), and the pulse pass writes a row of xin only for frames a pulse reaches.
+    // exc_src[f]: where the vocoder finds frame f's excitation -- 0 its row of xin, 1 the noise stream
+    // (unvoiced behind unvoiced), 2 exc_tab.
+    double *exc_tab;          // [maxT * fperiod]
+    uint8_t *exc_src;         // [sumT]
+    uint32_t *exc_gen;        // [sumT][2] = (utterance, frame | vcur << 30 | vprev << 31)
+    uint32_t *exc_gen_count;  // [1]
+    int exc_no_table;         // 1: every frame goes through the per-frame pass (JB_BATCH_NO_EXC_TABLE, debug tap)
     double *pcm;          // [sumT*fperiod] f64 PCM, or nullptr when the i16 sink is selected
     int16_t *pcm16;       // [sumT*fperiod] clamped i16 PCM (JB_BATCH_PCM_I16), or nullptr
     double *exc;          // optional [sumT*fperiod] excitation before gain, or nullptr
@@ -150,6 +165,14 @@ struct VocDev {
 // shared noise stream at the frame's first sample minus the ring buffer's delay.
 __device__ __forceinline__ const double *exc_frame_ptr(const VocDev &vd, uint64_t base, uint32_t t)
 {
+    if (vd.exc_src) {
+        const uint32_t code = vd.exc_src[base + t];
+        if (code == 1)
+            return vd.noise + ((uint64_t)t * (uint64_t)vd.fperiod - (uint64_t)((vd.nlpf - 1) / 2));
+        if (code == 2)
+            return vd.exc_tab + (uint64_t)t * (uint64_t)vd.fperiod;
+        return vd.xin + (base + t) * (uint64_t)vd.fperiod;
+    }
     if (vd.skip_unvoiced && t >= 1 && !vd.voiced[base + t] && !vd.voiced[base + t - 1])
         return vd.noise + ((uint64_t)t * (uint64_t)vd.fperiod - (uint64_t)((vd.nlpf - 1) / 2));
     return vd.xin + (base + t) * (uint64_t)vd.fperiod;
@@ -169,6 +192,33 @@ struct VocWork {
 // recomputed state meets the checkpoint the original chunk left there, the rest of the chunk stands.
 // 48 frames for chunks of 96 frames and more, 24 for chunks of 40 to 95, none below.
 constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16;
+
+// Timing experiments only (library built with -DJB_DBG_GATES, never the product): JB_DBG_SKIP is a bit mask of
+// launches to leave out once a launcher has been called JB_DBG_SKIP_AFTER times (default 2: bench.py's warm-up
+// steps run in full, so the workspaces the skipped kernels would have written hold the right values) --
+// the ceiling of what removing a kernel can be worth (tools/gate.sh).  1 MCP build, 2 MCP band solve,
+// 4 pulse-free excitation pass, 8 pulse repair pass, 16 resident GV, 32 LF0 GV, 64 pulse walk.
+#ifdef JB_DBG_GATES
+#include <cstdlib>
+inline bool dbg_skip(int bit, int &calls)
+{
+    const char *m = getenv("JB_DBG_SKIP"), *a = getenv("JB_DBG_SKIP_AFTER");
+    const int after = a ? atoi(a) : 2;
+    return m && (atoi(m) & bit) && calls++ >= after;
+}
+#define JB_DBG_SKIP_IF(bit, stmt_else)                                                                         \
+    do {                                                                                                        \
+        static int calls_ = 0;                                                                                  \
+        if (!dbg_skip(bit, calls_)) {                                                                           \
+            stmt_else;                                                                                          \
+        }                                                                                                       \
+    } while (0)
+#else
+#define JB_DBG_SKIP_IF(bit, stmt_else)                                                                         \
+    do {                                                                                                        \
+        stmt_else;                                                                                              \
+    } while (0)
+#endif
 
 struct BatchDev {
     int B;
@@ -200,8 +250,10 @@ hipError_t launch_prep(const BatchDev &bd, const StreamDev &sd, int stream_index
 // between (optional) is called after the band solve has been enqueued and before the GV sweeps
 // are: the caller may enqueue other work on `stream` there.
 typedef hipError_t (*jb_enqueue_hook)(void *ctx, hipStream_t stream);
+// after_ivar (optional) is recorded behind the inverse-variance pass of the [dim][frame] path (at once on the others)
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index, hipStream_t stream,
-                       hipEvent_t after_build, jb_enqueue_hook between = nullptr, void *between_ctx = nullptr);
+                       hipEvent_t after_build, jb_enqueue_hook between = nullptr, void *between_ctx = nullptr,
+                       hipEvent_t after_ivar = nullptr);
 // resident GV: plan (0 = not applicable: row too long for a gang, no device capacity), bytes of the
 // control block for n gangs, launch (memset of the control block + the persistent kernel)
 int gv_gang_plan(int device, uint32_t maxT, uint32_t n_rows, int *tiles_per_gang, int *n_gangs);

@@ -2136,7 +2136,8 @@ static void launch_fb(const BatchDev &bd, const StreamDev &sd, int si, hipStream
 
 template <int BW>
 static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
-                                 hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx)
+                                 hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx,
+                                 hipEvent_t after_ivar)
 {
     const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
     if (work == 0 || bd.B == 0)
@@ -2147,13 +2148,15 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
             const uint64_t ne = (uint64_t)bd.maxS * (uint64_t)(sd.W * sd.L);
             dim3 grid((unsigned)((ne + 255) / 256), bd.B), block(256);
             hipLaunchKernelGGL(k_mlpg_ivar, grid, block, 0, stream, bd, sd, si);
+            if (after_ivar)
+                (void)hipEventRecord(after_ivar, stream);
         }
         {
             // sliding-window loads for up to three windows (StreamDev::mt requires W <= 3, L <= 60: 256 threads)
             dim3 grid((bd.maxT + kBuildTF - 1) / kBuildTF, bd.B);
             const size_t lds = sizeof(double) * (size_t)(BW + 1) * sd.L * (kBuildTF + 1);
             const int nthr = ((kBuildTF / kBuildRun) * sd.L + 63) / 64 * 64;
-            hipLaunchKernelGGL(k_mlpg_build_mt2<BW>, grid, dim3((unsigned)nthr), lds, stream, bd, sd, si);
+            JB_DBG_SKIP_IF(si == 0 ? 1 : 0, hipLaunchKernelGGL(k_mlpg_build_mt2<BW>, grid, dim3((unsigned)nthr), lds, stream, bd, sd, si));
         }
         if (after_build)
             (void)hipEventRecord(after_build, stream);
@@ -2166,7 +2169,7 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
                 hipLaunchKernelGGL((k_mlpg_solve3<false, true, true>), grid, block, 0, stream, bd, sd, si);
         } else {
             if (tp)
-                launch_fb(bd, sd, si, stream);
+                JB_DBG_SKIP_IF(si == 0 ? 2 : 0, launch_fb(bd, sd, si, stream));
             else
                 hipLaunchKernelGGL((k_mlpg_solve3<true, true, true>), grid, block, 0, stream, bd, sd, si);
         }
@@ -2178,7 +2181,8 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
         }
         if (tp && sd.gv_gang_ctl) {
             // resident form: one persistent launch, band matrix in registers (jb_gv_gang.hip)
-            hipError_t he = launch_gv_gang(bd, sd, si, stream);
+            hipError_t he = hipSuccess;
+            JB_DBG_SKIP_IF(16, he = launch_gv_gang(bd, sd, si, stream));
             if (he != hipSuccess)
                 return he;
         } else if (tp) {
@@ -2221,7 +2225,7 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
                         launch_fb(bd, sd, si, stream);
                     else
                         hipLaunchKernelGGL((k_mlpg_solve3<false, false>), grid, block, 0, stream, bd, sd, si);
-                    hipLaunchKernelGGL(k_mlpg_gv_vt<false>, gvgrid, block, 0, stream, bd, sd, si);
+                    JB_DBG_SKIP_IF(32, hipLaunchKernelGGL(k_mlpg_gv_vt<false>, gvgrid, block, 0, stream, bd, sd, si));
                 } else {
                     hipLaunchKernelGGL((k_mlpg_solve3<false, true>), grid, block, 0, stream, bd, sd, si);
                 }
@@ -2338,20 +2342,24 @@ int mlpg_mt_max_dim() { return kMtMaxDim; }
 int mlpg_gv_tile_frames() { return kGvTT; }
 
 static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
-                                    hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx);
+                                    hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx,
+                                    hipEvent_t after_ivar);
 
 hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream, hipEvent_t after_build,
-                       jb_enqueue_hook between, void *between_ctx)
+                       jb_enqueue_hook between, void *between_ctx, hipEvent_t after_ivar)
 {
-    hipError_t e = launch_mlpg_inner(bd, sd, si, stream, after_build, between, between_ctx);
+    hipError_t e = launch_mlpg_inner(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
     if (e == hipSuccess && between) // a path without a distinct GV phase: run the hook at the end
         e = between(between_ctx, stream);
     return e;
 }
 
 static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream,
-                                    hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx)
+                                    hipEvent_t after_build, jb_enqueue_hook &between, void *between_ctx,
+                                    hipEvent_t after_ivar)
 {
+    if (after_ivar && !(sd.BW == 3 && sd.mt)) // no inverse-variance pass on this path: "done" from the start
+        (void)hipEventRecord(after_ivar, stream);
     if (sd.BW == 1 && sd.W == 1 && !sd.use_gv && !sd.generic_solver) {
         const uint64_t work = (uint64_t)bd.maxT * (uint64_t)sd.L;
         if (work == 0 || bd.B == 0)
@@ -2364,11 +2372,11 @@ static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int
     }
     switch (sd.BW) {
     case 1:
-        return launch_mlpg_bw<1>(bd, sd, si, stream, after_build, between, between_ctx);
+        return launch_mlpg_bw<1>(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
     case 3:
-        return launch_mlpg_bw<3>(bd, sd, si, stream, after_build, between, between_ctx);
+        return launch_mlpg_bw<3>(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
     case 5:
-        return launch_mlpg_bw<5>(bd, sd, si, stream, after_build, between, between_ctx);
+        return launch_mlpg_bw<5>(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
     default:
         return hipErrorInvalidValue;
     }

@@ -94,6 +94,142 @@ __global__ __launch_bounds__(kMc2bFrames) void k_mc2b(BatchDev bd, VocDev vd)
 // state carried across frames: at every
 // frame start pitch_of_curr_point is reset to the previous frame's pitch by
 // Excitation::end, excitation.rs:102-104).
+// ---- one frame of the walk in closed form (round 4; CPU model and proof by exhaustion against the loop:
+// tests/tools/pulse_closed_form.py, 0 mismatches of fires and carried counter in 300 k stress frames) ----
+// Excitation::get's voiced branch (excitation.rs:73-81) runs, per sample,
+//     counter += 1; fire = counter >= cur; if fire: counter -= cur; cur += inc
+// and only `counter` is carried from frame to frame.  Two facts make a frame cost O(pulses), not O(samples):
+//   * while cur stays in one binade, fl(cur + inc) = cur + d with d = RN_ulp(inc): cur_k = cur_0 + k*d exactly
+//     (a tie -- inc = (p - p')/fperiod is one once in fperiod frames, p - p' being a multiple of the ulp --
+//     rounds to even: from an even mantissa on, d is constant too);
+//   * n increments of the counter are exact whenever c + n is representable (all c + k, k <= n, then are:
+//     they share c's fractional bits and are no larger): one TwoSum tells.  Otherwise the walk stays below the
+//     top of the counter's binade and takes the crossing as one rounded addition, as the loop does.
+// The first fire of a stretch is estimated by a division and settled by evaluating both (exact) sides.  A
+// sample whose cur cannot start a segment (tie from an odd mantissa, |d| out of range, denormal range) is
+// taken the loop's way.  Round 2's event-driven form stopped at EVERY binade top of the counter (~9 per pitch
+// period, 15 iterations per frame: slower than the loop on a wave in lockstep); here the exactness test makes
+// the usual stretch the rest of the frame: 1.6 iterations per frame on the synthetic utterances.
+__device__ __forceinline__ int pw_expo(double x) { return (int)(((unsigned long long)__double_as_longlong(x) >> 52) & 0x7ffull); }
+__device__ __forceinline__ double pw_pow2e(int e) { return __longlong_as_double((long long)e << 52); } // biased exponent e
+__device__ __forceinline__ bool pw_add_exact(double a, double b)
+{
+    const double s = a + b, bb = s - a;
+    return (a - (s - bb)) + (b - bb) == 0.0;
+}
+__device__ __forceinline__ void pw_set(unsigned long long (&w)[4], int jj, int bs)
+{
+    int q = 0;
+    while (jj >= bs) {
+        jj -= bs;
+        q++;
+    }
+    const unsigned long long bit = 1ull << jj;
+    w[0] |= q == 0 ? bit : 0ull;
+    w[1] |= q == 1 ? bit : 0ull;
+    w[2] |= q == 2 ? bit : 0ull;
+    w[3] |= q == 3 ? bit : 0ull;
+}
+__device__ __forceinline__ void pulse_frame_closed(double &counter, const double u0, const double inc, const int fp,
+                                                   const int bs, unsigned long long (&w)[4])
+{
+    double c = counter, us = u0; // us: cur at sample j (exact)
+    int j = 0;
+    while (j < fp) {
+        // ---- the cur-segment that starts at sample j: cur_{j+k} = us + k*d for k = 0..kk ----
+        const int e = pw_expo(us);
+        bool ok = us > 0.0 && e > 60;
+        double d = 0.0;
+        if (ok) {
+            const double u1 = us + inc;
+            d = u1 - us;
+            const double hU = pw_pow2e(e - 53); // half an ulp of the binade
+            const double r = fabs(inc - d);
+            ok = pw_expo(u1) == e && d > -8.0 && d < 0.9 &&
+                 (r < hU || (r == hU && (__double_as_longlong(us) & 1ll) == 0));
+        }
+        if (!ok) {
+            c = c + 1.0;
+            if (c >= us) {
+                pw_set(w, j, bs);
+                c = c - us;
+            }
+            us = us + inc;
+            j++;
+            continue;
+        }
+        const int rem = fp - 1 - j;
+        const double top = pw_pow2e(e + 1), bot = pw_pow2e(e);
+        int kk = rem;
+        {
+            const double ul = us + (double)rem * d;
+            if (!(ul < top && ul >= bot)) {
+                // the segment ends inside the frame: last k with cur_k still in the binade
+                if (d > 0.0) {
+                    const double q = (top - us) / d;
+                    kk = q > (double)(rem + 2) ? rem : min(max((int)ceil(q) - 1, 0), rem);
+                    while (kk > 0 && !(us + (double)kk * d < top))
+                        kk--;
+                    while (kk < rem && (us + (double)(kk + 1) * d < top))
+                        kk++;
+                } else {
+                    const double q = (us - bot) / -d;
+                    kk = q > (double)(rem + 2) ? rem : min(max((int)floor(q), 0), rem);
+                    while (kk > 0 && !(us + (double)kk * d >= bot))
+                        kk--;
+                    while (kk < rem && (us + (double)(kk + 1) * d >= bot))
+                        kk++;
+                }
+            }
+        }
+        const int jend = j + kk, js = j;
+        const double rcp = 1.0 / (1.0 - d);
+        // ---- the counter through the segment, a stretch of exact increments at a time ----
+        while (j <= jend) {
+            const int lim = jend - j + 1;
+            const double uj = us + (double)(j - js) * d;
+            int M;
+            if (pw_add_exact(c, (double)lim))
+                M = lim;
+            else if (c >= 1.0)
+                M = min((int)ceil(pw_pow2e(pw_expo(c) + 1) - c) - 1, lim);
+            else
+                M = 0;
+            if (M <= 0) {
+                c = c + 1.0;
+                if (c >= uj) {
+                    pw_set(w, j, bs);
+                    c = c - uj;
+                }
+                j++;
+                continue;
+            }
+            // first m in [0, M) with  c + (m + 1) >= uj + m*d  (both sides exact), M if none
+            const double a = uj - c - 1.0;
+            int m = 0;
+            if (a > 0.0) {
+                const double est = ceil(a * rcp);
+                m = est < (double)M ? (int)est : M;
+            }
+            while (m > 0 && (c + (double)m) >= (uj + (double)(m - 1) * d))
+                m--;
+            while (m < M && !((c + (double)(m + 1)) >= (uj + (double)m * d)))
+                m++;
+            if (m < M) {
+                c = (c + (double)(m + 1)) - (uj + (double)m * d);
+                pw_set(w, j + m, bs);
+                j += m + 1;
+            } else {
+                c = c + (double)M;
+                j += M;
+            }
+        }
+        // leave the segment: the update that crosses the binade is a rounded addition
+        us = (us + (double)(jend - js) * d) + inc;
+    }
+    counter = c;
+}
+
 // One voiced run (entry r of utterance b's compact run list from k_prep_states).
 __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, int b, uint32_t r)
 {
@@ -108,6 +244,51 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
     if (t0 > 0 && vd.pitch[base + t0 - 1] != 0.0)
         return; // continuation of the previous list entry (zero-length states in between)
     double prevp = 0.0, counter = 0.0;
+    if (nblk <= 4) {
+        // frames in blocks of eight: the next block's pitch values are requested before this block is walked
+        // (a frame is ~0.5 us of work now, less than the latency of its own load)
+        constexpr int PB = 8;
+        const double *pp = vd.pitch + base;
+        const uint32_t T = u.T;
+        double pb[PB], pn[PB];
+#pragma unroll
+        for (int k = 0; k < PB; k++)
+            pb[k] = pp[min(t0 + (uint32_t)k, T - 1)];
+        for (uint32_t tb = t0; tb < T; tb += PB) {
+#pragma unroll
+            for (int k = 0; k < PB; k++)
+                pn[k] = pp[min(tb + (uint32_t)(PB + k), T - 1)];
+#pragma unroll
+            for (int k = 0; k < PB; k++) {
+                const uint32_t t = tb + (uint32_t)k;
+                const double p = t < T ? pb[k] : 0.0;
+                if (p == 0.0)
+                    return;
+                double cur, inc;
+                // Excitation::start (excitation.rs:25-33)
+                if (prevp != 0.0) {
+                    cur = prevp;
+                    inc = (p - prevp) / (double)fp;
+                } else {
+                    inc = 0.0;
+                    cur = p;
+                    counter = p;
+                }
+                vd.cur_start[base + t] = cur;
+                vd.pinc[base + t] = inc;
+                vd.counter_start[base + t] = counter;
+                unsigned long long w[4] = {0ull, 0ull, 0ull, 0ull};
+                pulse_frame_closed(counter, cur, inc, fp, bs, w);
+                for (int q = 0; q < nblk; q++)
+                    vd.pmask[(base + t) * nblk + q] = w[q];
+                prevp = p; // Excitation::end
+            }
+#pragma unroll
+            for (int k = 0; k < PB; k++)
+                pb[k] = pn[k];
+        }
+        return;
+    }
     for (uint32_t t = t0; t < u.T; t++) {
         const double p = vd.pitch[base + t];
         if (p == 0.0)
@@ -125,11 +306,10 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
         vd.cur_start[base + t] = cur;
         vd.pinc[base + t] = inc;
         vd.counter_start[base + t] = counter;
-        int i = 0;
         for (int q = 0; q < nblk; q++) {
-            // voiced branch of Excitation::get (excitation.rs:73-81); the pulse bits are gathered in two
-            // 32-bit halves (one select and one shift-or per sample instead of six 64-bit mask operations:
-            // this loop is the latency of the whole LF0 chain for mid-size batches)
+            // voiced branch of Excitation::get (excitation.rs:73-81), sample by sample (frame periods with more
+            // than four mask words: the closed form above keeps a frame's words in registers); the pulse bits
+            // are gathered in two 32-bit halves
             uint32_t mlo = 0, mhi = 0;
             const int b32 = bs < 32 ? bs : 32;
 #pragma unroll 4
@@ -148,7 +328,6 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
                 mhi |= (uint32_t)fire << (j - 32);
                 cur += inc;
             }
-            i += bs;
             vd.pmask[(base + t) * nblk + q] = ((unsigned long long)mhi << 32) | mlo;
         }
         prevp = p; // Excitation::end
@@ -310,7 +489,7 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
 // own e (previous-frame entries read as zero: x + 0*c == x), the second over the previous
 // frame's e with its taps, executed only by the lanes that own the first 32 samples and only
 // when that frame was voiced.
-// A sample whose window holds no pulse does not depend on the LF0 track: k_excite_noise4 computes
+// A sample whose window holds no pulse does not depend on the LF0 track: the pulse-free pass computes
 // EVERY sample that way from the MSD voiced flags and the LPF taps alone (it can start with the
 // step); after the pulse walk, k_excite_fix adds the pulse terms.  Together they equal k_excite up to the
 // order of the additions (~1e-16 relative).
@@ -318,54 +497,36 @@ constexpr int kExw = 4;           // samples per lane
 constexpr int kExwHalo = 32;      // staged history, multiple of kExw, >= nlpf-1
 constexpr int kExwQ = (256 + kExwHalo) / kExw; // LDS row pitch (q = (m + halo) / 4)
 
-// The pulse-free pass.  NLPF is a template parameter (with a run-time tap count every tap is its own
-// scalar load + branch: 14 ms).  A lane loads the four noise values of its own samples as one 32-byte piece
-// and keeps them (the only LDS image is this frame's e, for the 30-sample history of a lane's window), the
-// start values noise[n - 15] come straight from memory (the L1 has the lines), the previous frame's tail is
-// loaded by the eight lanes that need it, and the taps of the frame are scalar loads issued WITH everything
-// else at the top: a wave is a chain of memory round trips, so everything it will read is requested in one
-// go behind the utterance descriptor.  (An earlier form staged 272 samples through three LDS images and
-// spent two thirds of its VALU instructions outside its FMAs: tools/experiments/README.md.)
+// The pulse-free pass of ONE frame by one wave.  NLPF is a template parameter (with a run-time tap count every
+// tap is its own scalar load + branch: 14 ms).  A lane loads the four noise values of its own samples as one
+// 32-byte piece and keeps them (the only LDS image is this frame's e, for the 30-sample history of a lane's
+// window), the start values noise[n - 15] come straight from memory (the L1 has the lines), the previous
+// frame's tail is loaded by the eight lanes that need it, and the taps of the frame are scalar loads issued
+// WITH everything else at the top: a wave is a chain of memory round trips, so everything it will read is
+// requested in one go.  (An earlier form staged 272 samples through three LDS images and spent two thirds of
+// its VALU instructions outside its FMAs: tools/experiments/README.md.)
+//   n0 = first sample of the frame in its utterance; tc / tpp = taps of the frame and of its predecessor
+//   (wave-uniform pointers); vcur / vprev = voiced flags of the two (vprev false for an utterance's first frame).
+// Returns the lane's four samples in x (own = the lane holds samples of the frame).
 constexpr int kN4Group = 4; // taps per window group of pass 1
 template <int NLPF>
-__global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, int utt_fastest)
+__device__ __forceinline__ bool exc_pulse_free(const VocDev &vd, const int fp, const long n0,
+                                               const double *__restrict__ tc, const double *__restrict__ tpp,
+                                               const bool vcur, const bool vprev, const int lane,
+                                               double (*ec)[kExwQ], double *ep, double *xs, double (&x)[kExw])
 {
     static_assert(NLPF - 1 <= kExwHalo - 2, "history window too short");
     constexpr int kExwWin = NLPF - 1 + kExw;
     constexpr int anti = (NLPF - 1) / 2;
     constexpr int HQ = kExwHalo / kExw; // history columns of the image
-    // utt_fastest: consecutive workgroups are the SAME four frames of consecutive utterances.  The noise
-    // is one table for all utterances (excitation.rs:177-237, seed fixed), indexed by the sample's
-    // position in its utterance: in this order the workgroups in flight read the same few KB of it (L2
-    // hits) instead of each utterance streaming the whole table from the Infinity Cache again.
-    const int b = utt_fastest ? blockIdx.x : blockIdx.y;
-    const uint32_t bx = utt_fastest ? blockIdx.y : blockIdx.x;
-    const UttDev *u = bd.utt + b;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(bx * 4u + (uint32_t)wv));
-    if (fr >= u->T)
-        return;
-    const int fp = vd.fperiod;
-    const uint64_t base = u->frame_off;
-    const uint64_t f = base + fr;
-    const long n0 = (long)fr * (long)fp;
-    __shared__ double ec_s[4][kExw][kExwQ];
-    __shared__ double ep_s[4][2 * kExwHalo];
-    __shared__ double xs_s[4][kExwHalo];
-    double(*ec)[kExwQ] = ec_s[wv];
-    double *ep = ep_s[wv];
-    double *xs = xs_s[wv];
     const int i0 = lane * kExw;
     const bool own = i0 < fp;
     // ---- every request of the wave ----
-    const uint64_t fprev = fr > 0 ? f - 1 : f;
-    const uint32_t vflag_c = vd.voiced[f], vflag_p = vd.voiced[fprev];
-    const double *tc = vd.lpf + f * (uint64_t)NLPF;
     double ck[NLPF]; // wave-uniform: scalar loads
 #pragma unroll
     for (int k = 0; k < NLPF; k++)
         ck[k] = tc[k];
-    const double tpv = lane < NLPF ? vd.lpf[fprev * (uint64_t)NLPF + (uint64_t)lane] : 0.0;
+    const double tpv = lane < NLPF ? tpp[lane] : 0.0;
     const long nl = own ? n0 + i0 : n0; // (a lane past the frame reads the frame's first samples and keeps nothing)
     const double2 nva = *reinterpret_cast<const double2 *>(vd.noise + nl);
     const double2 nvb = *reinterpret_cast<const double2 *>(vd.noise + nl + 2);
@@ -382,12 +543,7 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
     const long ntc = has_tail ? nt : n0;
     const double2 tla = *reinterpret_cast<const double2 *>(vd.noise + ntc);
     const double2 tlb = *reinterpret_cast<const double2 *>(vd.noise + ntc + 2);
-    const bool vcur = __builtin_amdgcn_readfirstlane((int)vflag_c) != 0;
-    const bool vprev = fr > 0 && __builtin_amdgcn_readfirstlane((int)vflag_p) != 0;
-    if (vd.skip_unvoiced && fr >= 1 && !vcur && !vprev)
-        return;
     const double nv[kExw] = {nva.x, nva.y, nvb.x, nvb.y};
-    double x[kExw];
 #pragma unroll
     for (int r = 0; r < kExw; r++)
         x[r] = xi[r];
@@ -423,8 +579,7 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
     if (vcur && own) {
         // the window e[i0 - (NLPF-1) .. i0 + 3] a GROUP of taps at a time (taps k0..k1 touch eleven of its 34
         // values): with the whole window in registers the kernel needs 62 VGPRs and only one of its waves fits
-        // a SIMD beside the resident GV kernel's two of 208, under which its last third runs; same order of the
-        // additions, so the same bits
+        // a SIMD beside the resident GV kernel's two of 208; same order of the additions, so the same bits
         constexpr int G = kN4Group;
 #pragma unroll
         for (int k0 = 0; k0 < NLPF; k0 += G) {
@@ -490,14 +645,153 @@ __global__ __launch_bounds__(256) void k_excite_noise4(BatchDev bd, VocDev vd, i
                 x[r] = xs[i0 + r];
         }
     }
-    if (!own)
+    return own;
+}
+
+// Where does each frame's excitation come from (VocDev::exc_src)?  One wave per 64 consecutive frames of an
+// utterance: lanes as (frame pair, tap) compare the LPF rows of frames fr0-1 .. fr0+63 with the canonical taps
+// (row 0 of the batch) bit by bit, two frames per coalesced request, all requests in flight together; then
+// lane = frame classifies: unvoiced behind unvoiced -> the noise stream; voiced behind voiced with both rows
+// canonical -> the shared table (until the pulse pass finds a pulse reaching the frame); everything else -> the
+// per-frame pass, whose work list (exc_gen) the wave appends its frames to (one atomic per wave).
+template <int NLPF>
+__global__ __launch_bounds__(256) void k_exc_classify(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.y;
+    const UttDev *u = bd.utt + b;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t T = u->T;
+    const uint32_t fr0 = (blockIdx.x * 4u + (uint32_t)wv) * 64u;
+    if (fr0 >= T)
         return;
-    const uint64_t o = base * (uint64_t)fp + (uint64_t)n0 + (uint64_t)i0;
-    *reinterpret_cast<double2 *>(vd.xin + o) = make_double2(x[0], x[1]);
-    *reinterpret_cast<double2 *>(vd.xin + o + 2) = make_double2(x[2], x[3]);
-    if (vd.exc) {
-        *reinterpret_cast<double2 *>(vd.exc + o) = make_double2(x[0], x[1]);
-        *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[2], x[3]);
+    const uint64_t base = u->frame_off;
+    unsigned long long canon = 0ull; // bit j: row of frame fr0 - 1 + j is canonical (j = 0..63), bit 64 below
+    bool canon64 = false;
+    if (!vd.exc_no_table) {
+        const int half = lane >> 5, k = lane & 31;
+        const bool tap = k < NLPF;
+        const double cref = vd.lpf[tap ? k : 0];
+        double v[33];
+#pragma unroll
+        for (int s = 0; s < 33; s++) {
+            const long fr = (long)fr0 - 1 + 2 * s + half;
+            const bool in = tap && fr >= 0 && fr < (long)T;
+            v[s] = vd.lpf[in ? (base + (uint64_t)fr) * (uint64_t)NLPF + (uint64_t)k : (uint64_t)(tap ? k : 0)];
+            if (!(fr >= 0 && fr < (long)T))
+                v[s] = __longlong_as_double(~__double_as_longlong(cref)); // outside the utterance: not canonical
+        }
+        // (all 33 requests are out before the first comparison waits for one: the compiler otherwise sinks every
+        // load to its use and the wave lives through 33 round trips)
+#pragma unroll
+        for (int s = 0; s < 33; s++)
+            asm volatile("" : "+v"(v[s]));
+#pragma unroll
+        for (int s = 0; s < 33; s++) {
+            const bool eq = !tap || __double_as_longlong(v[s]) == __double_as_longlong(cref);
+            const unsigned long long m = __ballot(eq);
+            const bool ea = (uint32_t)m == 0xFFFFFFFFu, eb = (uint32_t)(m >> 32) == 0xFFFFFFFFu;
+            if (s < 32)
+                canon |= ((unsigned long long)ea << (2 * s)) | ((unsigned long long)eb << (2 * s + 1));
+            else
+                canon64 = ea;
+        }
+    }
+    const uint32_t fr = fr0 + (uint32_t)lane;
+    const bool in = fr < T;
+    const uint64_t f = base + (in ? fr : fr0);
+    const bool vcur = in && vd.voiced[f] != 0;
+    const bool vprev = in && fr > 0 && vd.voiced[f - 1] != 0;
+    const bool ccur = lane == 63 ? canon64 : ((canon >> (lane + 1)) & 1ull) != 0;
+    const bool cprev = ((canon >> lane) & 1ull) != 0;
+    uint32_t code = 0;
+    if (!vd.exc_no_table && !vcur && !vprev && fr >= 1)
+        code = 1;
+    else if (!vd.exc_no_table && vcur && vprev && ccur && cprev)
+        code = 2;
+    if (in)
+        vd.exc_src[f] = (uint8_t)code;
+    const bool gen = in && code == 0;
+    const unsigned long long gm = __ballot(gen);
+    if (gm == 0ull)
+        return;
+    uint32_t slot0 = 0;
+    if (lane == 0)
+        slot0 = atomicAdd(vd.exc_gen_count, (uint32_t)__popcll(gm));
+    slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+    if (gen) {
+        const uint32_t rank = (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
+        uint32_t *e = vd.exc_gen + 2 * (uint64_t)(slot0 + rank);
+        e[0] = (uint32_t)b;
+        e[1] = fr | (vcur ? 1u << 30 : 0u) | (vprev ? 1u << 31 : 0u);
+    }
+}
+
+// The shared table: the pulse-free excitation of a voiced frame behind a voiced frame, both with the canonical
+// taps, for every frame position 1 .. maxT-1 (a first frame has no predecessor: never read from the table).
+template <int NLPF>
+__global__ __launch_bounds__(256) void k_exc_table(BatchDev bd, VocDev vd)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (uint32_t)wv));
+    if (fr == 0 || fr >= bd.maxT)
+        return;
+    __shared__ double ec_s[4][kExw][kExwQ];
+    __shared__ double ep_s[4][2 * kExwHalo];
+    __shared__ double xs_s[4][kExwHalo];
+    const int fp = vd.fperiod;
+    const long n0 = (long)fr * (long)fp;
+    double x[kExw];
+    if (!exc_pulse_free<NLPF>(vd, fp, n0, vd.lpf, vd.lpf, true, true, lane, ec_s[wv], ep_s[wv], xs_s[wv], x))
+        return;
+    double *o = vd.exc_tab + (uint64_t)n0 + (uint64_t)(lane * kExw);
+    *reinterpret_cast<double2 *>(o) = make_double2(x[0], x[1]);
+    *reinterpret_cast<double2 *>(o + 2) = make_double2(x[2], x[3]);
+}
+
+// The per-frame pass over the work list of k_exc_classify: every wave of a fixed grid takes entries in
+// turn (the next entry is requested while the current frame is worked on).
+template <int NLPF>
+__global__ __launch_bounds__(256) void k_exc_general(BatchDev bd, VocDev vd)
+{
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double ec_s[4][kExw][kExwQ];
+    __shared__ double ep_s[4][2 * kExwHalo];
+    __shared__ double xs_s[4][kExwHalo];
+    const uint32_t count = *vd.exc_gen_count;
+    const uint32_t stride = gridDim.x * 4u;
+    uint32_t i = blockIdx.x * 4u + (uint32_t)wv;
+    if (i >= count)
+        return;
+    const int fp = vd.fperiod;
+    uint32_t eb = vd.exc_gen[2 * (uint64_t)i], ef = vd.exc_gen[2 * (uint64_t)i + 1];
+    for (; i < count; i += stride) {
+        const int b = __builtin_amdgcn_readfirstlane((int)eb);
+        const uint32_t efu = (uint32_t)__builtin_amdgcn_readfirstlane((int)ef);
+        const uint32_t inext = i + stride < count ? i + stride : i;
+        eb = vd.exc_gen[2 * (uint64_t)inext];
+        ef = vd.exc_gen[2 * (uint64_t)inext + 1];
+        const uint32_t fr = efu & 0x3FFFFFFFu;
+        const bool vcur = (efu >> 30 & 1u) != 0, vprev = (efu >> 31) != 0;
+        const uint64_t base = bd.utt[b].frame_off;
+        const uint64_t f = base + fr;
+        const uint64_t fprev = fr > 0 ? f - 1 : f;
+        const long n0 = (long)fr * (long)fp;
+        double x[kExw];
+        const bool own = exc_pulse_free<NLPF>(vd, fp, n0, vd.lpf + f * (uint64_t)NLPF, vd.lpf + fprev * (uint64_t)NLPF,
+                                              vcur, vprev, lane, ec_s[wv], ep_s[wv], xs_s[wv], x);
+        if (own) {
+            const uint64_t o = base * (uint64_t)fp + (uint64_t)n0 + (uint64_t)(lane * kExw);
+            *reinterpret_cast<double2 *>(vd.xin + o) = make_double2(x[0], x[1]);
+            *reinterpret_cast<double2 *>(vd.xin + o + 2) = make_double2(x[2], x[3]);
+            if (vd.exc) {
+                *reinterpret_cast<double2 *>(vd.exc + o) = make_double2(x[0], x[1]);
+                *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[2], x[3]);
+            }
+        }
+        // the LDS images are reused by the next frame
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -549,13 +843,15 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     const bool own = s0 < fp;
     const int tail0 = fp - H; // first sample of the previous frame whose pulse reaches into this one
     unsigned long long mword = 0ull;
-    uint32_t vfl = 0;
+    uint32_t vfl = 0, codev = 0; // codev: exc_src of frame jf on lane 4 * jf + 1
     {
         const int half = lane >> 5, jf = (lane & 31) / 4, q = lane & 3;
         const long frl = (long)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv) - half;
         if (frl >= 0 && frl < (long)T) {
             if (q == 0)
                 vfl = vd.voiced[base + (uint64_t)frl];
+            if (q == 1 && half == 0 && vd.exc_src)
+                codev = vd.exc_src[base + (uint64_t)frl];
             if (q < nblk)
                 mword = vd.pmask[(base + (uint64_t)frl) * (uint64_t)nblk + (uint64_t)q];
         }
@@ -601,14 +897,14 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     constexpr int kFixGroup = 4;
     static_assert(kFixFrames % kFixGroup == 0, "whole groups");
     for (int j0 = 0; j0 < kFixFrames; j0 += kFixGroup) {
-        bool work[kFixGroup], touched[kFixGroup];
+        bool work[kFixGroup], touched[kFixGroup], from_tab[kFixGroup];
         double tv[kFixGroup], pv[kFixGroup], x[kFixGroup][kExw];
 #pragma unroll
         for (int g = 0; g < kFixGroup; g++) {
             const int jf = j0 + g;
             const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
-            work[g] = touched[g] = false;
+            work[g] = touched[g] = from_tab[g] = false;
             tv[g] = pv[g] = 0.0;
 #pragma unroll
             for (int r = 0; r < kExw; r++)
@@ -622,8 +918,11 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             const bool any_p = (m8 & 0xFu) != 0, any_c = (m8 >> 4) != 0;
             bool tch = false;
             each_pulse(jf, m8, [&](int p, int, int) { tch = tch || (s0 + kExw - 1 >= p && s0 <= p + H); });
+            // a frame that stood on the shared table until now (exc_src 2) gets a row of its own: every lane
+            // takes its samples from the table and writes them with the pulse terms added
+            from_tab[g] = __builtin_amdgcn_readlane((int)codev, 4 * jf + 1) == 2;
             work[g] = true;
-            touched[g] = tch && own;
+            touched[g] = (tch || from_tab[g]) && own;
             {
                 // taps of the previous frame (lanes 0..31; only if one of its last H samples holds a pulse: one
                 // frame in eight) and of this one (lanes 32..63), lane = tap
@@ -637,9 +936,10 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                 }
             }
             if (touched[g]) {
-                const uint64_t o = f * (uint64_t)fp + (uint64_t)s0;
-                const double2 xa = *reinterpret_cast<const double2 *>(vd.xin + o);
-                const double2 xb = *reinterpret_cast<const double2 *>(vd.xin + o + 2);
+                const double *src = from_tab[g] ? vd.exc_tab + ((uint64_t)fr * (uint64_t)fp + (uint64_t)s0)
+                                                : vd.xin + (f * (uint64_t)fp + (uint64_t)s0);
+                const double2 xa = *reinterpret_cast<const double2 *>(src);
+                const double2 xb = *reinterpret_cast<const double2 *>(src + 2);
                 x[g][0] = xa.x;
                 x[g][1] = xa.y;
                 x[g][2] = xb.x;
@@ -686,6 +986,8 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                     *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[g][2], x[g][3]);
                 }
             }
+            if (from_tab[g] && lane == 0)
+                vd.exc_src[f] = 0; // the vocoder reads the row
         }
     } // groups of frames
 }
@@ -1439,7 +1741,7 @@ hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
     return hipGetLastError();
 }
 
-// the split form (k_excite_noise4 + k_excite_fix) is built for these shapes; everything else takes k_excite
+// the split form (k_exc_* + k_excite_fix) is built for these shapes; everything else takes k_excite
 bool excite_is_split(const VocDev &vd)
 {
     // (fperiod = 4m with m <= 64: one of m, 2m, 4m is the block size, so a frame has at most four mask words --
@@ -1452,21 +1754,36 @@ hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t
 {
     if (bd.B == 0 || bd.maxT == 0 || !excite_is_split(vd))
         return hipSuccess;
-    dim3 grid((bd.maxT + 3) / 4, bd.B), block(256);
-    const int swap = grid.x <= 65535u; // grid.y limit
-    if (swap)
-        grid = dim3(bd.B, (bd.maxT + 3) / 4);
-    // 32 KB of LDS that the kernel does not use ride with every workgroup: they cap the workgroups a CU takes
-    // at three (12 waves instead of up to 40).  This pass runs on a side stream beside the MCP chain's build
-    // and band solve, which are chains of round trips at low occupancy; with all the wave slots it could get
-    // it stretched them by more than it gained (parameter generation, same box, kernel at 48 VGPRs: 31.0-31.4 ms
-    // with 16 KB, 29.1-30.1 with 24, 28.7-29.6 with 32, 29.2-29.4 with 40; the same cap on the LPF MLPG or
-    // the pulse repair pass loses).
+    if (!vd.exc_src || !vd.exc_gen || !vd.exc_gen_count || !vd.exc_tab)
+        return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(vd.exc_gen_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess)
+        return e;
+    const dim3 block(256);
+    const dim3 gcls((bd.maxT + 255) / 256, bd.B), gtab((bd.maxT + 3) / 4);
+    // The per-frame pass runs on a side stream beside the MCP chain's build and band solve, which are chains
+    // of round trips at low occupancy: 32 KB of LDS that the kernel does not use ride with every workgroup and
+    // cap the workgroups a CU takes at three (12 waves instead of up to 40) -- with all the wave slots it could
+    // get it stretched them by more than it gained (measured in round 2 when EVERY frame went through this
+    // pass; it still does for a voice whose LPF taps differ from frame to frame).  Fixed grid: three
+    // workgroups per CU of the device, each wave taking list entries in turn.
     constexpr size_t pad = 32 * 1024;
-    if (vd.nlpf == 31)
-        hipLaunchKernelGGL(k_excite_noise4<31>, grid, block, pad, stream, bd, vd, swap);
-    else
-        hipLaunchKernelGGL(k_excite_noise4<15>, grid, block, pad, stream, bd, vd, swap);
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const dim3 ggen((unsigned)(3 * cus));
+    if (vd.nlpf == 31) {
+        hipLaunchKernelGGL(k_exc_classify<31>, gcls, block, 0, stream, bd, vd);
+        if (!vd.exc_no_table)
+            hipLaunchKernelGGL(k_exc_table<31>, gtab, block, 0, stream, bd, vd);
+        JB_DBG_SKIP_IF(4, hipLaunchKernelGGL(k_exc_general<31>, ggen, block, pad, stream, bd, vd));
+    } else {
+        hipLaunchKernelGGL(k_exc_classify<15>, gcls, block, 0, stream, bd, vd);
+        if (!vd.exc_no_table)
+            hipLaunchKernelGGL(k_exc_table<15>, gtab, block, 0, stream, bd, vd);
+        hipLaunchKernelGGL(k_exc_general<15>, ggen, block, pad, stream, bd, vd);
+    }
     return hipGetLastError();
 }
 
@@ -1477,7 +1794,7 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
     if (excite_is_split(vd)) {
         dim3 gfix((bd.maxT + 4 * kFixFrames - 1) / (4 * kFixFrames), bd.B), block(256);
         if (vd.nlpf == 31)
-            hipLaunchKernelGGL(k_excite_fix<31>, gfix, block, 0, stream, bd, vd);
+            JB_DBG_SKIP_IF(8, hipLaunchKernelGGL(k_excite_fix<31>, gfix, block, 0, stream, bd, vd));
         else
             hipLaunchKernelGGL(k_excite_fix<15>, gfix, block, 0, stream, bd, vd);
         return hipGetLastError();
@@ -1495,7 +1812,7 @@ hipError_t launch_pulse(const BatchDev &bd, const VocDev &vd, hipStream_t stream
     if (bd.B == 0 || bd.maxT == 0)
         return hipSuccess;
     hipLaunchKernelGGL(k_run_scan, dim3(1), dim3(256), 0, stream, bd, vd);
-    hipLaunchKernelGGL(k_pulse_queue, dim3(kPulseQueueWaves), dim3(64), 0, stream, bd, vd);
+    JB_DBG_SKIP_IF(64, hipLaunchKernelGGL(k_pulse_queue, dim3(kPulseQueueWaves), dim3(64), 0, stream, bd, vd));
     return hipGetLastError();
 }
 
