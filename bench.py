@@ -187,7 +187,7 @@ def _host_cpu():
     return model, nproc, aff, quota
 
 
-def cpu_baseline(utt, vi, batch_size):
+def cpu_baseline(utt, vi, batch_size, gpu=None):
     """the oracle (C restatement of jbonsai's CPU path, kind="port") built
     -O3 -march=native ON THIS BOX (oracle/Makefile `native`; no FMA contraction, no fast-math: same bits
     as the checker build), on the same synthetic utterance as the GPU batch:
@@ -214,11 +214,32 @@ def cpu_baseline(utt, vi, batch_size):
                                   s.mean, s.var, msd, s.gv_mean, s.gv_var, s.gv_switch))
     nsamp = int(utt.durations.sum()) * vi.fperiod
 
-    def one():
+    def one(keep=False):
         tr = [O.mlpg(s, utt.durations) for s in sts]
-        O.vocoder(vi.sampling_frequency, vi.fperiod, vi.alpha, 1.0, tr[1][:, 0], tr[0], tr[2])
+        return O.vocoder(vi.sampling_frequency, vi.fperiod, vi.alpha, 1.0, tr[1][:, 0], tr[0], tr[2], dumps=keep)
 
-    one()  # warm-up
+    # warm-up -- and the error figure of the metric (SURVEY 8d "Error metric"): the oracle's PCM and excitation of
+    # the batch's utterance against what the GPU produced for it inside the timed batch (utterance 0 and the
+    # last one) and in a one-utterance batch with the excitation tap
+    ref_pcm, ref_exc, ref_pul = one(keep=True)
+    err = None
+    if gpu is not None:
+        def rel(a):
+            return float(np.sqrt(np.mean((a - ref_pcm) ** 2)) / np.sqrt(np.mean(ref_pcm ** 2)))
+        same_len = all(len(a) == len(ref_pcm) for a in gpu["pcm"])
+        err = {"length_equal": bool(same_len), "samples": int(len(ref_pcm)), "utterances_compared": len(gpu["pcm"]),
+               "gate": {"rel_rms": 1e-9, "north_star_rms": 1e-4}}
+        if same_len:
+            err["rel_rms"] = max(rel(a) for a in gpu["pcm"])
+            err["max_abs_i16_scale"] = max(float(np.max(np.abs(a - ref_pcm))) for a in gpu["pcm"])
+            err["ref_rms_i16_scale"] = float(np.sqrt(np.mean(ref_pcm ** 2)))
+            if gpu.get("exc") is not None and len(gpu["exc"]) == len(ref_exc):
+                d = float(np.max(np.abs(gpu["exc"] - ref_exc)))
+                err["excitation_max_abs"] = d
+                err["pulses"] = int(np.count_nonzero(ref_pul))
+                # a pulse one sample off is an excitation error of the pulse's size (sqrt(period) * tap ~ 1..5)
+                err["pulse_positions_equal"] = bool(d < 1e-6)
+    del ref_pcm, ref_exc, ref_pul
     runs = []
     for _ in range(5):
         t0 = time.perf_counter()
@@ -253,6 +274,7 @@ def cpu_baseline(utt, vi, batch_size):
         "all_cores": {"value": all_cores, "unit": "samples/s", "threads": threads, "utterances": done[0],
                       "of_batch": batch_size, "wall_s": dt,
                       "realtime_factor": all_cores / vi.sampling_frequency},
+        "error_vs_oracle": err,
         "cpu_model": model, "nproc": nproc, "affinity": aff, "cgroup_cpu_quota": quota, "build": build,
         "sample": f"{done[0]} of the batch's {batch_size} utterances of {nsamp} samples (the same synthetic utterance "
                   f"as the GPU batch), one per thread at a time on {threads} threads, {dt:.2f} s wall; single thread: "
@@ -921,6 +943,18 @@ def run_rank(args):
             "roofline": roofline_block(samples_per_step, voc_avg_ms, info, args.batch, frames),
             "kernel_sources_sha16": kernel_sources_sha16(),
         }
+    gpu_out = None
+    if R.rank == 0 and R.world == 1 and not args.no_cpu_baseline and not args.mixed and nd == 1:
+        # what the error figure compares: PCM of the first and the last utterance of the timed batch, and the
+        # excitation of the same utterance from a one-utterance batch with the debug tap
+        gpu_out = {"pcm": [batch.pcm(0), batch.pcm(args.batch - 1)], "exc": None}
+        try:
+            with J.Batch(vi, [utt], device=R.local_rank, keep_tracks=True) as bt:
+                bt.run()
+                bt.sync()
+                gpu_out["exc"] = bt.excitation(0)
+        except Exception as e:  # the figure then lacks the excitation part
+            print(f"excitation tap failed: {e!r}", file=sys.stderr)
     if R.world == 1 and not args.no_extras:
         ex = extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_step, R)
         if out is not None:
@@ -944,7 +978,9 @@ def run_rank(args):
             out["config3_strong" if R.world > 1 else "config3_job"] = rec
     if R.rank == 0:
         if R.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(utt, vi, args.batch)
+            out["cpu_baseline"] = cpu_baseline(utt, vi, args.batch, gpu_out)
+            # the metric's error figure, at the top level of the line (it is part of the metric)
+            out["error_vs_oracle"] = out["cpu_baseline"].pop("error_vs_oracle")
         print(json.dumps(out), flush=True)
     R.close()
 
