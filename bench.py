@@ -902,7 +902,9 @@ def run_rank(args):
         # config 2).  The library's own gather: grouped ncclSend / ncclRecv over xGMI (jb_gather_pcm); the
         # communicator id is control plane and travels over the launcher's rendezvous.  In the one-GPU
         # rehearsal (gloo) RCCL cannot run: there the slabs go through torch.distributed on the host.
-        if R.rehearse:
+        # With JB_RCCL_LIBRARY = the test double of tests/fake_rccl (several ranks on one device) the rehearsal
+        # takes the library's own gather too: functional only, its time says nothing about xGMI.
+        if R.rehearse and not os.environ.get("JB_RCCL_LIBRARY"):
             gather_ms = R.gather_slabs(pcm_slab_tensor(batch))
         else:
             gather_ms = R.gather_native(J, batch)

@@ -138,7 +138,8 @@ typedef struct jb_batch_opts {
 #define JB_BATCH_TEST_GANG_TIMEOUT 256u /* test aid: the first run behaves as if the resident GV kernel had timed
                                     out in formation (possible without a fault when several such launches share a
                                     device), which makes jb_batch_sync redo the step with the multi-launch GV
-                                    sweeps; jb_batch_gang_fallbacks counts these */
+                                    sweeps; jb_batch_gang_fallbacks counts these.  (JB_GENERATOR_TEST_GANG_TIMEOUT=1
+                                    in the environment does the same to the batch behind jb_generator_new.) */
 
 /* Time-chunked vocoder (default).  The MLSA recursion is time-serial per utterance
  * (src/vocoder/mlsa.rs), but it forgets its initial state within ~16 frames (measured:
@@ -289,6 +290,16 @@ int jb_batch_create_from_tracks(const jb_voice_desc *voice, const jb_track_utt *
  * pcm[i] must hold n_samples[i] = n_lf0 * fperiod doubles; pcm == NULL: n_samples only. */
 int jb_vocode_tracks_batch(const jb_voice_desc *voice, const jb_track_utt *utts, size_t n_utts,
                            const jb_batch_opts *opts, double *const *pcm, size_t *n_samples);
+/* Vocoder::new(nmcp, nlpf, stage, use_log_gain, rate, alpha, beta, volume, fperiod) followed by
+ * Vocoder::synthesize(lf0, spectrum, lpf, rawdata) frame after frame over the given tracks
+ * (src/vocoder/mod.rs:45-72,72-178): the Vocoder seam itself, WITHOUT SpeechGenerator::new's checks of the LPF
+ * length.  This is the one way to the ring-buffer-less branch of Excitation::get (nlpf == 0,
+ * src/vocoder/excitation.rs:87-100: bare pulses on voiced samples, the noise stream drawn on unvoiced samples
+ * only, no delay): voice->stream[2].vector_length == 0, lpf_width == 0, lpf may be NULL.  An even non-zero
+ * count is JB_ERR_UNSUPPORTED (the reference's ring buffer takes it; the kernels here do not).  Outer-length
+ * and lf0-width mismatches stay JB_ERR_INVALID.  Same buffers as jb_vocode_tracks_batch. */
+int jb_vocoder_synthesize_batch(const jb_voice_desc *voice, const jb_track_utt *utts, size_t n_utts,
+                                const jb_batch_opts *opts, double *const *pcm, size_t *n_samples);
 
 /* ---- multi-GPU (SURVEY 8b "device_ids[] / n_devices", 8e) ----------------------------------
  * Utterances are independent, so a batch shards over the GPUs of a node with no data-path
@@ -323,7 +334,12 @@ void jb_comm_free(jb_comm *c);
 /* Collective: every rank passes its (finished or running: the call waits) batch.  On `root`, *out holds
  * one device slab per rank (f64 samples, or i16 for JB_BATCH_PCM_I16 batches; utterance i of rank r's batch
  * at its jb_batch_pcm_offset); the root's own entry aliases its batch's slab (no copy: valid while that
- * batch lives).  On the other ranks *out is NULL.  *ms (may be NULL) = wall time of the exchange. */
+ * batch lives).  On the other ranks *out is NULL.  *ms (may be NULL) = wall time of the exchange.
+ * Failure is collective: a rank whose local work failed still calls this (b = NULL is allowed for it) and
+ * EVERY rank then returns an error instead of blocking; so does every rank when the root cannot allocate its
+ * receive slabs or when f64 and 16-bit slabs are mixed.  RCCL is bound at first use with dlopen
+ * ("librccl.so.1"; JB_RCCL_LIBRARY = full path of another library to bind, e.g. the test double of
+ * tests/fake_rccl that lets several ranks share one device). */
 int jb_gather_pcm(jb_comm *c, jb_batch *b, int root, jb_gathered **out, float *ms);
 size_t jb_gathered_samples(const jb_gathered *g, int rank);
 void *jb_gathered_device(const jb_gathered *g, int rank);
@@ -449,6 +465,13 @@ int jb_engine_tree_index(const jb_engine *e, size_t voice, int kind, int state_i
 /* Engine::generator (src/engine.rs:301) + SpeechGenerator (src/speech.rs:25-96). */
 int jb_generator_new(const jb_engine *e, const char *const *label_lines, size_t n_lines,
                      jb_generator **out);
+/* SpeechGenerator::new(fperiod, vocoder, spectrum, lf0, lpf) on tracks the caller holds (src/speech.rs:25-50),
+ * for jb_generator_step = generate_step (:65-82).  Of `voice` the Vocoder::new arguments are read, as in
+ * jb_batch_create_from_tracks; the three panics of SpeechGenerator::new come back as JB_ERR_INVALID with the
+ * reference's messages.  opts may be NULL (current device, defaults); the 16-bit sink flag is ignored
+ * (generate_step hands out f64 samples). */
+int jb_generator_new_from_tracks(const jb_voice_desc *voice, const jb_track_utt *utt, const jb_batch_opts *opts,
+                                 jb_generator **out);
 size_t jb_generator_fperiod(const jb_generator *g);
 size_t jb_generator_synthesized_frames(const jb_generator *g);
 size_t jb_generator_total_frames(const jb_generator *g);

@@ -147,7 +147,7 @@ SYMBOLS = [
     "jb_engine_set_interpolation_weight", "jb_engine_get_interpolation_weight", "jb_synthesize", "jb_pcm_free", "jb_write_wav_i16", "jb_write_wav_f64", "jb_synthesize_batch", "jb_synthesize_batch_i16", "jb_pcm_i16_free",
     "jb_engine_model_shape", "jb_engine_pdf_table", "jb_engine_tree_index",
     "jb_engine_states", "jb_states_utt", "jb_engine_voice_desc", "jb_states_free",
-    "jb_generator_new", "jb_generator_fperiod", "jb_generator_synthesized_frames",
+    "jb_generator_new", "jb_generator_new_from_tracks", "jb_vocoder_synthesize_batch", "jb_generator_fperiod", "jb_generator_synthesized_frames",
     "jb_generator_total_frames", "jb_generator_step", "jb_generator_step_n", "jb_generator_free",
     "jb_comm_unique_id", "jb_comm_init", "jb_comm_rank", "jb_comm_size", "jb_comm_free", "jb_gather_pcm",
     "jb_gathered_samples", "jb_gathered_device", "jb_gathered_read", "jb_gathered_free",
@@ -226,6 +226,10 @@ def lib():
                                               C.POINTER(vp)]
     L.jb_vocode_tracks_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(TrackUtt), sz, C.POINTER(BatchOpts),
                                          C.POINTER(dp), C.POINTER(sz)]
+    L.jb_vocoder_synthesize_batch.argtypes = [C.POINTER(VoiceDesc), C.POINTER(TrackUtt), sz, C.POINTER(BatchOpts),
+                                              C.POINTER(dp), C.POINTER(sz)]
+    L.jb_generator_new_from_tracks.argtypes = [C.POINTER(VoiceDesc), C.POINTER(TrackUtt), C.POINTER(BatchOpts),
+                                               C.POINTER(vp)]
     L.jb_set_cached_memory_limit.argtypes = [sz]
     L.jb_comm_unique_id.argtypes = [C.c_char_p, sz]
     L.jb_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int32, C.POINTER(vp)]

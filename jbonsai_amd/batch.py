@@ -399,6 +399,44 @@ def vocode_tracks_batch(voice: VoiceInfo, utts: Sequence["TrackUtterance"], devi
     return out
 
 
+def vocoder_synthesize_batch(voice: VoiceInfo, utts: Sequence["TrackUtterance"], device: int = -1):
+    """jb_vocoder_synthesize_batch = Vocoder::new + Vocoder::synthesize per frame (vocoder/mod.rs:45-178): like
+    vocode_tracks_batch without SpeechGenerator::new's LPF checks, so that nlpf == 0 (voice.streams[2]
+    .vector_length == 0, lpf tracks of width 0) reaches Excitation::get's ring-buffer-less branch."""
+    L = F.lib()
+    vd, keep = voice.c_struct()
+    arr = (F.TrackUtt * max(1, len(utts)))()
+    for i, u in enumerate(utts):
+        arr[i] = u.c_struct()
+    ns = (C.c_size_t * max(1, len(utts)))()
+    opts = F.BatchOpts()
+    opts.device = device
+    F.check(L.jb_vocoder_synthesize_batch(C.byref(vd), arr, len(utts), C.byref(opts), None, ns))
+    out = [np.empty(ns[i], dtype=np.float64) for i in range(len(utts))]
+    ptrs = (C.POINTER(C.c_double) * max(1, len(utts)))(*[_dp(o) for o in out])
+    F.check(L.jb_vocoder_synthesize_batch(C.byref(vd), arr, len(utts), C.byref(opts), ptrs, ns))
+    del keep
+    return out
+
+
+def generator_from_tracks(voice: VoiceInfo, utt: "TrackUtterance", device: int = -1):
+    """jb_generator_new_from_tracks = SpeechGenerator::new on caller-held tracks (speech.rs:25-50); step it with
+    generate_step / generate_steps / generate_all."""
+    from .engine import SpeechGenerator
+
+    L = F.lib()
+    vd, keep = voice.c_struct()
+    arr = (F.TrackUtt * 1)()
+    arr[0] = utt.c_struct()
+    opts = F.BatchOpts()
+    opts.device = device
+    h = C.c_void_p()
+    F.check(L.jb_generator_new_from_tracks(C.byref(vd), arr, C.byref(opts), C.byref(h)))
+    g = SpeechGenerator(h, L)
+    g._keep = (keep, utt)
+    return g
+
+
 def paramgen_vocode_batch(voice: VoiceInfo, utts: Sequence[Utterance], device: int = -1,
                           devices: Optional[Sequence[int]] = None):
     """One-shot jb_paramgen_vocode_batch: returns a list of f64 PCM arrays.  With `devices` the batch

@@ -59,7 +59,9 @@ class Comm:
     def gather_pcm(self, batch, root: int = 0):
         """Collective.  Returns (Gathered on the root / None elsewhere, milliseconds of the exchange)."""
         out, ms = C.c_void_p(), C.c_float()
-        F.check(self._L.jb_gather_pcm(self._h, batch._h, root, C.byref(out), C.byref(ms)))
+        # batch = None: this rank's local work failed; it still joins, and every rank gets an error
+        F.check(self._L.jb_gather_pcm(self._h, batch._h if batch is not None else None, root, C.byref(out),
+                                      C.byref(ms)))
         dt = np.int16 if (batch.flags & F.BATCH_PCM_I16) else np.float64
         return (Gathered(out, self._L, self.n_ranks, dt) if out else None), ms.value
 

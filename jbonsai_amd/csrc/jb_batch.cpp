@@ -559,7 +559,7 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
     return JB_OK;
 }
 
-static int check_voice(const jb_voice_desc *v, bool need_windows = true)
+static int check_voice(const jb_voice_desc *v, bool need_windows = true, bool vocoder_level = false)
 {
     if (!v)
         return JB_ERR_INVALID;
@@ -588,7 +588,11 @@ static int check_voice(const jb_voice_desc *v, bool need_windows = true)
     // SpeechGenerator::new panics on an even LPF length, 0 included (speech.rs:38-40): the ring-buffer-less
     // branch of Excitation::get (excitation.rs:87-100) can be reached through Vocoder::synthesize alone,
     // never through Engine / SpeechGenerator, which is the boundary this library mirrors
-    if (p.vector_length % 2 == 0) {
+    if (p.vector_length % 2 == 0 && !(vocoder_level && p.vector_length == 0)) {
+        if (vocoder_level) { // Vocoder::new takes any nlpf; the kernels here are built for odd counts and for none
+            set_error("an even, non-zero number of low-pass filter coefficients is not supported");
+            return JB_ERR_UNSUPPORTED;
+        }
         set_error("The number of low-pass filter coefficient must be odd numbers."); // speech.rs:38-40
         return JB_ERR_INVALID;
     }
@@ -628,7 +632,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                   Batch **out, const IndexSrc *idx, const TrackSrc *trk)
 {
     *out = nullptr;
-    int rc = check_voice(voice, trk == nullptr);
+    int rc = check_voice(voice, trk == nullptr, trk && trk->vocoder_level);
     if (rc)
         return rc;
     // Parameter tracks as the source (SpeechGenerator::new, src/speech.rs:25-50).  The kernels behind the
@@ -654,7 +658,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                 set_error("The size of lf0 static vector must be 1."); // speech.rs:35-37
                 return JB_ERR_INVALID;
             }
-            if (t.n_lpf && t.lpf_width % 2 == 0) {
+            if (t.n_lpf && t.lpf_width % 2 == 0 && !(trk->vocoder_level && t.lpf_width == 0)) {
                 set_error("The number of low-pass filter coefficient must be odd numbers."); // speech.rs:38-40
                 return JB_ERR_INVALID;
             }
@@ -1023,6 +1027,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     // frames whose excitation is the noise stream itself are not stored (not with the debug tap, which
     // wants every sample, nor with the one-pass kernel for other tap counts / frame periods)
     vd.skip_unvoiced = (!vd.exc && excite_is_split(vd)) ? 1 : 0;
+    if (vd.nlpf == 0 && !mlpg_only && (rc = b->dalloc(&vd.uv_before, std::max<size_t>(nf, 1), false)))
+        return rc; // ring-buffer-less excitation: unvoiced frames before each frame = its place in the noise stream
     if (excite_is_split(vd) && !mlpg_only) {
         // shared pulse-free excitation (jb_device.h): the table, the per-frame source codes, the work list of the
         // per-frame pass.  With the debug tap (every sample wanted as computed per utterance) and on request
@@ -1212,6 +1218,10 @@ int Batch::build_generator_work()
     }
     int rc = dalloc(&gen_work_dev, gw.size(), false);
     if (rc)
+        return rc;
+    // the serially served head goes to a buffer of its own: the whole-utterance run writes the same frames of
+    // vd.pcm meanwhile (and, from the throughput kernel, not bit for bit the same values)
+    if (vd.pcm && (rc = dalloc(&gen_pcm, (size_t)vd.fperiod * 64, false)))
         return rc;
     hipError_t e = hipMemcpy(gen_work_dev, gw.data(), sizeof(VocWork) * gw.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess)
@@ -1652,6 +1662,21 @@ int Batch::sync()
         return rc ? rc : sync();
     }
     return finish_verify();
+}
+
+int Batch::gang_timeout_seen(bool *seen)
+{
+    *seen = false;
+    for (int si = 0; gang_check_pending && si < kMaxStream; si++)
+        if (sd[si].gv_gang_ctl) {
+            uint32_t err = 0;
+            hipError_t e = hipMemcpy(&err, &((GvGangCtl *)sd[si].gv_gang_ctl)->err, sizeof err, hipMemcpyDeviceToHost);
+            if (e != hipSuccess)
+                return hip_fail(e, "hipMemcpy(gv gang err)");
+            if (err)
+                *seen = true;
+        }
+    return JB_OK;
 }
 
 // Every read entry waits for the batch's own streams first (they are non-blocking streams: a plain
@@ -2188,6 +2213,32 @@ int jb_vocode_tracks_batch(const jb_voice_desc *voice, const jb_track_utt *utts,
     if (rc)
         return rc;
     std::unique_ptr<Batch> guard((Batch *)hb);
+    if (n_samples)
+        for (size_t i = 0; i < n; i++)
+            n_samples[i] = jb_batch_num_samples(hb, i);
+    if (!pcm)
+        return JB_OK;
+    if ((rc = guard->run(false)) || (rc = guard->sync()))
+        return rc;
+    for (size_t i = 0; i < n; i++) {
+        size_t ns = jb_batch_num_samples(hb, i);
+        if (ns && (rc = jb_batch_read_pcm(hb, i, pcm[i], ns)))
+            return rc;
+    }
+    return JB_OK;
+}
+
+int jb_vocoder_synthesize_batch(const jb_voice_desc *voice, const jb_track_utt *utts, size_t n,
+                                const jb_batch_opts *opts, double *const *pcm, size_t *n_samples)
+{
+    Batch *b = nullptr;
+    jb::TrackSrc src{utts};
+    src.vocoder_level = true;
+    int rc = Batch::create(voice, nullptr, n, opts, &b, nullptr, &src);
+    if (rc)
+        return rc;
+    std::unique_ptr<Batch> guard(b);
+    jb_batch *hb = (jb_batch *)b;
     if (n_samples)
         for (size_t i = 0; i < n; i++)
             n_samples[i] = jb_batch_num_samples(hb, i);

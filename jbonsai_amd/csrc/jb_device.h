@@ -152,6 +152,9 @@ struct VocDev {
     uint32_t *exc_gen;        // [sumT][2] = (utterance, frame | vcur << 30 | vprev << 31)
     uint32_t *exc_gen_count;  // [1]
     int exc_no_table;         // 1: every frame goes through the per-frame pass (JB_BATCH_NO_EXC_TABLE, debug tap)
+    // nlpf == 0 (Excitation::get without a ring buffer, excitation.rs:87-100: noise is drawn on unvoiced samples
+    // only): unvoiced frames of the utterance before each frame, i.e. its place in the noise stream (k_uv_scan)
+    uint32_t *uv_before;      // [sumT], or nullptr
     double *pcm;          // [sumT*fperiod] f64 PCM, or nullptr when the i16 sink is selected
     int16_t *pcm16;       // [sumT*fperiod] clamped i16 PCM (JB_BATCH_PCM_I16), or nullptr
     double *exc;          // optional [sumT*fperiod] excitation before gain, or nullptr

@@ -1206,6 +1206,9 @@ int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_
     jb_batch_opts opts{};
     opts.device = -1;
     opts.flags = CENG(e)->cond.batch_invariant ? (JB_BATCH_SERIAL | JB_BATCH_SERIAL_GV) : 0;
+    if (const char *ev = getenv("JB_GENERATOR_TEST_GANG_TIMEOUT")) // test aid, as JB_BATCH_TEST_GANG_TIMEOUT
+        if (atoi(ev) != 0)
+            opts.flags |= JB_BATCH_TEST_GANG_TIMEOUT;
     jb::Batch *b = nullptr;
     if ((rc = jb::Batch::create(&CENG(e)->desc, &st.utt, 1, &opts, &b)))
         return rc;
@@ -1214,6 +1217,35 @@ int jb_generator_new(const jb_engine *e, const char *const *lines, size_t n, jb_
     g->total = b->T[0];
     // Engine::generator runs all three MLPGs before returning (src/engine.rs:333-357); here they are
     // enqueued, with the vocoder behind them, and the call returns while the device works
+    if ((rc = b->build_generator_work()) || (rc = b->run(false)))
+        return rc;
+    *out = (jb_generator *)g.release();
+    return JB_OK;
+}
+
+// SpeechGenerator::new(fperiod, vocoder, spectrum, lf0, lpf) on tracks the caller holds (src/speech.rs:25-50),
+// to be stepped with jb_generator_step (generate_step, :65-82): the same three panics as error codes
+int jb_generator_new_from_tracks(const jb_voice_desc *voice, const jb_track_utt *utt, const jb_batch_opts *opts,
+                                 jb_generator **out)
+{
+    if (!voice || !utt || !out)
+        return JB_ERR_INVALID;
+    *out = nullptr;
+    std::unique_ptr<jb::Generator> g(new jb::Generator());
+    jb_batch_opts o{};
+    if (opts)
+        o = *opts;
+    else
+        o.device = -1;
+    o.flags &= ~(uint32_t)(JB_BATCH_PCM_I16 | JB_BATCH_MLPG_ONLY); // generate_step hands out f64 samples
+    jb::Batch *b = nullptr;
+    jb::TrackSrc src{utt};
+    int rc = jb::Batch::create(voice, nullptr, 1, &o, &b, nullptr, &src);
+    if (rc)
+        return rc;
+    g->batch.reset(b);
+    g->fperiod = b->voice.fperiod;
+    g->total = b->T[0];
     if ((rc = b->build_generator_work()) || (rc = b->run(false)))
         return rc;
     *out = (jb_generator *)g.release();
@@ -1260,19 +1292,38 @@ long jb_generator_step(jb_generator *hg, double *buf, size_t buf_len)
     if (!g->ahead_ready) {
         // the utterance is still in flight: this frame from the serial recursion on the side stream
         hipStream_t ss = b->stream_lf0;
+        hipError_t he;
         if (!g->serial_armed) {
-            hipStreamWaitEvent(ss, b->ev_mlpg_done, 0);
-            g->serial_armed = true;
+            // Parameter generation must be complete before a frame is served -- and it is not if the resident GV
+            // kernel gave up in formation (possible without a fault when several such launches share a device:
+            // generators made back to back): the flag is read here, once, not only in Batch::sync, which would
+            // redo the step after the head of the utterance had gone out computed from an unfinished MCP track.
+            if ((he = hipEventSynchronize(b->ev_mlpg_done)) != hipSuccess)
+                return hip_fail(he, "generator: parameter generation");
+            bool timed_out = false;
+            if ((rc = b->gang_timeout_seen(&timed_out)))
+                return rc;
+            if (timed_out) {
+                if ((rc = generator_finish(g))) // sync(): the step again with the multi-launch GV, certified
+                    return rc;
+            } else {
+                g->serial_armed = true;
+            }
         }
-        hipError_t he = launch_vocoder(b->bd, b->vd, b->gen_work_dev + g->next, 1, ss);
-        if (he != hipSuccess)
-            return hip_fail(he, "k_vocoder");
-        if ((he = hipStreamSynchronize(ss)) != hipSuccess)
-            return hip_fail(he, "generator step");
-        if ((rc = b->read(b->vd.pcm + g->next * g->fperiod, buf, g->fperiod * sizeof(double), false)))
-            return rc;
-        g->next++;
-        return (long)g->fperiod;
+        if (g->serial_armed && !g->ahead_ready) {
+            // the serial recursion writes the frame into a buffer of its own (the whole-utterance run is writing
+            // the same frames of the PCM slab, and from the throughput kernel not bit for bit the same values)
+            jb::VocDev vdg = b->vd;
+            vdg.pcm = b->gen_pcm - g->next * g->fperiod; // utterance 0, frame `next` -> gen_pcm[0 .. fperiod)
+            if ((he = launch_vocoder(b->bd, vdg, b->gen_work_dev + g->next, 1, ss)) != hipSuccess)
+                return hip_fail(he, "k_vocoder");
+            if ((he = hipStreamSynchronize(ss)) != hipSuccess)
+                return hip_fail(he, "generator step");
+            if ((rc = b->read(b->gen_pcm, buf, g->fperiod * sizeof(double), false)))
+                return rc;
+            g->next++;
+            return (long)g->fperiod;
+        }
     }
     if (g->next < g->cache_first || g->next >= g->cache_first + g->cache_frames) {
         const size_t nf = std::min(kGenBlockFrames, g->total - g->next);

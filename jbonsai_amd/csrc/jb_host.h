@@ -46,6 +46,10 @@ struct IndexSrc {
 // Parameter tracks as the batch's source (SpeechGenerator::new, src/speech.rs:25-50): no MLPG
 struct TrackSrc {
     const jb_track_utt *utts;
+    // Vocoder::new + Vocoder::synthesize per frame (vocoder/mod.rs:45-72) instead of SpeechGenerator::new:
+    // no check of the LPF length, so nlpf == 0 (the ring-buffer-less branch of Excitation::get,
+    // excitation.rs:87-100) is reachable, as it is in the reference through this seam alone
+    bool vocoder_level = false;
 };
 
 struct Batch {
@@ -103,6 +107,10 @@ struct Batch {
     int upload(const void *host, size_t bytes, const void **dev);
     bool from_tracks = false;        // created from parameter tracks: run() starts at the frame prologue
     bool gang_check_pending = false; // a resident GV kernel has been enqueued since its error flag was last read
+    // the resident GV kernel of the pending run gave up in formation (flag read, not cleared: sync() acts on it);
+    // the caller has waited for ev_mlpg_done
+    int gang_timeout_seen(bool *seen);
+    double *gen_pcm = nullptr;       // PCM of the streaming generator's serially served frames (its own buffer)
     bool last_run_timed = false;
     uint32_t gang_fallbacks = 0;     // times the resident GV kernel timed out in formation and the sweeps took over
     static int create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n,

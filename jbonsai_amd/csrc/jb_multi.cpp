@@ -265,10 +265,18 @@ const Rccl *rccl()
 {
     static const Rccl r = [] {
         Rccl x;
-        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-            x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (x.h)
-                break;
+        // JB_RCCL_LIBRARY = full path of the library to bind instead (a host whose RCCL lives elsewhere; the
+        // test double of tests/fake_rccl, which lets N ranks share one device).  Bound RTLD_LOCAL: its symbols
+        // are only ever reached through this table.
+        if (const char *ov = getenv("JB_RCCL_LIBRARY")) {
+            if (*ov)
+                x.h = dlopen(ov, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+                x.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (x.h)
+                    break;
+            }
         }
         if (!x.h)
             return x;
@@ -399,45 +407,104 @@ void jb_comm_free(jb_comm *c) { delete (jb::Comm *)c; }
 int jb_comm_rank(const jb_comm *c) { return c ? ((const jb::Comm *)c)->rank : -1; }
 int jb_comm_size(const jb_comm *c) { return c ? ((const jb::Comm *)c)->n_ranks : 0; }
 
+// Failure is COLLECTIVE: a rank that cannot contribute (no batch, a batch on another device, a run that failed)
+// still joins the exchange of the counts with a sentinel, and a root that cannot allocate its receive slabs
+// says so in a second one-word exchange -- every rank then leaves with an error instead of one rank returning
+// early and its peers blocking in RCCL for good.  (What cannot be made collective after the fact: an RCCL call
+// that itself fails on one rank.)
 int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float *ms)
 {
     jb::Comm *c = (jb::Comm *)hc;
     jb::Batch *b = (jb::Batch *)hb;
     if (out)
         *out = nullptr;
-    if (!c || !b || !out || root < 0 || root >= c->n_ranks)
+    if (!c || root < 0 || root >= c->n_ranks) // the same answer on every rank of a correct program: before any exchange
         return JB_ERR_INVALID;
-    if (b->device != c->device) {
-        jb::set_error("the batch lives on another device than the communicator");
-        return JB_ERR_INVALID;
-    }
+    constexpr uint64_t kFail = ~0ull, kI16 = 1ull << 62;
+    int local_rc = JB_OK;
+    std::string local_err;
     size_t ns = 0;
-    void *slab = jb_batch_device_pcm(hb, &ns); // waits for the run and its certification
-    if (!slab && ns)
-        return JB_ERR_DEVICE;
-    const size_t elem = (b->flags & JB_BATCH_PCM_I16) ? 2 : 8;
+    void *slab = nullptr;
+    if (!b || !out) {
+        local_rc = JB_ERR_INVALID;
+        local_err = "jb_gather_pcm: no batch / no output handle on this rank";
+    } else if (b->device != c->device) {
+        local_rc = JB_ERR_INVALID;
+        local_err = "the batch lives on another device than the communicator";
+    } else {
+        slab = jb_batch_device_pcm(hb, &ns); // waits for the run and its certification
+        if (!slab && ns) {
+            local_rc = JB_ERR_DEVICE;
+            local_err = std::string("this rank's batch has no PCM to contribute: ") + jb_last_error();
+        }
+    }
+    const size_t elem = (b && (b->flags & JB_BATCH_PCM_I16)) ? 2 : 8;
     hipError_t he = hipSetDevice(c->device);
-    if (he != hipSuccess)
-        return jb::hip_fail(he, "hipSetDevice");
+    if (he != hipSuccess && local_rc == JB_OK) {
+        local_rc = JB_ERR_DEVICE;
+        local_err = std::string("hipSetDevice: ") + hipGetErrorString(he);
+    }
+    if (c->n_ranks == 1) {
+        if (local_rc) {
+            jb::set_error(local_err);
+            return local_rc;
+        }
+        std::unique_ptr<jb::Gathered> g(new jb::Gathered());
+        g->device = c->device;
+        g->n_ranks = 1;
+        g->elem = elem;
+        g->slab.assign(1, slab);
+        g->owned.assign(1, 0);
+        g->samples.assign(1, ns);
+        if (ms)
+            *ms = 0.0f;
+        *out = (jb_gathered *)g.release();
+        return JB_OK;
+    }
+    const jb::Rccl *r = jb::rccl();
+    if (!r) { // cannot happen behind a successful jb_comm_init of more than one rank
+        jb::set_error("RCCL (librccl.so.1) cannot be loaded");
+        return JB_ERR_DEVICE;
+    }
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<uint64_t> counts((size_t)c->n_ranks, 0);
-    counts[(size_t)c->rank] = ns;
-    const jb::Rccl *r = c->n_ranks > 1 ? jb::rccl() : nullptr;
-    if (c->n_ranks > 1) {
-        // every rank learns every slab's length (the root to size its receive buffers, the others
-        // nothing more than that the call is collective)
-        uint64_t mine = ns;
-        if ((he = hipMemcpyAsync(c->counts_dev + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-            return jb::hip_fail(he, "hipMemcpy(count)");
+    // one word per rank: its sample count (bit 62: 16-bit samples), or the sentinel
+    auto exchange = [&](uint64_t mine, std::vector<uint64_t> &all, const char *what) -> int {
+        all.assign((size_t)c->n_ranks, 0);
+        hipError_t e1 = hipMemcpyAsync(c->counts_dev + c->rank, &mine, sizeof mine, hipMemcpyHostToDevice, c->stream);
+        if (e1 != hipSuccess)
+            return jb::hip_fail(e1, what);
         ncclResult_t e = r->AllGather(c->counts_dev + c->rank, c->counts_dev, 1, ncclUint64, c->comm, c->stream);
         if (e != ncclSuccess)
-            return jb::rccl_fail(r, e, "ncclAllGather(counts)");
-        if ((he = hipMemcpyAsync(counts.data(), c->counts_dev, sizeof(uint64_t) * counts.size(), hipMemcpyDeviceToHost,
+            return jb::rccl_fail(r, e, what);
+        if ((e1 = hipMemcpyAsync(all.data(), c->counts_dev, sizeof(uint64_t) * all.size(), hipMemcpyDeviceToHost,
                                  c->stream)) != hipSuccess ||
-            (he = hipStreamSynchronize(c->stream)) != hipSuccess)
-            return jb::hip_fail(he, "count exchange");
+            (e1 = hipStreamSynchronize(c->stream)) != hipSuccess)
+            return jb::hip_fail(e1, what);
+        return JB_OK;
+    };
+    std::vector<uint64_t> words, status;
+    int rc = exchange(local_rc ? kFail : ((uint64_t)ns | (elem == 2 ? kI16 : 0)), words, "ncclAllGather(counts)");
+    if (rc)
+        return rc;
+    for (int p = 0; p < c->n_ranks; p++)
+        if (words[(size_t)p] == kFail) {
+            if (local_rc) {
+                jb::set_error(local_err + " (the gather was abandoned on every rank)");
+                return local_rc;
+            }
+            jb::set_error("rank " + std::to_string(p) + " could not contribute its PCM: the gather was abandoned on every rank");
+            return JB_ERR_DEVICE;
+        }
+    std::vector<uint64_t> counts((size_t)c->n_ranks);
+    bool mixed = false;
+    for (int p = 0; p < c->n_ranks; p++) {
+        counts[(size_t)p] = words[(size_t)p] & ~kI16;
+        if (counts[(size_t)p] && ((words[(size_t)p] & kI16) != 0) != (elem == 2) && ns)
+            mixed = true; // f64 and 16-bit slabs in one gather
     }
+    // the root's receive slabs, then one more word from everybody: can the transfer start?
     std::unique_ptr<jb::Gathered> g;
+    uint64_t my_status = mixed ? 2 : 0;
     if (c->rank == root) {
         g.reset(new jb::Gathered());
         g->device = c->device;
@@ -446,17 +513,30 @@ int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float 
         g->slab.assign((size_t)c->n_ranks, nullptr);
         g->owned.assign((size_t)c->n_ranks, 0);
         g->samples.assign(counts.begin(), counts.end());
-        for (int p = 0; p < c->n_ranks; p++) {
+        for (int p = 0; p < c->n_ranks && !my_status; p++) {
             if (p == root) {
                 g->slab[(size_t)p] = slab; // no copy: valid while the batch lives
             } else if (counts[(size_t)p]) {
-                if ((he = hipMalloc(&g->slab[(size_t)p], counts[(size_t)p] * elem)) != hipSuccess)
-                    return jb::hip_fail(he, "hipMalloc(gather)");
-                g->owned[(size_t)p] = 1;
+                if ((he = hipMalloc(&g->slab[(size_t)p], counts[(size_t)p] * elem)) != hipSuccess) {
+                    (void)hipGetLastError();
+                    my_status = 1;
+                } else {
+                    g->owned[(size_t)p] = 1;
+                }
             }
         }
     }
-    if (c->n_ranks > 1) {
+    if ((rc = exchange(my_status, status, "ncclAllGather(status)")))
+        return rc;
+    for (int p = 0; p < c->n_ranks; p++)
+        if (status[(size_t)p]) {
+            jb::set_error(status[(size_t)p] == 2
+                              ? "f64 and 16-bit PCM slabs in one gather: the gather was abandoned on every rank"
+                              : "rank " + std::to_string(p) +
+                                    " (the root) could not allocate its receive slabs: the gather was abandoned on every rank");
+            return status[(size_t)p] == 2 ? JB_ERR_INVALID : JB_ERR_DEVICE;
+        }
+    {
         ncclResult_t e = r->GroupStart();
         if (e != ncclSuccess)
             return jb::rccl_fail(r, e, "ncclGroupStart");
@@ -467,7 +547,7 @@ int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float 
         } else if (ns) {
             e = r->Send(slab, ns * elem, ncclUint8, root, c->comm, c->stream);
         }
-        ncclResult_t e2 = r->GroupEnd();
+        ncclResult_t e2 = r->GroupEnd(); // always: a group left open would take the next call with it
         if (e != ncclSuccess || e2 != ncclSuccess)
             return jb::rccl_fail(r, e != ncclSuccess ? e : e2, "ncclSend/ncclRecv");
         if ((he = hipStreamSynchronize(c->stream)) != hipSuccess)

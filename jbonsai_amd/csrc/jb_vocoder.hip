@@ -478,6 +478,50 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     vd.xin[base * (uint64_t)fp + n] = x;
 }
 
+// nlpf == 0: the ring-buffer-less branch of Excitation::get (excitation.rs:87-100), reachable through
+// Vocoder::synthesize alone (SpeechGenerator::new refuses an even LPF length).  Unvoiced samples take the next
+// value of the noise stream -- which is drawn on unvoiced samples only, so the stream position of a frame is
+// fperiod times the number of unvoiced frames before it --, voiced samples are the bare pulse, no delay.
+__global__ __launch_bounds__(64) void k_uv_scan(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const UttDev *u = bd.utt + b;
+    const uint64_t base = u->frame_off;
+    uint32_t acc = 0;
+    for (uint32_t t0 = 0; t0 < u->T; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        const bool uv = t < u->T && vd.pitch[base + t] == 0.0;
+        const unsigned long long m = __ballot(uv);
+        if (t < u->T)
+            vd.uv_before[base + t] = acc + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        acc += (uint32_t)__popcll(m);
+    }
+}
+__global__ __launch_bounds__(256) void k_excite_nolpf(BatchDev bd, VocDev vd)
+{
+    const int b = blockIdx.y;
+    const UttDev *u = bd.utt + b;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk;
+    const uint64_t N = (uint64_t)u->T * (uint64_t)fp;
+    const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N)
+        return;
+    const uint64_t base = u->frame_off;
+    const uint32_t fr = (uint32_t)(n / (uint64_t)fp);
+    const int i = (int)(n - (uint64_t)fr * (uint64_t)fp);
+    const uint64_t f = base + fr;
+    double x;
+    if (vd.pitch[f] != 0.0) {
+        const unsigned long long pm = vd.pmask[f * (uint64_t)nblk + (uint64_t)(i / bs)];
+        x = ((pm >> (i % bs)) & 1ull) ? sqrt(fma((double)i, vd.pinc[f], vd.cur_start[f])) : 0.0;
+    } else {
+        x = vd.noise[(uint64_t)vd.uv_before[f] * (uint64_t)fp + (uint64_t)i];
+    }
+    if (vd.exc)
+        vd.exc[base * (uint64_t)fp + n] = x;
+    vd.xin[base * (uint64_t)fp + n] = x;
+}
+
 // Split excitation, ONE WAVE PER FRAME with FOUR CONSECUTIVE SAMPLES PER LANE (fperiod % 4 == 0,
 // fperiod <= 256, nlpf <= 33).  k_excite above reads e[] and two tap sets from LDS for every
 // (sample, tap): ~93 LDS reads per sample, which made it LDS-bound (21 ms at config 2).  Here a
@@ -1801,6 +1845,13 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
     }
     const uint64_t maxN = (uint64_t)bd.maxT * (uint64_t)vd.fperiod;
     dim3 grid((unsigned)((maxN + kExcBlock - 1) / kExcBlock), bd.B), block(kExcBlock);
+    if (vd.nlpf == 0) {
+        if (!vd.uv_before)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_uv_scan, dim3(bd.B), dim3(64), 0, stream, bd, vd);
+        hipLaunchKernelGGL(k_excite_nolpf, grid, block, 0, stream, bd, vd);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_excite, grid, block, 0, stream, bd, vd);
     return hipGetLastError();
 }
