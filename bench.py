@@ -687,6 +687,62 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
         b16.close()
     except Exception as e:  # a secondary record must not cost the headline
         ex["d2h_inclusive"] = {"error": repr(e)}
+    # (1b) host-visible throughput (Engine::synthesize hands PCM to the host, src/engine.rs:294): two batches
+    #      alternating, the staged D2H of step k's PCM (its own copy stream, a reader thread) running beside the GPU
+    #      work of step k + 1.  16-bit sink: the 3.1 GB copy is shorter than a step and hides behind it; f64: 12.6 GB
+    #      over the link take longer than a step, so the link rate is the bound -- both stated.
+    def host_visible(dtype, i16):
+        import threading
+
+        pair = [J.Batch(vi, batch_utts, device=R.local_rank, pcm_i16=i16) for _ in range(2)]
+        try:
+            bufs = [[np.empty(b_.num_samples(i), dtype=dtype) for i in range(len(b_))] for b_ in pair]
+            for b_, bf in zip(pair, bufs):  # warm-up: pages touched, pools filled
+                b_.run()
+                b_.pcm_all(bf)
+            errs = []
+
+            def read(j):
+                try:
+                    pair[j].pcm_all(bufs[j])  # waits for that batch's step and its certification, then copies
+                except Exception as e:  # noqa: BLE001
+                    errs.append(repr(e))
+
+            nst = 6
+            readers = [None, None]
+            t0 = time.perf_counter()
+            for k in range(nst):
+                j = k % 2
+                if readers[j] is not None:
+                    readers[j].join()  # the slab of this batch has been read: it may be overwritten
+                pair[j].run()
+                if k >= 1:
+                    readers[1 - j] = threading.Thread(target=read, args=(1 - j,))
+                    readers[1 - j].start()
+            last = (nst - 1) % 2
+            if readers[1 - last] is not None:
+                readers[1 - last].join()
+            read(last)
+            dt = (time.perf_counter() - t0) / nst * 1e3
+            if errs:
+                raise RuntimeError(errs[0])
+            nbytes = sum(b.nbytes for b in bufs[0])
+            return {"ms_per_step": dt, "value": batch.total_samples / (dt * 1e-3), "unit": "samples/s on the host",
+                    "bytes_per_step": nbytes, "link_GBps_if_link_bound": nbytes / dt / 1e6, "steps": nst,
+                    "how": "two batches alternate; D2H of step k on a copy stream beside the GPU work of step k+1"}
+        finally:
+            for b_ in pair:
+                b_.close()
+
+    try:
+        ex["host_visible"] = {"i16": host_visible(np.int16, True)}
+        if host_mem_ok(3 * batch.total_samples * 8):
+            ex["host_visible"]["f64"] = host_visible(np.float64, False)
+            ex["host_visible"]["f64"]["note"] = "12.6 GB per step over PCIe: link-bound (the copy is longer than a step)"
+        else:
+            ex["host_visible"]["f64"] = {"skipped": "host memory too small for two f64 PCM sets"}
+    except Exception as e:
+        ex.setdefault("host_visible", {})["error"] = repr(e)
     # (2) config 2 with 64 DISTINCT utterances tiled over the batch: real hand-off failures and redo
     try:
         nd = 64
