@@ -46,7 +46,6 @@ FLOP_PER_SAMPLE = 1.39e3      # algorithmic f64 flops per output sample (SURVEY.
 # FP64 vector peak = half the guide's 157.3 TFLOPS FP32 vector rate (1024 SIMDs x 16 lanes x 2 flop x
 # 2.4 GHz); tools/microbench/f64_rate.hip sustains 68 TFLOP/s of dependent-free v_fma_f64 on this part
 FP64_VALU_PEAK_TFLOPS = 78.6
-DEFAULT_CU_SPLIT = 0  # CU partition off: measured slower at every split
 VOICE = ROOT / "tests" / "golden" / "voice" / "nitech_jp_atr503_m001.htsvoice"
 CONFIG3_UTTS = 4096           # BASELINE config 3: "Batch=4096 mixed-length synthetic ... sequences"
 SUB_BATCH_FRAMES = 7_000_000  # frames per sub-batch of the config-3 job (config 2 is 6.54 M: ~62 GB of HBM)
@@ -68,10 +67,6 @@ def parse_args():
                     help="skip the secondary measurements appended to the default line (distinct utterances, "
                          "D2H-inclusive, labels -> PCM, configs 4 and 5 at batch 1024, the config-3 job); none of "
                          "them enters `value`")
-    ap.add_argument("--cu-split", type=int, default=-1,
-                    help="CUs per XCD (of 32) given to parameter generation when two batches are in "
-                         "flight; the vocoder gets the rest (jb_batch_opts.mlpg_cus_per_xcd); "
-                         "-1 = default (0 with --pipeline 1)")
     ap.add_argument("--distinct", type=int, default=1,
                     help="number of DISTINCT synthetic utterances tiled over the batch (default 1 = BASELINE "
                          "config 2's copies of one utterance); >1 shows the cost of real hand-off failures")
@@ -935,13 +930,12 @@ def run_rank(args):
     nd = max(1, min(args.distinct, args.batch))
     utts = [utt] + [synth.synth_utterance(tab, frames, 1000 + i) for i in range(1, nd)]
     depth = max(1, args.pipeline)
-    cu_split = args.cu_split if args.cu_split >= 0 else (DEFAULT_CU_SPLIT if depth > 1 else 0)
     if args.mixed:
         lens = synth.mixed_lengths(args.batch, seed=3 + R.rank)
         batch_utts = [synth.synth_utterance(tab, T, 2000 + i) for i, T in enumerate(lens)]
     else:
         batch_utts = [utts[i % nd] for i in range(args.batch)]
-    batches = [J.Batch(vi, batch_utts, device=R.local_rank, mlpg_cus_per_xcd=cu_split) for _ in range(depth)]
+    batches = [J.Batch(vi, batch_utts, device=R.local_rank) for _ in range(depth)]
     batch = batches[0]
     samples_per_step = batch.total_samples
 
@@ -990,7 +984,7 @@ def run_rank(args):
                              "utterance from real nitech pdfs (BASELINE config 2), nitech voice"),
                 "batch_per_gpu": args.batch, "frames_per_utterance": frames,
                 "samples_per_step_per_gpu": samples_per_step, "parallelism": f"utterance-sharded x{R.world}",
-                "batches_in_flight": depth, "mlpg_cus_per_xcd": cu_split, "distinct_utterances": nd,
+                "batches_in_flight": depth, "distinct_utterances": nd,
                 "beta": args.beta,
                 "chunks_settled_at_checkpoint_last_step": redo_stats[0],
                 "vocoder_chunk_frames": info["chunk_frames"], "vocoder_warmup_frames": info["warmup_frames"],

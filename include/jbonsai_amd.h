@@ -100,16 +100,9 @@ typedef struct jb_batch_opts {
     uint32_t chunk_frames;  /* vocoder time-chunk length in frames; 0 = auto */
     uint32_t warmup_frames; /* frames each chunk starts early from zero state; 0 = default (18) */
     double verify_tol;      /* chunk hand-off check: max|state diff| <= tol*max|state|; 0 = default (1e-9) */
-    uint32_t mlpg_cus_per_xcd; /* CU partition for batches in flight (below); 0 = none */
+    uint32_t reserved0;     /* must be 0 (rounds 1-3: mlpg_cus_per_xcd, a CU partition that lost at every split; removed) */
     uint32_t reserved;
 } jb_batch_opts;
-
-/* CU partition.  The vocoder is FP64-VALU bound and moves little data; parameter generation is HBM-
- * traffic bound and needs few VALU cycles.  With mlpg_cus_per_xcd = k (1..31) the batch's parameter
- * generation streams are confined to k CUs of each of the 8 XCDs and its vocoder stream to the other
- * 32-k (hipExtStreamCreateWithCUMask; mask bit i = XCD i%8, CU i/8), so that with TWO batches in
- * flight one batch's vocoder and the other's parameter generation run side by side instead of
- * taking turns.  A single batch in flight only loses CUs this way: leave it 0. */
 
 #define JB_BATCH_KEEP_TRACKS 1u  /* keep MLPG parameter tracks readable (tests) */
 #define JB_BATCH_GENERIC_MLPG 2u /* un-fused, reference-shaped MLPG kernels (A/B parity tests) */
@@ -517,7 +510,7 @@ JB_LAYOUT_ASSERT(sizeof(jb_stream_states) == 64 && offsetof(jb_stream_states, gv
 JB_LAYOUT_ASSERT(sizeof(jb_state_utt) == 208 && offsetof(jb_state_utt, durations) == 8 &&
                      offsetof(jb_state_utt, stream) == 16, "jb_state_utt");
 JB_LAYOUT_ASSERT(sizeof(jb_batch_opts) == 32 && offsetof(jb_batch_opts, verify_tol) == 16 &&
-                     offsetof(jb_batch_opts, mlpg_cus_per_xcd) == 24, "jb_batch_opts");
+                     offsetof(jb_batch_opts, reserved0) == 24, "jb_batch_opts");
 JB_LAYOUT_ASSERT(sizeof(jb_pdf_table) == 16 && offsetof(jb_pdf_table, n_rows) == 8, "jb_pdf_table");
 JB_LAYOUT_ASSERT(sizeof(jb_index_stream) == 112 && offsetof(jb_index_stream, weight) == 64 &&
                      offsetof(jb_index_stream, gv_weight) == 96, "jb_index_stream");

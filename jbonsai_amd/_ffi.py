@@ -124,7 +124,7 @@ class TrackUtt(C.Structure):
 
 class BatchOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("flags", C.c_uint32), ("chunk_frames", C.c_uint32),
-                ("warmup_frames", C.c_uint32), ("verify_tol", C.c_double), ("mlpg_cus_per_xcd", C.c_uint32), ("reserved", C.c_uint32)]
+                ("warmup_frames", C.c_uint32), ("verify_tol", C.c_double), ("reserved0", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 # every symbol include/jbonsai_amd.h declares (checked by tests/test_abi.py)

@@ -203,7 +203,7 @@ class Batch:
                  keep_tracks: bool = False, generic_mlpg: bool = False, serial: bool = False,
                  chunk_frames: int = 0, warmup_frames: int = 0, verify_tol: float = 0.0,
                  kernel: str = "auto", serial_gv: bool = False, pcm_i16: bool = False,
-                 mlpg_cus_per_xcd: int = 0, pdf_set: Optional[PdfSet] = None, mlpg_only: bool = False,
+                 pdf_set: Optional[PdfSet] = None, mlpg_only: bool = False,
                  test_gang_timeout: bool = False, no_exc_table: bool = False):
         L = F.lib()
         self._L = L
@@ -224,7 +224,6 @@ class Batch:
                       | (F.BATCH_NO_EXC_TABLE if no_exc_table else 0)
                       | {"auto": 0, "wave": F.BATCH_WAVE_KERNEL, "triple": F.BATCH_LANE_KERNEL}[kernel])
         opts.chunk_frames, opts.warmup_frames, opts.verify_tol = chunk_frames, warmup_frames, verify_tol
-        opts.mlpg_cus_per_xcd = mlpg_cus_per_xcd
         self.flags, self.device = opts.flags | (F.BATCH_KEEP_TRACKS if mlpg_only else 0), device
         h = C.c_void_p()
         if from_tracks:

@@ -220,8 +220,14 @@ void pool_free(int device, void *p, size_t bytes)
 // library asks for 16 when it is loaded, unless the variable is already set; it has to happen before the
 // process's first HIP call, which is why this is a load-time constructor and not something jb_engine_load does
 // (a host that initialises HIP before loading the library sets GPU_MAX_HW_QUEUES itself: INTEGRATION.md).
+// Opt-out: JB_LEAVE_HIP_ENV=1 -- the library then changes nothing in the process's environment (a host that
+// manages HIP's settings itself, or that loads the library into a process whose other threads may be reading the
+// environment: glibc's setenv is not safe against a concurrent getenv).
 __attribute__((constructor)) static void jb_ask_for_hw_queues()
 {
+    const char *leave = getenv("JB_LEAVE_HIP_ENV");
+    if (leave && atoi(leave) != 0)
+        return;
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
 }
 
@@ -258,31 +264,6 @@ void stream_release(int device, hipStream_t st)
     hipStreamDestroy(st);
 }
 
-// CU-masked streams (jb_batch_opts.mlpg_cus_per_xcd) are kept too, per (device, CUs per XCD, side), and NEVER
-// destroyed: hipStreamDestroy of a stream made by hipExtStreamCreateWithCUMask does not return every time on
-// this stack (ROCm 7.2: the close of a partitioned batch hung in it in 7 of 14 runs of one test; the work on the
-// stream had long finished).  A process uses a handful of splits at most; the queues die with it.
-std::map<std::tuple<int, int, int>, std::vector<hipStream_t>> g_masked_streams; // guarded by g_pool_mu
-
-hipError_t masked_stream_acquire(int device, int cus, int side, const uint32_t *mask, hipStream_t *st)
-{
-    {
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto &v = g_masked_streams[std::make_tuple(device, cus, side)];
-        if (!v.empty()) {
-            *st = v.back();
-            v.pop_back();
-            return hipSuccess;
-        }
-    }
-    return hipExtStreamCreateWithCUMask(st, 8, mask);
-}
-
-void masked_stream_release(int device, int cus, int side, hipStream_t st)
-{
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    g_masked_streams[std::make_tuple(device, cus, side)].push_back(st);
-}
 } // namespace
 
 void release_cached_memory()
@@ -347,19 +328,11 @@ Batch::~Batch()
     for (hipEvent_t ev : {ev_mlpg_done, ev_voc_done})
         if (ev)
             hipEventDestroy(ev);
-    auto drop = [&](hipStream_t st, int side) {
-        if (cu_split)
-            masked_stream_release(device, cu_split, side, st);
-        else
-            stream_release(device, st);
-    };
     for (hipStream_t st : {stream_lf0, stream_lpf})
         if (st && st != stream)
-            drop(st, 0);
-    if (stream_voc && stream_voc != stream)
-        drop(stream_voc, 1);
+            stream_release(device, st);
     if (stream)
-        drop(stream, 0);
+        stream_release(device, stream);
 }
 
 template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
@@ -729,35 +702,23 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->voice = *voice;
     // (stream priorities were tried for the critical path and made every latency-bound kernel
     // 2-4x slower on this stack; ordering is done with events instead)
-    b->cu_split = opts ? opts->mlpg_cus_per_xcd : 0;
-    if (b->cu_split > 31) {
-        set_error("mlpg_cus_per_xcd must be 0..31");
-        return JB_ERR_INVALID;
+    if (opts && opts->reserved0) {
+        // (rounds 1-3 had a CU partition here, hipExtStreamCreateWithCUMask streams for parameter generation and
+        // vocoder: it lost at every split and its streams could not be destroyed reliably; removed in round 4)
+        set_error("jb_batch_opts.reserved0 must be 0 (the CU partition of earlier versions was removed)");
+        return JB_ERR_UNSUPPORTED;
     }
-    // CU masks (256 CUs = 8 XCDs x 32; bit i = XCD i%8, CU i/8): parameter generation on CU
-    // indices [32-k, 32) of every XCD, the vocoder on [0, 32-k)
-    uint32_t mask_pg[8] = {0}, mask_voc[8] = {0};
-    for (uint32_t i = 0; i < 256; i++)
-        ((i / 8 >= 32 - b->cu_split) ? mask_pg : mask_voc)[i / 32] |= 1u << (i % 32);
-    auto mkstream = [&](hipStream_t *st, const uint32_t *mask) {
-        return b->cu_split ? masked_stream_acquire(b->device, b->cu_split, 0, mask, st) : stream_acquire(b->device, st);
-    };
-    e = mkstream(&b->stream, mask_pg);
+    e = stream_acquire(b->device, &b->stream);
     if (e != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
     // JB_ONE_STREAM=1 (profiling aid): the three parameter-generation chains run back to back
     // on the main stream, so that per-kernel durations are free of overlap effects
     if (getenv("JB_ONE_STREAM") && atoi(getenv("JB_ONE_STREAM")) != 0) {
         b->stream_lf0 = b->stream_lpf = b->stream;
-    } else if ((e = mkstream(&b->stream_lf0, mask_pg)) != hipSuccess ||
-               (e = mkstream(&b->stream_lpf, mask_pg)) != hipSuccess)
+    } else if ((e = stream_acquire(b->device, &b->stream_lf0)) != hipSuccess ||
+               (e = stream_acquire(b->device, &b->stream_lpf)) != hipSuccess)
         return hip_fail(e, "hipStreamCreate");
-    if (b->cu_split) {
-        if ((e = masked_stream_acquire(b->device, b->cu_split, 1, mask_voc, &b->stream_voc)) != hipSuccess)
-            return hip_fail(e, "hipExtStreamCreateWithCUMask");
-    } else {
-        b->stream_voc = b->stream;
-    }
+    b->stream_voc = b->stream;
     hipEventCreateWithFlags(&b->ev_mlpg_done, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_voc_done, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming);
@@ -940,7 +901,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                 // resident GV (one persistent launch, jb_gv_gang.hip) unless the CUs are partitioned (its
                 // grid is sized for the whole device) or a row has more tiles than a gang can hold
                 int tiles = 0, gangs = 0;
-                if (!b->cu_split && maxT > 0 &&
+                if (maxT > 0 &&
                     gv_gang_plan(dev, maxT, (uint32_t)nbl, &tiles, &gangs)) {
                     uint8_t *ctl;
                     if ((rc = b->dalloc(&ctl, gv_gang_ctl_bytes(gangs), true)))
@@ -1093,7 +1054,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = 0;
     } else if (ch == 0 && lp_mode) {
         // two waves on every SIMD the vocoder may use: 8 XCDs x (32 - k) CUs x 4 SIMDs x 2
-        const uint64_t target = 64ull * (32 - cu_split) * (uint64_t)vocoder_ls_chunks_per_wave();
+        const uint64_t target = 64ull * 32 * (uint64_t)vocoder_ls_chunks_per_wave();
         uint64_t c = (sumT + target - 1) / target;
         // while the batch cannot fill the chip the time of the launch is that of ONE chunk (chunk +
         // warm-up frames): chunks down to 16 frames.  Shorter chunks mean more hand-off positions and

@@ -193,7 +193,8 @@ struct VocWork {
 };
 // A failing chunk is first recomputed only up to VocDev::ckpt_frames frames past its start; if the
 // recomputed state meets the checkpoint the original chunk left there, the rest of the chunk stands.
-// 48 frames for chunks of 96 frames and more, 24 for chunks of 40 to 95, none below.
+// 48 frames into chunks of 96 frames and more, 24 into chunks of 36 to 95, 16 into chunks of 24 to 35, none below
+// (Batch::build_work).
 constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16;
 
 // Timing experiments only (library built with -DJB_DBG_GATES, never the product): JB_DBG_SKIP is a bit mask of

@@ -427,7 +427,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                     dp[i * ns + s] = {tmp[s], tmp[s + ns]};
             }
         });
-            if (S) {
+        if (S) {
             if (c.phoneme_alignment) {
                 // create_with_alignment (duration.rs:41-65)
                 size_t frame_count = 0, next_state = 0, state = 0, nd = 0;
@@ -456,7 +456,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                 }
             }
         }
-            st.utt.num_states = (uint32_t)S;
+        st.utt.num_states = (uint32_t)S;
         st.utt.durations = st.dur.data();
         // Models::stream / gv (model/mod.rs:98-146)
         for (size_t si = 0; si < v0.streams.size() && si < (size_t)kMaxStream; si++) {
@@ -489,28 +489,28 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                     io.row[v] = st.rows[si][v].data();
                 io.weight = st.weights[si].data();
             } else {
-            st.mean[si].assign(S * WL, 0.0);
-            st.var[si].assign(S * WL, 0.0);
-            st.msd[si].assign(S, DBL_MAX);
-            parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
-                std::vector<double> buf(plen);
-                QuestionMemo memo;
-                for (size_t i = lo; i < hi; i++) {
-                    memo.reset();
-                    for (size_t s = 0; s < ns; s++) {
-                        blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
-                            return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i], &memo);
-                        });
-                        const size_t row = i * ns + s;
-                        std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
-                        std::copy(buf.begin() + WL, buf.begin() + 2 * WL, st.var[si].begin() + row * WL);
-                        if (sm.is_msd)
-                            st.msd[si][row] = buf[2 * WL];
+                st.mean[si].assign(S * WL, 0.0);
+                st.var[si].assign(S * WL, 0.0);
+                st.msd[si].assign(S, DBL_MAX);
+                parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
+                    std::vector<double> buf(plen);
+                    QuestionMemo memo;
+                    for (size_t i = lo; i < hi; i++) {
+                        memo.reset();
+                        for (size_t s = 0; s < ns; s++) {
+                            blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
+                                return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i], &memo);
+                            });
+                            const size_t row = i * ns + s;
+                            std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
+                            std::copy(buf.begin() + WL, buf.begin() + 2 * WL, st.var[si].begin() + row * WL);
+                            if (sm.is_msd)
+                                st.msd[si][row] = buf[2 * WL];
+                        }
                     }
-                }
-            });
+                });
             }
-                    jb_stream_states &o = st.utt.stream[si];
+            jb_stream_states &o = st.utt.stream[si];
             o.mean = st.mean[si].data();
             o.var = st.var[si].data();
             o.msd = sm.is_msd ? st.msd[si].data() : nullptr;

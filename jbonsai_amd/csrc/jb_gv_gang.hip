@@ -324,9 +324,34 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
 #if JB_GG_PROFILE
         const long long tx0_ = clock64();
 #endif
+#if JB_GG_XCHG == 0
+        // timing experiment only (wrong sums): no traffic between the workgroups, every tile stands for all
+        if (wv == 0) {
+            if (lane == 0 && from_red) {
+                v0 = red[kbar & 1][0][0];
+                v1 = red[kbar & 1][0][1];
+                v2 = red[kbar & 1][0][2];
+                for (int w = 1; w < kGgWaves; w++) {
+                    v0 += red[kbar & 1][w][0];
+                    v1 += red[kbar & 1][w][1];
+                    v2 += red[kbar & 1][w][2];
+                }
+            }
+            v0 = gg_uni(v0); v1 = gg_uni(v1); v2 = gg_uni(v2); v3 = gg_uni(v3);
+            if (lane < NTg) {
+                recs[lane][0] = v0; recs[lane][1] = v1; recs[lane][2] = v2; recs[lane][3] = v3;
+            }
+            if (lane == 0)
+                sh_i[0] = 1;
+        }
+        if (false) {
+            typedef unsigned long long u64;
+            unsigned long long *slot = &G->rec[kbar & 1][0][0];
+#else
         if (wv == 0) {
             typedef unsigned long long u64;
             unsigned long long *slot = &G->rec[kbar & 1][0][0];
+#endif
             const u64 tagbase = 0x9E3779B97F4A7C15ull * (u64)(kbar + 1u);
             if (lane == 0) {
                 if (from_red) {
@@ -435,6 +460,9 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
     if (dead)
         return;
     uint32_t row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs[0][3]);
+#if JB_GG_XCHG == 0
+    row = (uint32_t)gang; // (timing experiment: no queue, gang g takes rows g, g + n_gangs, ...)
+#endif
 
     // Everything a row needs from the descriptor tables (a chain of four dependent scalar loads: launch
     // order -> utterance -> stream states -> GV pdf) is fetched one row ahead, while the current row's
@@ -467,7 +495,13 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
     };
     RowInfo cur = row_info(row), ahead{};
 
+#if JB_GG_XCHG == 0
+    uint32_t row_prev_ = row;
+#endif
     while (row < total_rows) {
+#if JB_GG_XCHG == 0
+        row_prev_ = row;
+#endif
         const uint32_t n = cur.n, gvl = cur.gvl;
         // the next row's number rides on this row's first exchange
         nxt = 0.0;
@@ -478,6 +512,10 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
             if (dead)
                 return;
             row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs[0][3]);
+#if JB_GG_XCHG == 0
+            row = row_prev_ + (uint32_t)n_gangs;
+            row_prev_ = row;
+#endif
             cur = row_info(row);
             continue;
         }
@@ -641,6 +679,9 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
                 return;
             if (it == 0) {
                 next_row = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)recs[0][3]);
+#if JB_GG_XCHG == 0
+                next_row = row + (uint32_t)n_gangs;
+#endif
                 ahead = row_info(next_row);
             }
             double S1, S2, H;

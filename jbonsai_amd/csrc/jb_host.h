@@ -58,9 +58,8 @@ struct Batch {
     int B = 0;
     jb_voice_desc voice{};
     hipStream_t stream = nullptr;            // main: MCP chain (and the vocoder unless CUs are partitioned)
-    hipStream_t stream_voc = nullptr;        // vocoder + hand-off check (== stream without a CU partition)
+    hipStream_t stream_voc = nullptr;        // vocoder + hand-off check (== stream)
     hipEvent_t ev_mlpg_done = nullptr, ev_voc_done = nullptr;
-    uint32_t cu_split = 0;                   // CUs per XCD given to parameter generation (0 = no partition)
     hipStream_t stream_lf0 = nullptr, stream_lpf = nullptr; // concurrent parameter-generation chains
     hipEvent_t ev_fork = nullptr, ev_lf0 = nullptr, ev_lpf = nullptr, ev_prep = nullptr, ev_build = nullptr, ev_mcpbuild = nullptr, ev_ivar = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;

@@ -324,23 +324,25 @@ def test_device_pcm_slab_as_torch_tensor(have_gpu):
     assert r.returncode == 0 and "slab ok" in r.stdout, r.stdout + r.stderr
 
 
-def test_cu_partition_gives_identical_pcm(oracle_voice, have_gpu):
-    """jb_batch_opts.mlpg_cus_per_xcd: parameter generation and vocoder on disjoint CU sets
-    (masked streams, separate vocoder stream).  Scheduling only: the PCM must not depend on the
-    split.  (A partitioned batch keeps the multi-launch GV sweeps -- the resident GV kernel sizes its
-    grid for the whole device -- whose sums have another fixed shape: against the unpartitioned
-    batch the PCM agrees to rounding, not bitwise.)"""
+def test_removed_cu_partition_field_must_be_zero(oracle_voice, have_gpu):
+    """jb_batch_opts.reserved0 was mlpg_cus_per_xcd in rounds 1-3 (a CU partition that lost at every split and
+    whose masked streams could not be destroyed reliably; removed in round 4): a caller that still sets it is
+    told so instead of silently running unpartitioned."""
+    import ctypes as C
+
+    from jbonsai_amd import _ffi as F
+
     v = oracle_voice
     d1, s1 = oracle_states(v, SAMPLE_SENTENCE_1)
-    d2, s2 = oracle_states(v, SAMPLE_SENTENCE_2)
-    utts = [to_utt(d2, s2), to_utt(d1, s1)] * 3
-    ref, _ = _run(v, utts, chunk_frames=64, kernel="triple")
-    first = None
-    for k in (8, 31):
-        got, info = _run(v, utts, chunk_frames=64, kernel="triple", mlpg_cus_per_xcd=k)
-        assert info["n_redo"] == 0
-        if first is None:
-            first = got
-        for a, b, c in zip(ref, got, first):
-            assert np.array_equal(b, c)
-            assert rel_rms(b, a) <= 1e-12
+    u = to_utt(d1, s1)
+    vd, keep = voice_info(v).c_struct()
+    arr = (F.StateUtt * 1)()
+    arr[0] = u.c_struct()
+    opts = F.BatchOpts()
+    opts.device, opts.reserved0 = -1, 8
+    h = C.c_void_p()
+    assert F.lib().jb_batch_create(C.byref(vd), arr, 1, C.byref(opts), C.byref(h)) == -2  # JB_ERR_UNSUPPORTED
+    opts.reserved0 = 0
+    assert F.lib().jb_batch_create(C.byref(vd), arr, 1, C.byref(opts), C.byref(h)) == 0
+    F.lib().jb_batch_free(h)
+    del keep

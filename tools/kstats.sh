@@ -1,6 +1,9 @@
 #!/bin/bash
 # rocprofv3 kernel trace of one default bench run; prints per-kernel totals (ms) for the timed steps.
 cd "$(dirname "$0")/.."
+# (refuse --gpus: bench.py would become a launcher that starts its ranks from a process the profiler has
+#  already initialised the GPU in -- the hop behind `--` that must not happen on this pool; profile one rank)
+case " $BENCH_ARGS $* " in *" --gpus "*) echo "profile a single rank: no --gpus under rocprofv3"; exit 2;; esac
 export TMPDIR=/tmp
 out=gpurun_out/kstats
 rm -rf $out; mkdir -p $out

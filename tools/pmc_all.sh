@@ -3,6 +3,9 @@
 # which unit could bound a kernel?  scalar ALU: one per CU (256); VALU: one per SIMD (1024); LDS: one per CU;
 # then the memory side: TLB misses, L2 hit rate, mean latency of a vector-L1 read request, address-unit busy.
 cd "$(dirname "$0")/.."
+# (refuse --gpus: bench.py would become a launcher that starts its ranks from a process the profiler has
+#  already initialised the GPU in -- the hop behind `--` that must not happen on this pool; profile one rank)
+case " $BENCH_ARGS $* " in *" --gpus "*) echo "profile a single rank: no --gpus under rocprofv3"; exit 2;; esac
 export TMPDIR=/tmp JB_ONE_STREAM=1
 out=gpurun_out/pmc_all
 rm -rf $out; mkdir -p $out

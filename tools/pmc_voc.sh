@@ -3,6 +3,9 @@
 # the totals are also written as a record carrying the workload and the kernel-source fingerprint of the
 # bench line they were measured on (profiles/r03_pmc_sq_k_vocoder_lt.json: what bench.py may quote).
 cd "$(dirname "$0")/.."
+# (refuse --gpus: bench.py would become a launcher that starts its ranks from a process the profiler has
+#  already initialised the GPU in -- the hop behind `--` that must not happen on this pool; profile one rank)
+case " $BENCH_ARGS $* " in *" --gpus "*) echo "profile a single rank: no --gpus under rocprofv3"; exit 2;; esac
 export TMPDIR=/tmp
 out=gpurun_out/pmc_voc
 mkdir -p $out

@@ -4,6 +4,9 @@
 # default r03) with the workload and the kernel-source fingerprint of the bench line it was measured on:
 # bench.py quotes it only for that workload on those sources.
 cd "$(dirname "$0")/.."
+# (refuse --gpus: bench.py would become a launcher that starts its ranks from a process the profiler has
+#  already initialised the GPU in -- the hop behind `--` that must not happen on this pool; profile one rank)
+case " $BENCH_ARGS $* " in *" --gpus "*) echo "profile a single rank: no --gpus under rocprofv3"; exit 2;; esac
 export TMPDIR=/tmp
 R=${1:-r03}
 out=gpurun_out/traffic
