@@ -404,7 +404,7 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-PROFILE_ROUND = "r03"  # profiles/<round>_* are what this line may quote
+PROFILE_ROUND = "r04"  # profiles/<round>_* are what this line may quote
 
 
 def kernel_sources_sha16():
