@@ -322,7 +322,7 @@ Batch::~Batch()
         hipEventDestroy(ev2);
     if (ev3)
         hipEventDestroy(ev3);
-    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build, ev_mcpbuild, ev_ivar})
+    for (hipEvent_t ev : {ev_fork, ev_lf0, ev_lpf, ev_prep, ev_build, ev_mcpbuild, ev_ivar, ev_fb})
         if (ev)
             hipEventDestroy(ev);
     for (hipEvent_t ev : {ev_mlpg_done, ev_voc_done})
@@ -728,6 +728,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     hipEventCreateWithFlags(&b->ev_build, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_mcpbuild, hipEventDisableTiming);
     hipEventCreateWithFlags(&b->ev_ivar, hipEventDisableTiming);
+    hipEventCreateWithFlags(&b->ev_fb, hipEventDisableTiming);
     hipEventCreate(&b->ev0);
     hipEventCreate(&b->ev1);
     hipEventCreate(&b->ev2);
@@ -961,7 +962,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->total_samples = nf * (size_t)vd.fperiod;
     if ((rc = b->dalloc(&vd.bcoef, nf * (size_t)vd.nmcp, false)) ||
         (rc = b->dalloc(&vd.pitch, nf, false)) || (rc = b->dalloc(&vd.cur_start, nf, false)) ||
-        (rc = b->dalloc(&vd.pinc, nf, false)) || (rc = b->dalloc(&vd.counter_start, nf, false)) ||
+        (rc = b->dalloc(&vd.pinc, nf, false)) ||
         (rc = b->dalloc(&vd.pmask, nf * (size_t)vd.nblk, false)) ||
         (rc = b->dalloc(&vd.xin, mlpg_only ? 1 : b->total_samples, false)))
         return rc;
@@ -995,6 +996,24 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         // per-frame pass.  With the debug tap (every sample wanted as computed per utterance) and on request
         // (JB_BATCH_NO_EXC_TABLE: A/B tests) every frame goes through the per-frame pass.
         vd.exc_no_table = (vd.exc || (b->flags & JB_BATCH_NO_EXC_TABLE)) ? 1 : 0;
+        {
+            // which frames carry the canonical taps: tracked by the LPF MLPG itself where that is the one-window
+            // kernel (a byte per frame instead of a second pass over the track); else k_exc_classify compares rows
+            StreamDev &sl = b->sd[2];
+            const bool is_static = sl.BW == 1 && sl.W == 1 && !sl.use_gv && !sl.generic_solver;
+            if (!trk && is_static && !vd.exc_no_table && nf) {
+                if ((rc = b->dalloc(&sl.canon, nf, false)))
+                    return rc;
+                sl.canon_n = nf;
+                sl.canon_ref_utt = 0;
+                for (size_t i = 0; i < n; i++)
+                    if (b->T[i] > 0) {
+                        sl.canon_ref_utt = (uint32_t)i; // owns the batch's first frame (frame_off 0)
+                        break;
+                    }
+                vd.lpf_canon = sl.canon;
+            }
+        }
         if ((rc = b->dalloc(&vd.exc_tab, std::max<size_t>((size_t)maxT * (size_t)vd.fperiod, 1), false)) ||
             (rc = b->dalloc(&vd.exc_src, std::max<size_t>(nf, 1), true)) ||
             (rc = b->dalloc(&vd.exc_gen, 2 * std::max<size_t>(nf, 1), false)) ||
@@ -1220,6 +1239,7 @@ static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
     Batch *b = (Batch *)ctx;
     hipError_t e;
     (void)stream;
+    hipEventRecord(b->ev_fb, stream); // the MCP band solve is enqueued up to here (the hook runs between it and the GV)
     // the LPF chain starts behind the MCP chain's inverse-variance pass: both stream at HBM rate, and side by
     // side (with the LF0 band solve) the pass on the critical chain took 3.1 ms instead of 0.5 (-0.45 ms per step)
     hipStreamWaitEvent(b->stream_lpf, b->ev_ivar, 0);
@@ -1342,6 +1362,10 @@ int Batch::enqueue_paramgen()
     // pulses (LF0): the samples after each pulse (split form) or the whole excitation
     hipStreamWaitEvent(stream_lf0, ev_lpf, 0);
     hipStreamWaitEvent(stream_lf0, ev_build, 0);
+#ifdef JB_DBG_GATES
+    if (dbg_sched() & 64)
+        hipStreamWaitEvent(stream_lf0, ev_fb, 0);
+#endif
     if ((e = launch_excite(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_excite");
     hipEventRecord(ev_lf0, stream_lf0);

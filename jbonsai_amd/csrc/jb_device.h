@@ -87,6 +87,12 @@ struct StreamDev {
     double *g;          // forward-substitution result / GV gradient
     double *par;        // compacted solution
     double *out;        // [sumT][L] scattered parameter track (NODATA in unvoiced frames)
+    // LPF stream, static path only (k_mlpg_static): canon[f] = 1 while every (mean, var) the frame's row was made
+    // from equals, bit for bit, that of the batch's first frame (utterance canon_ref_utt's first state) -- then so
+    // does the row.  Preset to 1 per run; a thread that sees a difference stores 0.  Null: not tracked.
+    uint8_t *canon;     // [canon_n = sumT]
+    uint64_t canon_n;
+    uint32_t canon_ref_utt;
 };
 
 // Control block of one launch of k_mlpg_gv_gang (zeroed before the launch) and per-gang records.
@@ -123,7 +129,6 @@ struct VocDev {
     double *pitch;        // [sumT]  period in samples, 0 = unvoiced
     double *cur_start;    // [sumT]  pitch_of_curr_point at frame start
     double *pinc;         // [sumT]  pitch_inc_per_point
-    double *counter_start;// [sumT]  pitch_counter at frame start
     unsigned long long *pmask; // [sumT][nblk] pulse bit per sample of each block
     const uint8_t *voiced;     // [sumT] MSD voiced flag of the LF0 stream (k_prep_frames)
     const uint32_t *run_list;  // voiced runs of the LF0 stream (k_prep_states)
@@ -148,6 +153,7 @@ struct VocDev {
     // exc_src[f]: where the vocoder finds frame f's excitation -- 0 its row of xin, 1 the noise stream
     // (unvoiced behind unvoiced), 2 exc_tab.
     double *exc_tab;          // [maxT * fperiod]
+    const uint8_t *lpf_canon; // [sumT] StreamDev::canon of the LPF stream, or nullptr: k_exc_classify compares the rows
     uint8_t *exc_src;         // [sumT]
     uint32_t *exc_gen;        // [sumT][2] = (utterance, frame | vcur << 30 | vprev << 31)
     uint32_t *exc_gen_count;  // [1]

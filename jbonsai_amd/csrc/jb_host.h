@@ -61,7 +61,7 @@ struct Batch {
     hipStream_t stream_voc = nullptr;        // vocoder + hand-off check (== stream)
     hipEvent_t ev_mlpg_done = nullptr, ev_voc_done = nullptr;
     hipStream_t stream_lf0 = nullptr, stream_lpf = nullptr; // concurrent parameter-generation chains
-    hipEvent_t ev_fork = nullptr, ev_lf0 = nullptr, ev_lpf = nullptr, ev_prep = nullptr, ev_build = nullptr, ev_mcpbuild = nullptr, ev_ivar = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_lf0 = nullptr, ev_lpf = nullptr, ev_prep = nullptr, ev_build = nullptr, ev_mcpbuild = nullptr, ev_ivar = nullptr, ev_fb = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     std::vector<uint32_t> T;
     std::vector<uint64_t> frame_off;

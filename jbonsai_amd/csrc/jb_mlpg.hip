@@ -309,15 +309,33 @@ __global__ void k_mlpg_build(BatchDev bd, StreamDev sd, int si)
 // MeanVari::with_ivar per (state, window, dim), once per batch: a frame's inverse variance is
 // its state's, and each is used by up to three neighbouring frames of every window, so the
 // table replaces ~6 f64 divisions per (frame, dim) in the build by loads.
-__global__ void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
+// kIvarPer elements per thread, block-strided (coalesced): with one element per thread the kernel is a stream of
+// 790 k tiny workgroups whose DISPATCH, not whose traffic, sets its time once other queues have work too
+// (0.5 ms alone, 2-3 ms at the head of the MCP chain beside the LF0 chain's kernels).
+constexpr int kIvarPer = 8;
+__global__ __launch_bounds__(256) void k_mlpg_ivar(BatchDev bd, StreamDev sd, int si)
 {
     const int b = blockIdx.y;
     const UttDev *up = bd.utt + b;
     const uint32_t WL = (uint32_t)(sd.W * sd.L);
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (uint64_t)up->S * WL)
+    const uint64_t n = (uint64_t)up->S * WL;
+    const uint64_t e0 = (uint64_t)blockIdx.x * (256u * kIvarPer) + threadIdx.x;
+    if (e0 >= n)
         return;
-    sd.ivar[up->state_off * (uint64_t)WL + e] = with_ivar(up->st[si].var[e]);
+    const double *var = up->st[si].var;
+    double *out = sd.ivar + up->state_off * (uint64_t)WL;
+    double v[kIvarPer];
+#pragma unroll
+    for (int k = 0; k < kIvarPer; k++) {
+        const uint64_t e = e0 + (uint64_t)k * 256u;
+        v[k] = var[e < n ? e : e0];
+    }
+#pragma unroll
+    for (int k = 0; k < kIvarPer; k++) {
+        const uint64_t e = e0 + (uint64_t)k * 256u;
+        if (e < n)
+            out[e] = with_ivar(v[k]);
+    }
 }
 
 // A3/A4 for the [dim][frame] workspace: a block computes kBuildTF frames x L dims with the
@@ -743,6 +761,15 @@ __global__ void k_mlpg_static(BatchDev bd, StreamDev sd, int si)
     const double d0 = 0.0 + wu * c;
     const double v = vo ? wum / d0 : kNoData;
     sd.out[(base + t) * (uint64_t)L + (uint64_t)m] = v;
+    if (sd.canon) {
+        // same inputs as the batch's first frame, bit for bit => the same row (what k_exc_classify asks)
+        const UttDev *ur = bd.utt + sd.canon_ref_utt;
+        const uint64_t pr = (uint64_t)sd.fstate[ur->frame_off] * (uint64_t)L + (uint64_t)m;
+        const StreamStatesDev sr = ur->st[si];
+        if (__double_as_longlong(sr.var[pr]) != __double_as_longlong(var) ||
+            __double_as_longlong(sr.mean[pr]) != __double_as_longlong(mean) || vo != sd.voiced[ur->frame_off])
+            sd.canon[base + t] = 0;
+    }
 }
 
 // --------------------------------------------------------------------------
@@ -1351,80 +1378,172 @@ __global__ __launch_bounds__(kFlNT, 1) void k_mlpg_fb_lds(BatchDev bd, StreamDev
 // the same bits.  k_mlpg_fb_lds walks the 15 k voiced frames of an utterance on ONE lane (4.2 ms for
 // 128 s); here the ~400 runs of an utterance are walked side by side, the longest run (a few
 // hundred frames) setting the time.  Same operations in the same order as k_mlpg_fb_lds's passes.
+// Memory side (round 4): a lane that streams its own run touches its own cache line with every access, 64 lines
+// per wave instruction -- the ~1,400 waves of config 2 kept the texture addresser of every CU busy and the
+// MCP chain's inverse-variance pass beside them took 2.0 ms instead of 0.6.  So the wave moves chunks of
+// kFrCh frames of all its 64 runs COOPERATIVELY: eight lanes fetch the eight frames of one run (64 B), eight
+// runs per instruction (8 lines instead of 64), through an LDS image [run][frame] (row pitch 9: conflict-free
+// both ways); the recurrences read and write the image.  The next chunk's values are requested before the
+// current chunk is worked on.
+constexpr int kFrCh = 8;            // frames per chunk
+constexpr int kFrPitch = kFrCh + 1; // LDS row pitch in doubles
 __global__ __launch_bounds__(64) void k_mlpg_fb_runs(BatchDev bd, StreamDev sd, int si)
 {
     const int b = (int)bd.order[blockIdx.y];
     const UttDev *up = bd.utt + b;
-    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
-    if (r >= sd.nruns[b])
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x * 64u + (uint32_t)lane;
+    const uint32_t nr = sd.nruns[b];
+    if (blockIdx.x * 64u >= nr)
         return;
     const uint64_t base = up->frame_off, sb = up->state_off;
     const uint32_t T = up->T;
-    const uint32_t t0 = sd.run_list[sb + r];
-    // entries of the run list: first frame of a voiced run; a zero-length voiced state can repeat an
-    // entry or leave one that continues the previous run (k_prep_states)
-    if (t0 >= T || !sd.voiced[base + t0] || (t0 > 0 && sd.voiced[base + t0 - 1]))
+    // this lane's run: compacted offset k0 and length (0: no run on this lane)
+    uint32_t k0 = 0, len = 0;
+    if (r < nr) {
+        const uint32_t t0 = sd.run_list[sb + r];
+        // entries of the run list: first frame of a voiced run; a zero-length voiced state can repeat an
+        // entry or leave one that continues the previous run (k_prep_states)
+        const bool ok = t0 < T && sd.voiced[base + t0] && !(t0 > 0 && sd.voiced[base + t0 - 1]) &&
+                        !(r > 0 && sd.run_list[sb + r - 1] == t0);
+        if (ok) {
+            const uint32_t s0 = sd.fstate[base + t0];
+            k0 = sd.s_vpre[sb + s0] + (t0 - sd.s_start[sb + s0]); // compacted index of the run's first frame
+            len = sd.s_rend[sb + s0] - t0 + 1;
+        }
+    }
+    __shared__ uint32_t rk0[64], rlen[64];
+    __shared__ double img[4][64][kFrPitch]; // four arrays x [run][frame]
+    rk0[lane] = k0;
+    rlen[lane] = len;
+    uint32_t maxlen = len;
+    for (int o = 32; o > 0; o >>= 1)
+        maxlen = max(maxlen, (uint32_t)__shfl_xor((int)maxlen, o));
+    if (maxlen == 0)
         return;
-    if (r > 0 && sd.run_list[sb + r - 1] == t0)
-        return;
-    const uint32_t s0 = sd.fstate[base + t0];
-    const uint32_t k0 = sd.s_vpre[sb + s0] + (t0 - sd.s_start[sb + s0]); // compacted index of the run's first frame
-    const uint32_t len = sd.s_rend[sb + s0] - t0 + 1;
-    const double *A0 = sd.A[0] + base + k0, *A1 = sd.A[1] + base + k0, *A2 = sd.A[2] + base + k0;
-    const double *Bv = sd.bvec + base + k0;
-    double *F0 = sd.F[0] + base + k0, *F1 = sd.F[1] + base + k0, *F2 = sd.F[2] + base + k0, *G = sd.g + base + k0;
-    double *P = sd.par + base + k0;
+    const uint32_t nch = (maxlen + kFrCh - 1) / kFrCh;
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    wsync();
+    const int sub = lane & 7, grp = lane >> 3; // cooperative side: frame within the chunk, run within the octet
+    const double *const in4[4] = {sd.A[0] + base, sd.A[1] + base, sd.A[2] + base, sd.bvec + base};
+    double *const f4[4] = {sd.F[0] + base, sd.F[1] + base, sd.F[2] + base, sd.g + base};
+    // fetch chunk c of four arrays for all 64 runs into registers: v[a][j] = arr_a[k0(8j+grp) + 8c + sub]
+    auto fetch = [&](const double *const (&arr)[4], uint32_t c, double (&v)[4][8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int rr = 8 * j + grp;
+            const uint32_t t = c * kFrCh + (uint32_t)sub;
+            const bool in = t < rlen[rr];
+            const uint64_t o = (uint64_t)rk0[rr] + (in ? t : 0u);
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+                v[a][j] = arr[a][o]; // (a lane past its run's end re-reads the run's first frame: valid, unused)
+        }
+    };
+    auto park = [&](const double (&v)[4][8]) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+                img[a][8 * j + grp][sub] = v[a][j];
+    };
+    // the image's rows back to memory: arr_a[k0(run) + 8c + sub] for the frames inside the run
+    auto drain = [&](double *const *arr, int na, uint32_t c) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int rr = 8 * j + grp;
+            const uint32_t t = c * kFrCh + (uint32_t)sub;
+            if (t < rlen[rr]) {
+                const uint64_t o = (uint64_t)rk0[rr] + t;
+                for (int a = 0; a < na; a++)
+                    arr[a][o] = img[a][rr][sub];
+            }
+        }
+    };
     // ---- ldl_factorization + forward substitution (mlpg.rs:79-105) ----
     {
         double p1_0 = 0, p1_1 = 0, p1_2 = 0, p2_0 = 0, p2_2 = 0, g1 = 0, g2 = 0;
-        double n0 = A0[0], n1 = A1[0], n2 = A2[0], nb = Bv[0]; // one frame ahead of the recurrence
-        for (uint32_t t = 0; t < len; t++) {
-            double r0 = n0, r1 = n1, r2 = n2, g = nb;
-            if (t + 1 < len) {
-                n0 = A0[t + 1];
-                n1 = A1[t + 1];
-                n2 = A2[t + 1];
-                nb = Bv[t + 1];
+        double v[4][8];
+        fetch(in4, 0, v);
+        for (uint32_t c = 0; c < nch; c++) {
+            wsync(); // the previous chunk's drain has read the image
+            park(v);
+            if (c + 1 < nch)
+                fetch(in4, c + 1, v);
+            wsync();
+            const uint32_t tb = c * kFrCh;
+#pragma unroll
+            for (int i = 0; i < kFrCh; i++) {
+                const uint32_t t = tb + (uint32_t)i;
+                if (t < len) {
+                    double r0 = img[0][lane][i], r1 = img[1][lane][i], r2 = img[2][lane][i], g = img[3][lane][i];
+                    if (t >= 1)
+                        r0 -= p1_1 * p1_1 * p1_0;
+                    if (t >= 2)
+                        r0 -= p2_2 * p2_2 * p2_0;
+                    if (t >= 1)
+                        r1 -= p1_1 * p1_2 * p1_0;
+                    const double rr = fb_rcp(r0);
+                    r1 = fb_div(r1, r0, rr);
+                    r2 = fb_div(r2, r0, rr);
+                    if (t >= 1)
+                        g -= p1_1 * g1;
+                    if (t >= 2)
+                        g -= p2_2 * g2;
+                    img[0][lane][i] = r0;
+                    img[1][lane][i] = r1;
+                    img[2][lane][i] = r2;
+                    img[3][lane][i] = g;
+                    p2_0 = p1_0;
+                    p2_2 = p1_2;
+                    g2 = g1;
+                    p1_0 = r0;
+                    p1_1 = r1;
+                    p1_2 = r2;
+                    g1 = g;
+                }
             }
-            if (t >= 1)
-                r0 -= p1_1 * p1_1 * p1_0;
-            if (t >= 2)
-                r0 -= p2_2 * p2_2 * p2_0;
-            if (t >= 1)
-                r1 -= p1_1 * p1_2 * p1_0;
-            const double rr = fb_rcp(r0);
-            r1 = fb_div(r1, r0, rr);
-            r2 = fb_div(r2, r0, rr);
-            if (t >= 1)
-                g -= p1_1 * g1;
-            if (t >= 2)
-                g -= p2_2 * g2;
-            F0[t] = r0;
-            F1[t] = r1;
-            F2[t] = r2;
-            G[t] = g;
-            p2_0 = p1_0;
-            p2_2 = p1_2;
-            g2 = g1;
-            p1_0 = r0;
-            p1_1 = r1;
-            p1_2 = r2;
-            g1 = g;
+            wsync();
+            drain(f4, 4, c);
         }
     }
-    // ---- backward substitution (mlpg.rs:106-113), t descending; the lane reads back its own stores ----
+    __threadfence_block(); // the backward pass reads back what the wave has just stored
+    wsync();
+    // ---- backward substitution (mlpg.rs:106-113), chunks and frames descending ----
     {
         double q1 = 0, q2 = 0;
-        for (uint32_t t = len; t-- > 0;) {
-            const double d = F0[t];
-            double p = fb_div(G[t], d, fb_rcp(d));
-            if (t + 1 < len)
-                p -= F1[t] * q1;
-            if (t + 2 < len)
-                p -= F2[t] * q2;
-            P[t] = p;
-            q2 = q1;
-            q1 = p;
+        double v[4][8];
+        double *const p1[1] = {sd.par + base};
+        const double *const fr4[4] = {sd.F[0] + base, sd.F[1] + base, sd.F[2] + base, sd.g + base};
+        fetch(fr4, nch - 1, v);
+        for (uint32_t c = nch; c-- > 0;) {
+            wsync();
+            park(v);
+            if (c > 0)
+                fetch(fr4, c - 1, v);
+            wsync();
+            const uint32_t tb = c * kFrCh;
+#pragma unroll
+            for (int i = kFrCh - 1; i >= 0; i--) {
+                const uint32_t t = tb + (uint32_t)i;
+                if (t < len) {
+                    const double d = img[0][lane][i];
+                    double p = fb_div(img[3][lane][i], d, fb_rcp(d));
+                    if (t + 1 < len)
+                        p -= img[1][lane][i] * q1;
+                    if (t + 2 < len)
+                        p -= img[2][lane][i] * q2;
+                    img[0][lane][i] = p; // (row 0 of the image now carries par)
+                    q2 = q1;
+                    q1 = p;
+                }
+            }
+            wsync();
+            drain(p1, 1, c);
         }
     }
 }
@@ -2146,7 +2265,8 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
         // [dim][frame] workspace: build, lane-per-dim factor/substitution sweeps, GV, transpose
         {
             const uint64_t ne = (uint64_t)bd.maxS * (uint64_t)(sd.W * sd.L);
-            dim3 grid((unsigned)((ne + 255) / 256), bd.B), block(256);
+            constexpr uint64_t per = 256u * kIvarPer;
+            dim3 grid((unsigned)((ne + per - 1) / per), bd.B), block(256);
             hipLaunchKernelGGL(k_mlpg_ivar, grid, block, 0, stream, bd, sd, si);
             if (after_ivar)
                 (void)hipEventRecord(after_ivar, stream);
@@ -2220,7 +2340,7 @@ static hipError_t launch_mlpg_bw(const BatchDev &bd, const StreamDev &sd, int si
                     // diagonal: same bits as a sweep over the whole utterance)
                     if (sd.L == 1 && bd.maxS > 0) {
                         dim3 rg((bd.maxS + 63) / 64, bd.B);
-                        hipLaunchKernelGGL(k_mlpg_fb_runs, rg, dim3(64), 0, stream, bd, sd, si);
+                        JB_DBG_SKIP_IF(128, hipLaunchKernelGGL(k_mlpg_fb_runs, rg, dim3(64), 0, stream, bd, sd, si));
                     } else if (sd.L == 1)
                         launch_fb(bd, sd, si, stream);
                     else
@@ -2365,6 +2485,11 @@ static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int
         if (work == 0 || bd.B == 0)
             return hipSuccess;
         dim3 grid((unsigned)((work + 255) / 256), bd.B), block(256);
+        if (sd.canon && sd.canon_n) {
+            hipError_t e = hipMemsetAsync(sd.canon, 1, sd.canon_n, stream);
+            if (e != hipSuccess)
+                return e;
+        }
         hipLaunchKernelGGL(k_mlpg_static, grid, block, 0, stream, bd, sd, si);
         if (after_build)
             (void)hipEventRecord(after_build, stream);

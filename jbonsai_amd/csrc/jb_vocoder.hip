@@ -43,15 +43,20 @@ __global__ void k_pitch(BatchDev bd, VocDev vd)
         return;
     const uint64_t f = u->frame_off + t;
     const double MAX_LF0 = 9.903487552536127, MIN_LF0 = 2.995732273553991; // constants.rs:4-6
-    const double l = vd.lf0[f];
-    double p;
-    if (l == kNoData) {
-        p = 0.0;
-    } else {
-        double cl = l < MIN_LF0 ? MIN_LF0 : (l > MAX_LF0 ? MAX_LF0 : l);
-        p = (double)vd.fs / exp(cl);
-    }
+    auto pitch_of = [&](double l) {
+        if (l == kNoData)
+            return 0.0;
+        const double cl = l < MIN_LF0 ? MIN_LF0 : (l > MAX_LF0 ? MAX_LF0 : l);
+        return (double)vd.fs / exp(cl);
+    };
+    const double p = pitch_of(vd.lf0[f]);
+    const double prevp = t > 0 ? pitch_of(vd.lf0[f - 1]) : 0.0;
     vd.pitch[f] = p;
+    // Excitation::start (excitation.rs:25-33) of a voiced frame: pitch_of_curr_point is the previous frame's pitch
+    // (Excitation::end, :102-104) unless that frame was unvoiced; written here, coalesced, and not by the pulse
+    // walk, whose lanes are one voiced run each (64 cache lines per store instruction)
+    vd.cur_start[f] = prevp != 0.0 ? prevp : p;
+    vd.pinc[f] = (prevp != 0.0 && p != 0.0) ? (p - prevp) / (double)vd.fperiod : 0.0;
 }
 
 // V2b: mc2b (cepstrum.rs:139-149).  64 frames per block staged through LDS so that both
@@ -274,13 +279,21 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
                     cur = p;
                     counter = p;
                 }
-                vd.cur_start[base + t] = cur;
-                vd.pinc[base + t] = inc;
-                vd.counter_start[base + t] = counter;
                 unsigned long long w[4] = {0ull, 0ull, 0ull, 0ull};
                 pulse_frame_closed(counter, cur, inc, fp, bs, w);
-                for (int q = 0; q < nblk; q++)
-                    vd.pmask[(base + t) * nblk + q] = w[q];
+                // (cur_start, pinc: k_pitch.)  The frame's mask words in as few stores as they fit: every lane is
+                // another run, so every store instruction of the wave touches 64 cache lines
+                unsigned long long *pm = vd.pmask + (base + t) * (uint64_t)nblk;
+                if (nblk == 4) {
+                    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                    u64x2 lo, hi;
+                    lo.x = w[0]; lo.y = w[1]; hi.x = w[2]; hi.y = w[3];
+                    *reinterpret_cast<u64x2 *>(pm) = lo;
+                    *reinterpret_cast<u64x2 *>(pm + 2) = hi;
+                } else {
+                    for (int q = 0; q < nblk; q++)
+                        pm[q] = w[q];
+                }
                 prevp = p; // Excitation::end
             }
 #pragma unroll
@@ -303,9 +316,6 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
             cur = p;
             counter = p;
         }
-        vd.cur_start[base + t] = cur;
-        vd.pinc[base + t] = inc;
-        vd.counter_start[base + t] = counter;
         for (int q = 0; q < nblk; q++) {
             // voiced branch of Excitation::get (excitation.rs:73-81), sample by sample (frame periods with more
             // than four mask words: the closed form above keeps a frame's words in registers); the pulse bits
@@ -376,19 +386,29 @@ __global__ __launch_bounds__(64) void k_pulse_queue(BatchDev bd, VocDev vd)
 {
     const uint32_t total = vd.run_base[bd.B];
     for (;;) {
-        const uint32_t idx = atomicAdd(vd.run_counter, 1u);
-        if (idx >= total)
-            return;
-        // utterance position: last p with run_base[p] <= idx
-        int lo = 0, hi = bd.B - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (vd.run_base[mid] <= idx)
-                lo = mid;
-            else
-                hi = mid - 1;
+        // 64 runs per reservation: one atomic per wave and turn, not one per lane (they all hit one address).
+        // The whole wave is here together every turn -- the reservation is read with readfirstlane --: a lane
+        // without a run of its own skips the walk, nothing else.
+        uint32_t idx0 = 0;
+        if (threadIdx.x == 0)
+            idx0 = atomicAdd(vd.run_counter, 64u);
+        idx0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx0);
+        if (idx0 >= total)
+            return; // wave-uniform: every wave reaches this once the queue is empty
+        const uint32_t idx = idx0 + threadIdx.x;
+        if (idx < total) {
+            // utterance position: last p with run_base[p] <= idx
+            int lo = 0, hi = bd.B - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (vd.run_base[mid] <= idx)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
+            pulse_run(bd, vd, (int)bd.order[lo], idx - vd.run_base[lo]);
         }
-        pulse_run(bd, vd, (int)bd.order[lo], idx - vd.run_base[lo]);
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -706,12 +726,22 @@ __global__ __launch_bounds__(256) void k_exc_classify(BatchDev bd, VocDev vd)
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t T = u->T;
     const uint32_t fr0 = (blockIdx.x * 4u + (uint32_t)wv) * 64u;
-    if (fr0 >= T)
-        return;
+    if (blockIdx.x * 256u >= T)
+        return; // (the whole workgroup: a wave past the end stays for the workgroup's one list reservation)
+    __shared__ uint32_t wcount[4], wbase;
     const uint64_t base = u->frame_off;
     unsigned long long canon = 0ull; // bit j: row of frame fr0 - 1 + j is canonical (j = 0..63), bit 64 below
     bool canon64 = false;
-    if (!vd.exc_no_table) {
+    if (!vd.exc_no_table && vd.lpf_canon) {
+        // the LPF MLPG kept track (k_mlpg_static: same inputs as the first frame's, bit for bit): one byte per frame
+        const long fa = (long)fr0 - 1 + lane;
+        const bool ina = fa >= 0 && fa < (long)T;
+        const uint8_t ca = vd.lpf_canon[base + (uint64_t)(ina ? fa : 0)];
+        const long fb = (long)fr0 + 63;
+        const uint8_t cb = vd.lpf_canon[base + (uint64_t)(fb < (long)T ? fb : 0)];
+        canon = __ballot(ina && ca != 0);
+        canon64 = fb < (long)T && cb != 0;
+    } else if (!vd.exc_no_table) {
         const int half = lane >> 5, k = lane & 31;
         const bool tap = k < NLPF;
         const double cref = vd.lpf[tap ? k : 0];
@@ -742,7 +772,7 @@ __global__ __launch_bounds__(256) void k_exc_classify(BatchDev bd, VocDev vd)
     }
     const uint32_t fr = fr0 + (uint32_t)lane;
     const bool in = fr < T;
-    const uint64_t f = base + (in ? fr : fr0);
+    const uint64_t f = base + (in ? fr : 0u); // (a lane past the utterance reads its first frame and keeps nothing)
     const bool vcur = in && vd.voiced[f] != 0;
     const bool vprev = in && fr > 0 && vd.voiced[f - 1] != 0;
     const bool ccur = lane == 63 ? canon64 : ((canon >> (lane + 1)) & 1ull) != 0;
@@ -756,12 +786,19 @@ __global__ __launch_bounds__(256) void k_exc_classify(BatchDev bd, VocDev vd)
         vd.exc_src[f] = (uint8_t)code;
     const bool gen = in && code == 0;
     const unsigned long long gm = __ballot(gen);
-    if (gm == 0ull)
-        return;
-    uint32_t slot0 = 0;
+    // one reservation in the work list per WORKGROUP (with one per wave, 100 k atomics on one address were what
+    // the kernel's 1.0 ms consisted of)
     if (lane == 0)
-        slot0 = atomicAdd(vd.exc_gen_count, (uint32_t)__popcll(gm));
-    slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot0);
+        wcount[wv] = (uint32_t)__popcll(gm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        wbase = tot ? atomicAdd(vd.exc_gen_count, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t slot0 = wbase;
+    for (int w = 0; w < wv; w++)
+        slot0 += wcount[w];
     if (gen) {
         const uint32_t rank = (uint32_t)__popcll(gm & ((1ull << lane) - 1ull));
         uint32_t *e = vd.exc_gen + 2 * (uint64_t)(slot0 + rank);
@@ -938,7 +975,10 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     // parameters, the samples of the lanes a pulse reaches), THEN the frames are worked off.  Frame after frame
     // with a load -> add -> store chain each, a wave lived through nine dependent round trips (26 us; the kernel
     // runs at full occupancy and was bound by exactly that).
-    constexpr int kFixGroup = 4;
+#ifndef JB_FIX_GROUP
+#define JB_FIX_GROUP 4
+#endif
+    constexpr int kFixGroup = JB_FIX_GROUP;
     static_assert(kFixFrames % kFixGroup == 0, "whole groups");
     for (int j0 = 0; j0 < kFixFrames; j0 += kFixGroup) {
         bool work[kFixGroup], touched[kFixGroup], from_tab[kFixGroup];

@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/.."
 cp jbonsai_amd/libjbonsai_amd.so /tmp/_keep.so
 trap 'cp /tmp/_keep.so jbonsai_amd/libjbonsai_amd.so' EXIT
-for rep in 1 2; do for l in "$@"; do
+for rep in $(seq 1 ${REPS:-2}); do for l in "$@"; do
   cp $l jbonsai_amd/libjbonsai_amd.so
   timeout -k 5 120 python bench.py --no-cpu-baseline --no-extras --steps 8 --warmup 3 $BENCH_ARGS 2>/dev/null | python -c "
 import sys, json
