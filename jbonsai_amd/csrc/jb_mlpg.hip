@@ -1573,7 +1573,10 @@ __device__ __forceinline__ double serial_add64(double acc, double v)
 
 // Loads of kVtNB blocks of 64 frames are issued together before their serial sums run, so a
 // lone wave pays one memory latency per 512 frames instead of one per 64.
-constexpr int kVtNB = 8; // 4: 3.08 ms, 8: 2.85, 16: 2.90 (LF0 of config 2, alone)
+#ifndef JB_VT_NB
+#define JB_VT_NB 8
+#endif
+constexpr int kVtNB = JB_VT_NB; // 4: 3.08 ms, 8: 2.85, 16: 2.90 (LF0 of config 2, alone)
 
 // In-order sum of one value per lane, acc += v[lane 0]; acc += v[lane 1]; ... -- through LDS:
 // the wave parks the values and every lane reads them back in order with broadcast
@@ -2490,7 +2493,7 @@ static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int
             if (e != hipSuccess)
                 return e;
         }
-        hipLaunchKernelGGL(k_mlpg_static, grid, block, 0, stream, bd, sd, si);
+        JB_DBG_SKIP_IF(256, hipLaunchKernelGGL(k_mlpg_static, grid, block, 0, stream, bd, sd, si));
         if (after_build)
             (void)hipEventRecord(after_build, stream);
         return hipGetLastError();
