@@ -1,5 +1,5 @@
 #!/bin/bash
-# DESIGN.md section 5's table: other batch shapes with DISTINCT utterances, one box
+# the shapes table of DESIGN.md section 5 (profiles/rNN_shapes.txt): other batch shapes with DISTINCT utterances, one box
 cd "$(dirname "$0")/.."
 for spec in "1 500" "16 2000" "64 2000" "256 2000" "1024 500" "16 25546" "64 25546" "256 25546"; do
   set -- $spec
