@@ -117,3 +117,7 @@ def test_library_asks_for_hardware_queues_in_a_fresh_process():
     r = subprocess.run([sys.executable, "-c", code, str(J.LIB_PATH)], capture_output=True, text=True,
                        env=dict(env, GPU_MAX_HW_QUEUES="6"), timeout=120)
     assert r.returncode == 0 and "b'6'" in r.stdout, r.stdout + r.stderr
+    # opt-out: JB_LEAVE_HIP_ENV=1 -- the library leaves the process's environment alone
+    r = subprocess.run([sys.executable, "-c", code, str(J.LIB_PATH)], capture_output=True, text=True,
+                       env=dict(env, JB_LEAVE_HIP_ENV="1"), timeout=120)
+    assert r.returncode == 0 and "None" in r.stdout, r.stdout + r.stderr
