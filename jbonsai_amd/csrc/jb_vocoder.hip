@@ -1362,21 +1362,39 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
 constexpr int DPP_WAVE_SHL1 = 0x130;
 constexpr int kLtChunks = 21;
 constexpr int kLtPf = 4; // coefficient reads in flight ahead of their use (2, 3 or 4 measure the same)
+// Waves per workgroup.  EIGHT = a whole CU (two waves of 256 VGPRs per SIMD): waves w and w + 4 of a workgroup land on
+// the same SIMD, so the two waves that share a SIMD can see each other's progress in LDS.  The issue arbiter serves
+// the OLDER wave of a SIMD first: with independent one-wave workgroups the older wave ran at its solo rate (6.7
+// cycles per instruction) and finished after 44.5 ms, the younger one got the gaps (12.6 cycles per instruction) and
+// then ran ALONE for 17 ms at the solo rate -- the kernel took 61.5 ms where two waves sharing the pipe to the end
+// need 58 (tools/lt_clocks.sh).  The pair now keeps level: every kLtBalance samples a wave posts its sample count
+// and raises its priority if it is behind its partner, lowers it if ahead.
+#ifndef JB_LT_WAVES
+#define JB_LT_WAVES 8
+#endif
+constexpr int kLtWaves = JB_LT_WAVES;
+constexpr int kLtBalance = 8;
+#ifdef JB_LT_CLOCKS
+// timing aid (tools/lt_clocks.sh): shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at the
+// start and end of two waves of the kernel: the clock the chip holds under this kernel
+__device__ unsigned long long g_lt_clk[8];
+#endif
 
 template <int NM, int TPLW>
-__global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
+__global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                                                        const VocWork *__restrict__ work,
                                                        const uint32_t *__restrict__ order,
                                                        uint32_t n_items)
 {
     constexpr int M = NM - 1; // live taps 1..M
     constexpr int NS = 2;     // stage slots per lane
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x % 64;
+    const int wv = threadIdx.x / 64; // wave of the workgroup (uniform)
     const bool idle = lane == 63;
     // pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 63 behaves like pos 2)
     const int pos = idle ? 2 : lane % 3;
     const int ci = idle ? 20 : lane / 3; // chunk slot of this lane within the wave
-    const uint32_t slot = blockIdx.x * (uint32_t)kLtChunks + (uint32_t)ci;
+    const uint32_t slot = (blockIdx.x * (uint32_t)kLtWaves + (uint32_t)wv) * (uint32_t)kLtChunks + (uint32_t)ci;
     const bool has = !idle && slot < n_items;
     const bool lead = has && pos == 0;
     const uint32_t item = has ? order[slot] : 0u;
@@ -1399,8 +1417,19 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
     uint32_t maxfr = nfr;
     for (int o = 32; o > 0; o >>= 1)
         maxfr = max(maxfr, (uint32_t)__shfl_xor((int)maxfr, o));
+    // (every wave works on LDS of its own and there is no workgroup barrier in this kernel: a wave may leave)
+    __shared__ uint32_t prog[8]; // samples done, per wave
+    if (kLtWaves == 8 && lane == 0)
+        prog[wv] = maxfr == 0 ? 0xffffffffu : 0u;
     if (maxfr == 0)
         return;
+#ifdef JB_LT_CLOCKS
+    const int clk_slot = wv != 0 ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 4 : -1;
+    if (clk_slot >= 0 && lane == 0) {
+        g_lt_clk[clk_slot] = clock64();
+        g_lt_clk[clk_slot + 1] = wall_clock64();
+    }
+#endif
     const uint64_t base = has ? bd.utt[wk.utt].frame_off : 0;
     const int fp = vd.fperiod;
     const double a = vd.alpha, na = -a, iaa = 1.0 - a * a, vol = vd.volume;
@@ -1410,8 +1439,13 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
     const double w0 = kPPade[s0 + 1];
     const double w1 = (s0 + 1 < kPade) ? kPPade[s0 + 2] : 0.0;
 
-    __shared__ double2 cc[NM - 1][kLtChunks]; // row k-1: (c_k at frame start, per-sample increment)
-    __shared__ double gqs[kLtChunks];         // per-sample gain ratio exp(cinc0) of the current frame
+    __shared__ double2 cc_[kLtWaves][NM - 1][kLtChunks]; // row k-1: (c_k at frame start, per-sample increment)
+    __shared__ double gqs_[kLtWaves][kLtChunks];         // per-sample gain ratio exp(cinc0) of the current frame
+    double2 (*const cc)[kLtChunks] = cc_[wv];
+    double *const gqs = gqs_[wv];
+    // the tables are the wave's own and LDS serves a wave's operations in order: ordering them takes no barrier, only
+    // that the compiler keeps the stores of a frame's set-up between the asm-issued reads of the two frames
+#define JB_LT_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
     double d[NS][M + 1];
     double u[NS]; // slot inputs (d22[stage])
@@ -1492,7 +1526,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         }
         // frame setup (vocoder/mod.rs:116-125): c = previous target, cinc = (cc - c)/fperiod;
         // the three lanes of a triple fill every third tap
-        __syncthreads();
+        JB_LT_FENCE();
         if (has) {
             const double *bcur = vd.bcoef + f * (uint64_t)NM;
             const double *bprev = (t > 0) ? bcur - NM : (vd.bfirst ? vd.bfirst + (uint64_t)wk.utt * NM : bcur);
@@ -1505,7 +1539,7 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
             if (pos == 0)
                 gqs[ci] = exp((bcur[0] - bprev[0]) / (double)fp);
         }
-        __syncthreads();
+        JB_LT_FENCE();
         const double *xp = exc_frame_ptr(vd, base, t);
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
         double xn = act ? xp[0] : 0.0;
@@ -1690,6 +1724,23 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
         // (this form needs an even frame period: checked on the host, which otherwise builds chunks for
         // the wave kernel)
         for (int i2 = 0; i2 < fp; i2 += 2) {
+            if (kLtWaves == 8 && i2 % kLtBalance == 0) {
+                // keep level with the wave that shares this SIMD (w ^ 4): post the sample count, read the partner's
+                // (0xffffffff once it has left), and take the higher issue priority if behind.  The LDS queue is
+                // drained before the tap loop's counted waits start (they are valid among loads only).
+                const uint32_t mine = tl * (uint32_t)fp + (uint32_t)i2;
+                uint32_t theirs;
+                asm volatile("ds_write_b32 %1, %2\n\t"
+                             "ds_read_b32 %0, %3\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=v"(theirs)
+                             : "v"((uint32_t)(uintptr_t)&prog[wv]), "v"(mine), "v"((uint32_t)(uintptr_t)&prog[wv ^ 4])
+                             : "memory");
+                if (mine > (uint32_t)__builtin_amdgcn_readfirstlane((int)theirs))
+                    __builtin_amdgcn_s_setprio(0);
+                else
+                    __builtin_amdgcn_s_setprio(1);
+            }
             sample(i2, std::false_type{});
             sample(i2 + 1, std::true_type{});
         }
@@ -1702,6 +1753,14 @@ __global__ __launch_bounds__(64, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                 save_state(se_);
         }
     }
+    if (kLtWaves == 8 && lane == 0)
+        prog[wv] = 0xffffffffu;
+#ifdef JB_LT_CLOCKS
+    if (clk_slot >= 0 && lane == 0) {
+        g_lt_clk[clk_slot + 2] = clock64();
+        g_lt_clk[clk_slot + 3] = wall_clock64();
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------
@@ -1936,7 +1995,8 @@ hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork
 {
     if (n_items == 0)
         return hipSuccess;
-    dim3 grid((n_items + kLtChunks - 1) / kLtChunks), block(64);
+    const uint32_t per_wg = (uint32_t)(kLtChunks * kLtWaves);
+    dim3 grid((n_items + per_wg - 1) / per_wg), block(64 * kLtWaves);
     switch (vd.nmcp) {
     case 35:
         hipLaunchKernelGGL((k_vocoder_lt<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
@@ -1947,6 +2007,18 @@ hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork
     default:
         return hipErrorInvalidValue;
     }
+#ifdef JB_LT_CLOCKS
+    {
+        unsigned long long c[8];
+        hipStreamSynchronize(stream);
+        if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_lt_clk), sizeof c) == hipSuccess)
+            for (int k = 0; k < 8; k += 4) {
+                const double us = (double)(c[k + 3] - c[k + 1]) / 100.0; // 100 MHz
+                fprintf(stderr, "k_vocoder_lt wave %d: %.3f ms, %.0f shader-clock ticks = %.3f GHz\n", k / 4, us / 1e3,
+                        (double)(c[k + 2] - c[k]), (double)(c[k + 2] - c[k]) / us / 1e3);
+            }
+    }
+#endif
     return hipGetLastError();
 }
 
