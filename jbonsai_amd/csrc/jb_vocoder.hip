@@ -1636,26 +1636,40 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
 #pragma unroll
             for (int k = 0; k < kLtPf; k++)
                 JB_LDS_RD(cq[k], 2 + k); // taps 2 .. 1+PF
+            // The coefficients are waited for in PAIRS, one tap block ahead of the first use, and each tap is followed
+            // by one interpolation and one new request:
+            //     W(2,3) c2 R6 B1 | W(4,5) c3 R7 B2 | c4 R8 B3 | W(6,7) c5 R9 B4 | c6 R10 B5 | ...
+            // Per sample that is 18 waits instead of 34 and one s_nop instead of 11.  (The hazard recogniser puts an
+            // s_nop between an asm statement and a following instruction that reads a register the statement writes
+            // unless a compiler-emitted instruction stands between them -- asm statements count as nothing: so the
+            // interpolation of the NEXT tap stands between two tap blocks, and the wait that defines a pair's
+            // registers stands one interpolation before their first use.)  Every instruction of a wave that is not
+            // a VALU instruction is an issue slot in which the pipe is busy only if the other wave of the SIMD has a
+            // VALU instruction ready.
+            static_assert(kLtPf == 4 && M % 2 == 0 && M >= 6, "pair schedule: four slots, taps 2..M in pairs + one");
+            double cv[M + 2];
+            auto wait_pair = [&](const int j, const int younger) { // taps j, j+1
+                v2d &qa = cq[(j - 2) % kLtPf], &qb = cq[(j - 1) % kLtPf];
+                switch (younger) {
+                case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa), "+v"(qb)); break;
+                case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(qa), "+v"(qb)); break;
+                default: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(qa), "+v"(qb)); break;
+                }
+            };
+            cv[1] = 0.0;
 #pragma unroll
             for (int j = 1; j <= M; j++) {
-                double cj = 0.0;
-                if (j >= 2) {
-                    const int slotq = (j - 2) % kLtPf;
-                    const int inflight = (M - j) < (kLtPf - 1) ? (M - j) : (kLtPf - 1);
-                    switch (inflight) { // younger reads that may still be in flight
-                    case 0: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cq[slotq])); break;
-                    case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(cq[slotq])); break;
-                    case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(cq[slotq])); break;
-                    case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(cq[slotq])); break;
-                    case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cq[slotq])); break;
-                    case 5: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(cq[slotq])); break;
-                    case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(cq[slotq])); break;
-                    default: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(cq[slotq])); break;
-                    }
-                    cj = fma(fi, cq[slotq].y, cq[slotq].x);
-                    if (j + kLtPf <= M)
-                        JB_LDS_RD(cq[slotq], j + kLtPf);
+                if (j == 1)
+                    wait_pair(2, 2); // requests 4, 5 are younger
+                else if (j % 2 == 0 && j + 2 <= M)
+                    wait_pair(j + 2, j + 4 <= M ? 1 : 0); // (tap M + 1 does not exist: its slot is just tied)
+                if (j + 1 <= M) {
+                    const int sq = (j - 1) % kLtPf; // slot of tap j + 1
+                    cv[j + 1] = fma(fi, cq[sq].y, cq[sq].x);
+                    if (j + 5 <= M)
+                        JB_LDS_RD(cq[sq], j + 5);
                 }
+                const double cj = cv[j];
                 // all-pass section of tap j for both stage slots, then the dot-product terms:
                 //   rem' = d - a*rem ; d' = (1-a^2)*rem + a*d = rem + a*rem' ; y += c_j * d'
                 // as ONE block of three-address v_fma_f64.  (a) hipcc would select the destructive
@@ -1669,7 +1683,7 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
                     if (j == 2) {
                         // the first term of the dot products: a product, not an FMA onto a zero that a
                         // v_mov would have to make first
-                        asm("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                        asm volatile("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
                             "v_fma_f64 %[rn1], %[na], %[r1], %[d1]\n\t"
                             "v_fma_f64 %[d0], %[a], %[rn0], %[r0]\n\t"
                             "v_fma_f64 %[d1], %[a], %[rn1], %[r1]\n\t"
@@ -1681,7 +1695,7 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
                     } else if (j > 2) {
                         // (the interpolation c_j = c0 + i*cinc stays outside: inside the block it
                         // doubles the padding at the asm boundaries, measured +1 ms)
-                        asm("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                        asm volatile("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
                             "v_fma_f64 %[rn1], %[na], %[r1], %[d1]\n\t"
                             "v_fma_f64 %[d0], %[a], %[rn0], %[r0]\n\t"
                             "v_fma_f64 %[d1], %[a], %[rn1], %[r1]\n\t"
@@ -1691,7 +1705,7 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
                               [y0] "+v"(y[0]), [y1] "+v"(y[1])
                             : [na] "s"(na), [a] "s"(a), [r0] "v"(r[0]), [r1] "v"(r[1]), [c] "v"(cj));
                     } else {
-                        asm("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                        asm volatile("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
                             "v_fma_f64 %[rn1], %[na], %[r1], %[d1]\n\t"
                             "v_fma_f64 %[d0], %[a], %[rn0], %[r0]\n\t"
                             "v_fma_f64 %[d1], %[a], %[rn1], %[r1]"

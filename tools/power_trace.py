@@ -3,12 +3,16 @@ a thread (amdgpu: power1_average / power1_input in microwatts, freq1_input in Hz
 Usage: python tools/power_trace.py [bench.py arguments]"""
 import glob, subprocess, sys, threading, time, statistics as st
 
-def files():
-    out = {}
-    for h in glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*'):
+def cards():
+    """hwmon directories of every amdgpu device the box shows (all GPUs of the host appear in sysfs, one is ours)"""
+    out = []
+    for h in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
+        d = {}
         for name in ('power1_average', 'power1_input', 'freq1_input', 'power1_cap'):
             for p in glob.glob(h + '/' + name):
-                out.setdefault(name, p)
+                d[name] = p
+        if 'power1_average' in d or 'power1_input' in d:
+            out.append(d)
     return out
 
 def rd(p):
@@ -17,12 +21,12 @@ def rd(p):
     except Exception:
         return None
 
-F = files()
-print('hwmon files:', F, flush=True)
-samples, stop = [], False
+C = cards()
+allsamples, stop = [[] for _ in C], False
 def loop():
     while not stop:
-        samples.append((time.time(), rd(F.get('power1_average') or F.get('power1_input', '')), rd(F.get('freq1_input', ''))))
+        for F, sm in zip(C, allsamples):
+            sm.append((time.time(), rd(F.get('power1_average') or F.get('power1_input', '')), rd(F.get('freq1_input', ''))))
         time.sleep(0.004)
 t = threading.Thread(target=loop); t.start()
 args = sys.argv[1:] or ['--no-cpu-baseline', '--no-extras', '--steps', '30', '--warmup', '3']
@@ -31,6 +35,10 @@ r = subprocess.run([sys.executable, 'bench.py'] + args, capture_output=True, tex
 t1 = time.time()
 stop = True; t.join()
 print(r.stdout.strip().splitlines()[-1][:300] if r.stdout.strip() else r.stderr[-500:])
+# ours is the device whose power moved most during the run
+spread = [max([s[1] or 0 for s in sm] or [0]) - min([s[1] or 0 for s in sm] or [0]) for sm in allsamples]
+k = spread.index(max(spread)); F, samples = C[k], allsamples[k]
+print('device', k, 'of', len(C), F.get('power1_input') or F.get('power1_average'))
 print('power cap (W):', (rd(F['power1_cap']) or 0) / 1e6 if 'power1_cap' in F else None)
 # the timed steps are the last part of the run: take the last 30 % of the samples
 n = len(samples); tail = samples[int(n * 0.7):]
