@@ -1072,8 +1072,17 @@ int Batch::build_work(const jb_batch_opts *opts)
     if (serial) {
         ch = 0;
     } else if (ch == 0 && lp_mode) {
-        // two waves on every SIMD the vocoder may use: 8 XCDs x (32 - k) CUs x 4 SIMDs x 2
-        const uint64_t target = 64ull * 32 * (uint64_t)vocoder_ls_chunks_per_wave();
+        // two waves on every SIMD: 8 XCDs x 32 CUs x 4 SIMDs x 2 -- or ONE, while the batch is too small to give
+        // every SIMD two waves of chunks that are long against their warm-up.  The launch takes as long as one
+        // chunk-with-warm-up at the rate a wave gets: a lone wave issues an instruction every 6.7 cycles, one of a
+        // pair every 8.9 (tools/lt_clocks.sh); compare the two at the chunk length each would get (floor below).
+        constexpr uint64_t cfloor = 16;
+        const uint64_t slots1 = 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave();
+        auto launch_cost = [&](uint64_t slots, double cycles) {
+            return (double)(std::max<uint64_t>((sumT + slots - 1) / slots, cfloor) + warmup_frames) * cycles;
+        };
+        lt_waves_per_simd = launch_cost(slots1, 6.7) < launch_cost(2 * slots1, 8.9) ? 1 : 2;
+        const uint64_t target = slots1 * (uint64_t)lt_waves_per_simd;
         uint64_t c = (sumT + target - 1) / target;
         // while the batch cannot fill the chip the time of the launch is that of ONE chunk (chunk +
         // warm-up frames): chunks down to 16 frames.  Shorter chunks mean more hand-off positions and
@@ -1083,7 +1092,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         // step, 64 x 4,600 32.7 -> 23.0, 256 x 2,000 33.4 -> 23.5, 1024 x 500 22.8 -> 21.0 -- and 12 or
         // 8 gain nothing more.  (The earlier floor had been tuned on copies of one utterance, whose
         // hand-offs all pass.)
-        constexpr uint64_t cmin = 16;
+        constexpr uint64_t cmin = cfloor;
         ch = (uint32_t)std::max<uint64_t>(c, cmin);
         // (no rounding of the chunk length: 153 frames instead of 156 on config 2 is 1.7 % fewer frames per
         // chunk-with-warm-up and still fits the chip -- 42,752 items for 43,008 slots)
@@ -1110,7 +1119,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
-    // the checkpoint a failed chunk is first recomputed to (finish_verify): 48 frames into chunks of 96 and more, 24 into
+    // the checkpoint a failed chunk is first recomputed to (finish_verify): 32 frames into chunks of 64 and more, 24 into
     // chunks of 36 and more, 16 into chunks of 24 and more (a single 128 s utterance, 799 chunks of 32 frames: all six
     // failing hand-offs settle there and the redo is one round of 16 frames, 10.2 -> 9.2 ms per call; 8 frames into
     // 16-frame chunks settle three in four but the rest still take their rounds: same time, not done)
@@ -1213,7 +1222,7 @@ int Batch::enqueue_vocoder()
 {
     hipError_t e;
     if (lp_mode)
-        e = launch_vocoder_ls(bd, vd, work_dev, order_dev, n_items, stream_voc);
+        e = launch_vocoder_ls(bd, vd, work_dev, order_dev, n_items, lt_waves_per_simd, stream_voc);
     else
         e = launch_vocoder(bd, vd, work_dev, n_items, stream_voc);
     if (e != hipSuccess)

@@ -199,9 +199,11 @@ struct VocWork {
 };
 // A failing chunk is first recomputed only up to VocDev::ckpt_frames frames past its start; if the
 // recomputed state meets the checkpoint the original chunk left there, the rest of the chunk stands.
-// 48 frames into chunks of 96 frames and more, 24 into chunks of 36 to 95, 16 into chunks of 24 to 35, none below
-// (Batch::build_work).
-constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16;
+// 32 frames into chunks of 64 frames and more, 24 into chunks of 36 to 63, 16 into chunks of 24 to 35, none below
+// (Batch::build_work).  A redo round lasts as long as the frames to the checkpoint (0.06 ms per frame, one wave per
+// chunk); a hand-off that failed behind 18 frames of warm-up settles there if 18 + 32 frames from zero state are
+// enough, and no position of the CPU study needed more than 43 (tests/tools/warmup_decay.py).  (48 until round 4.)
+constexpr uint32_t kVocCkptFrames = 32, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16;
 
 // Timing experiments only (library built with -DJB_DBG_GATES, never the product): JB_DBG_SKIP is a bit mask of
 // launches to leave out once a launcher has been called JB_DBG_SKIP_AFTER times (default 2: bench.py's warm-up
@@ -292,9 +294,10 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
                           hipStream_t stream);
 // lane-serial throughput kernel (one chunk per lane); order_dev = launch permutation of items
 bool vocoder_ls_supported(int nmcp);
-int vocoder_ls_chunks_per_wave(); // 20 (lane triples) or 32 (lane pairs)
+int vocoder_ls_chunks_per_wave(); // 21 (lane triples)
+// waves_per_simd: 2 = eight-wave workgroups (a whole CU), 1 = four-wave workgroups
 hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
-                             const uint32_t *order_dev, uint32_t n_items, hipStream_t stream);
+                             const uint32_t *order_dev, uint32_t n_items, int waves_per_simd, hipStream_t stream);
 // compares save_warm of item i with save_end of item i-1 (same utterance): bad[i]=1 and
 // ++*n_bad when max|diff| > tol * max|state|
 // (carried-state slots only: ntaps = nmcp - 1 live taps, see voc_state_differs)

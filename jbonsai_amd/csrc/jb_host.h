@@ -87,7 +87,8 @@ struct Batch {
     uint8_t *bad_dev = nullptr;
     uint32_t *nbad_dev = nullptr;
     bool verify_pending = false;
-    bool lp_mode = false;            // lane-pair throughput kernel
+    bool lp_mode = false;            // lane-triple throughput kernel
+    int lt_waves_per_simd = 2;       // its waves per SIMD: 2 (eight-wave workgroups) or 1 (build_work)
     uint32_t *order_dev = nullptr;   // its launch permutation
     VocWork *redo_dev = nullptr;
     VocWork *gen_work_dev = nullptr; // one item per frame of utterance 0 (streaming generator)

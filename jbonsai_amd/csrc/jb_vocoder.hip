@@ -1369,10 +1369,8 @@ constexpr int kLtPf = 4; // coefficient reads in flight ahead of their use (2, 3
 // then ran ALONE for 17 ms at the solo rate -- the kernel took 61.5 ms where two waves sharing the pipe to the end
 // need 58 (tools/lt_clocks.sh).  The pair now keeps level: every kLtBalance samples a wave posts its sample count
 // and raises its priority if it is behind its partner, lowers it if ahead.
-#ifndef JB_LT_WAVES
-#define JB_LT_WAVES 8
-#endif
-constexpr int kLtWaves = JB_LT_WAVES;
+// FOUR waves per workgroup = one wave per SIMD, for batches that cannot give every SIMD two waves of chunks that
+// are long against their warm-up: a lone wave issues an instruction every 6.7 cycles, one of a pair every 8.9.
 constexpr int kLtBalance = 8;
 #ifdef JB_LT_CLOCKS
 // timing aid (tools/lt_clocks.sh): shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at the
@@ -1380,7 +1378,7 @@ constexpr int kLtBalance = 8;
 __device__ unsigned long long g_lt_clk[8];
 #endif
 
-template <int NM, int TPLW>
+template <int NM, int TPLW, int kLtWaves>
 __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                                                        const VocWork *__restrict__ work,
                                                        const uint32_t *__restrict__ order,
@@ -2005,18 +2003,28 @@ bool vocoder_ls_supported(int nmcp) { return nmcp == 35 || nmcp == 25; }
 int vocoder_ls_chunks_per_wave() { return kLtChunks; }
 
 hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
-                             const uint32_t *order_dev, uint32_t n_items, hipStream_t stream)
+                             const uint32_t *order_dev, uint32_t n_items, int waves_per_simd, hipStream_t stream)
 {
     if (n_items == 0)
         return hipSuccess;
-    const uint32_t per_wg = (uint32_t)(kLtChunks * kLtWaves);
-    dim3 grid((n_items + per_wg - 1) / per_wg), block(64 * kLtWaves);
-    switch (vd.nmcp) {
-    case 35:
-        hipLaunchKernelGGL((k_vocoder_lt<35, 3>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+    if (waves_per_simd != 1 && waves_per_simd != 2)
+        return hipErrorInvalidValue;
+    const int wv = 4 * waves_per_simd;
+    const uint32_t per_wg = (uint32_t)(kLtChunks * wv);
+    dim3 grid((n_items + per_wg - 1) / per_wg), block(64 * wv);
+    const int key = vd.nmcp * 10 + wv;
+    switch (key) {
+    case 358:
+        hipLaunchKernelGGL((k_vocoder_lt<35, 3, 8>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
         break;
-    case 25:
-        hipLaunchKernelGGL((k_vocoder_lt<25, 2>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+    case 354:
+        hipLaunchKernelGGL((k_vocoder_lt<35, 3, 4>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+        break;
+    case 258:
+        hipLaunchKernelGGL((k_vocoder_lt<25, 2, 8>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
+        break;
+    case 254:
+        hipLaunchKernelGGL((k_vocoder_lt<25, 2, 4>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
         break;
     default:
         return hipErrorInvalidValue;
