@@ -79,6 +79,9 @@ def parse_args():
                          "never part of `value` (SURVEY 8e)")
     ap.add_argument("--beta", type=float, default=0.0,
                     help="post-filter coefficient (off-config: BASELINE's metric is quoted at beta = 0)")
+    ap.add_argument("--kernel", choices=("auto", "wave", "triple"), default="auto",
+                    help="vocoder kernel of the timed batch (auto = the library's choice by batch size; measurement aid)")
+    ap.add_argument("--chunk-frames", type=int, default=0, help="chunk length of the timed batch (0 = the library's choice)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
                          "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
@@ -935,7 +938,8 @@ def run_rank(args):
         batch_utts = [synth.synth_utterance(tab, T, 2000 + i) for i, T in enumerate(lens)]
     else:
         batch_utts = [utts[i % nd] for i in range(args.batch)]
-    batches = [J.Batch(vi, batch_utts, device=R.local_rank) for _ in range(depth)]
+    batches = [J.Batch(vi, batch_utts, device=R.local_rank, kernel=args.kernel, chunk_frames=args.chunk_frames)
+               for _ in range(depth)]
     batch = batches[0]
     samples_per_step = batch.total_samples
 

@@ -1064,7 +1064,7 @@ int Batch::build_work(const jb_batch_opts *opts)
     // waves of 21 chunks that are long against the warm-up (measured crossover against the wave kernel at
     // one item per SIMD: between 6 and 8 utterances of 25.5 k frames -- 22.4 vs 26.7 ms at 6, 28.5 vs 26.9
     // at 8)
-    constexpr uint64_t lp_min = 190000;
+    constexpr uint64_t lp_min = 100000;
     // (the lane-triple kernel walks the samples of a frame two at a time)
     lp_mode = !serial && !(flags & JB_BATCH_WAVE_KERNEL) && vd.stage == 0 && vocoder_ls_supported(vd.nmcp) &&
               (vd.fperiod & 1) == 0 &&
@@ -1119,6 +1119,14 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
+    if (lp_mode && ch != 0) {
+        // (a chunk length given by the caller: one wave per SIMD if the items fit)
+        uint64_t it = 0;
+        for (int i = 0; i < B; i++)
+            it += (T[(size_t)i] + ch - 1) / ch;
+        if (opts && opts->chunk_frames)
+            lt_waves_per_simd = it <= 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave() ? 1 : 2;
+    }
     // the checkpoint a failed chunk is first recomputed to (finish_verify): 32 frames into chunks of 64 and more, 24 into
     // chunks of 36 and more, 16 into chunks of 24 and more (a single 128 s utterance, 799 chunks of 32 frames: all six
     // failing hand-offs settle there and the redo is one round of 16 frames, 10.2 -> 9.2 ms per call; 8 frames into
@@ -1481,19 +1489,24 @@ int Batch::finish_verify()
     };
     std::vector<uint8_t> pending(bad);
     pending[0] = 0;
+    const bool redo_trace = getenv("JB_REDO_TRACE") != nullptr; // debugging aid: one line per redo round on stderr
     for (;;) {
         // This round: every failing chunk whose predecessor is final, AND -- speculatively -- a failing chunk
-        // behind a failing chunk that has a checkpoint: the predecessor's first-pass end state stands if it
-        // settles at its checkpoint (295 of 297 do), and stage A of a chunk with a checkpoint does not touch
-        // that dump, so both can be recomputed in the same launch.  Where the predecessor does not settle, the
-        // successor's recomputation started from a state that is about to be replaced: it stays pending for
-        // the next round.  (Before, a run of consecutive failures cost one round per chunk: 3 ms each.)
+        // behind a failing chunk: it starts from the end state its predecessor left in the FIRST pass.  That state
+        // stands if the predecessor settles at its checkpoint (295 of 297 do; stage A of a chunk with a checkpoint
+        // does not touch the dump), or, for a chunk without a checkpoint, if the end state of its recomputation
+        // -- written to a scratch dump, compared after the launch, then copied over -- meets it to the hand-off
+        // tolerance (the trajectory that started wrong has had warm-up + chunk frames to converge: every one of
+        // 156 did in a batch of 16 x 25,546 frames).  Where it does not stand, the successor's recomputation
+        // started from a state that is being replaced: it stays pending for the next round.  (Before, a run of
+        // consecutive failures cost one round per chunk: 3 ms each with checkpoints, 1.2 ms each for 20-frame
+        // chunks, two or three rounds per step in small batches.)
         std::vector<uint32_t> ids;
         std::vector<uint8_t> in_round(n_items, 0);
         for (uint32_t k = 1; k < n_items; k++) {
             if (!pending[k])
                 continue;
-            if (!pending[k - 1] || (in_round[k - 1] && work[k - 1].save_ckpt && work[k - 1].utt == work[k].utt)) {
+            if (!pending[k - 1] || (in_round[k - 1] && work[k - 1].save_end && work[k - 1].utt == work[k].utt)) {
                 ids.push_back(k);
                 in_round[k] = 1;
             }
@@ -1502,7 +1515,9 @@ int Batch::finish_verify()
             break;
         // stage A: up to the checkpoint (or the whole chunk where there is none)
         std::vector<VocWork> round;
-        std::vector<uint32_t> part; // positions in ids with a checkpoint
+        std::vector<uint32_t> part; // positions in ids whose recomputed state is compared: with a checkpoint, or
+                                    // (spec_end) recomputed to the end with a successor in this round
+        std::vector<uint8_t> spec_end(n_items, 0);
         for (size_t j = 0; j < ids.size(); j++) {
             const uint32_t k = ids[j];
             VocWork w = work[k];
@@ -1511,6 +1526,10 @@ int Batch::finish_verify()
             w.save_warm = nullptr;
             if (w.save_ckpt) {
                 w.t_end = w.t_out + vd.ckpt_frames;
+                w.save_end = tmp_state + (size_t)k * stride;
+                part.push_back((uint32_t)j);
+            } else if (k + 1 < n_items && in_round[k + 1] && work[k + 1].utt == w.utt && w.save_end) {
+                spec_end[k] = 1;
                 w.save_end = tmp_state + (size_t)k * stride;
                 part.push_back((uint32_t)j);
             }
@@ -1526,7 +1545,7 @@ int Batch::finish_verify()
             for (size_t q = 0; q < part.size(); q++) {
                 const uint32_t k = ids[part[q]];
                 pairs[2 * q] = tmp_state + (size_t)k * stride;
-                pairs[2 * q + 1] = work[k].save_ckpt;
+                pairs[2 * q + 1] = spec_end[k] ? work[k].save_end : work[k].save_ckpt;
             }
             hipMemcpy(pairs_dev, pairs.data(), sizeof(double *) * pairs.size(), hipMemcpyHostToDevice);
             hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
@@ -1540,6 +1559,13 @@ int Batch::finish_verify()
                 return hip_fail(e, "hipMemcpy(bad2)");
             for (size_t q = 0; q < part.size(); q++)
                 unsettled[ids[part[q]]] = bad2[q];
+            // the exact end state of a chunk recomputed to its end goes where the first pass left its own
+            for (size_t q = 0; q < part.size(); q++) {
+                const uint32_t k = ids[part[q]];
+                if (spec_end[k] && (e = hipMemcpyAsync(work[k].save_end, tmp_state + (size_t)k * stride, sizeof(double) * stride,
+                                                       hipMemcpyDeviceToDevice, stream_voc)) != hipSuccess)
+                    return hip_fail(e, "hipMemcpy(end state)");
+            }
         }
         // in chunk order: what this round's recomputations are worth
         std::vector<VocWork> rest;      // stage B: the rest of valid chunks that had not converged at their checkpoint
@@ -1548,8 +1574,10 @@ int Batch::finish_verify()
         for (uint32_t k : ids) {
             // valid: started from a final state -- the predecessor was final before the round, or it was in the
             // round, valid itself, and settled at its checkpoint (its first-pass end state stands)
+            // round, valid itself, and its first-pass end state stands (settled at its checkpoint / met by the end
+            // state of its recomputation)
             const bool pred_in = in_round[k - 1] && pending[k - 1];
-            const bool valid = !pred_in || (final_now[k - 1] && work[k - 1].save_ckpt && !unsettled[k - 1]);
+            const bool valid = !pred_in || (final_now[k - 1] && (work[k - 1].save_ckpt || spec_end[k - 1]) && !unsettled[k - 1]);
             if (!valid)
                 continue; // stays pending: next round, from the state its predecessor is getting now
             final_now[k] = 1;
@@ -1574,6 +1602,9 @@ int Batch::finish_verify()
         for (uint32_t k : ids)
             if (final_now[k])
                 pending[k] = 0;
+        if (redo_trace)
+            fprintf(stderr, "redo round: %zu items (%zu to a checkpoint), %zu continue past it, %u settled so far, %u to the end so far\n",
+                    ids.size(), part.size(), rest.size(), n_redo_partial, n_redo_full);
         // Re-certification.  Chunk k+1 was checked against the end state chunk k left in the first
         // pass -- the end of a trajectory now known to have started wrong.  Where chunk k has been
         // recomputed to its end, that dump now holds the exact state: compare it with the warm state of
@@ -1581,8 +1612,10 @@ int Batch::finish_verify()
         // its first-pass end state, whose trajectory was certified at the checkpoint: nothing to re-check.)
         std::vector<uint32_t> succ;
         for (uint32_t k : full_ids)
+            // (a successor that was recomputed in this round started from this chunk's end state: nothing to re-check
+            // if that was valid, and it is still pending if not)
             if (k + 1 < n_items && work[k + 1].utt == work[k].utt && work[k + 1].save_warm && !pending[k + 1] &&
-                work[k].save_end)
+                !in_round[k + 1] && work[k].save_end)
                 succ.push_back(k + 1);
         if (!succ.empty()) {
             std::vector<const double *> pairs(2 * succ.size());
@@ -1600,6 +1633,9 @@ int Batch::finish_verify()
                     hipSuccess ||
                 (e = hipStreamSynchronize(stream_voc)) != hipSuccess)
                 return hip_fail(e, "hipMemcpy(bad3)");
+            if (redo_trace)
+                fprintf(stderr, "  re-certified %zu successors: %zu fail\n", succ.size(),
+                        (size_t)std::count_if(bad3.begin(), bad3.end(), [](uint8_t x) { return x != 0; }));
             for (size_t q = 0; q < succ.size(); q++)
                 if (bad3[q]) {
                     pending[succ[q]] = 1;
