@@ -1134,6 +1134,7 @@ int Batch::build_work(const jb_batch_opts *opts)
     vd.ckpt_frames = ch >= 2 * kVocCkptFrames ? kVocCkptFrames
                      : ch >= kVocCkptFramesShort + 12 ? kVocCkptFramesShort
                      : ch >= kVocCkptFramesTiny + 8 ? kVocCkptFramesTiny : 0;
+    vd.ckpt2_frames = (vd.ckpt_frames == kVocCkptFrames && ch >= kVocCkpt2Frames + 48) ? kVocCkpt2Frames : 0;
     work.clear();
     const int stride = vd.state_stride;
     for (int i = 0; i < B; i++) {
@@ -1167,7 +1168,8 @@ int Batch::build_work(const jb_batch_opts *opts)
         // zeroed: slots of the state layout that a kernel does not write must compare equal
         if ((rc = dalloc(&end_state, (size_t)n_items * stride, true)) ||
             (rc = dalloc(&warm_state, (size_t)n_items * stride, true)) ||
-            (rc = dalloc(&ckpt_state, (size_t)n_items * stride, true)))
+            (rc = dalloc(&ckpt_state, (size_t)n_items * stride, true)) ||
+            (vd.ckpt2_frames && (rc = dalloc(&ckpt2_state, (size_t)n_items * stride, true))))
             return rc;
         state_stride = stride;
         for (uint32_t k = 0; k < n_items; k++) {
@@ -1185,6 +1187,8 @@ int Batch::build_work(const jb_batch_opts *opts)
             const uint32_t need = vd.ckpt_frames + (vd.ckpt_frames < kVocCkptFramesShort ? 8u : 12u);
             w.save_ckpt = (!first && vd.ckpt_frames && w.t_end - w.t_out >= need) ? ckpt_state + (size_t)k * stride
                                                                                    : nullptr;
+            w.save_ckpt2 = (w.save_ckpt && vd.ckpt2_frames && w.t_end - w.t_out >= vd.ckpt2_frames + 12u)
+                               ? ckpt2_state + (size_t)k * stride : nullptr;
         }
     }
     if (n_items)
@@ -1533,7 +1537,7 @@ int Batch::finish_verify()
                 w.save_end = tmp_state + (size_t)k * stride;
                 part.push_back((uint32_t)j);
             }
-            w.save_ckpt = nullptr;
+            w.save_ckpt = w.save_ckpt2 = nullptr;
             round.push_back(w);
         }
         if ((rc = run_round(round)))
@@ -1567,6 +1571,50 @@ int Batch::finish_verify()
                     return hip_fail(e, "hipMemcpy(end state)");
             }
         }
+        // second checkpoint: a chunk that had not converged at the first one goes on to it and is compared again
+        std::vector<uint8_t> at2(n_items, 0);
+        if (vd.ckpt2_frames) {
+            std::vector<VocWork> mid;
+            std::vector<uint32_t> mid_ids;
+            for (uint32_t k : ids)
+                if (work[k].save_ckpt && work[k].save_ckpt2 && unsettled[k]) {
+                    if (!tmp2_state && (rc = dalloc(&tmp2_state, (size_t)n_items * stride, true)))
+                        return rc;
+                    VocWork w = work[k];
+                    w.t_start = w.t_out = work[k].t_out + vd.ckpt_frames;
+                    w.t_end = work[k].t_out + vd.ckpt2_frames;
+                    w.load_state = tmp_state + (size_t)k * stride;
+                    w.save_end = tmp2_state + (size_t)k * stride;
+                    w.save_warm = w.save_ckpt = w.save_ckpt2 = nullptr;
+                    mid.push_back(w);
+                    mid_ids.push_back(k);
+                }
+            if (!mid.empty()) {
+                if ((rc = run_round(mid)))
+                    return rc;
+                std::vector<const double *> pairs(2 * mid_ids.size());
+                for (size_t q = 0; q < mid_ids.size(); q++) {
+                    pairs[2 * q] = tmp2_state + (size_t)mid_ids[q] * stride;
+                    pairs[2 * q + 1] = work[mid_ids[q]].save_ckpt2;
+                }
+                hipMemcpy(pairs_dev, pairs.data(), sizeof(double *) * pairs.size(), hipMemcpyHostToDevice);
+                hipMemsetAsync(nbad_dev, 0, sizeof(uint32_t), stream_voc);
+                if ((e = launch_voc_verify_pairs(pairs_dev, (uint32_t)mid_ids.size(), vd.state_stride, vd.stage > 0 ? -1 : vd.nmcp - 1,
+                                                 verify_tol, bad_dev, nbad_dev, stream_voc)) != hipSuccess)
+                    return hip_fail(e, "k_voc_verify_pairs(second checkpoint)");
+                std::vector<uint8_t> badm(mid_ids.size());
+                if ((e = hipMemcpyAsync(badm.data(), bad_dev, mid_ids.size(), hipMemcpyDeviceToHost, stream_voc)) != hipSuccess ||
+                    (e = hipStreamSynchronize(stream_voc)) != hipSuccess)
+                    return hip_fail(e, "hipMemcpy(bad, second checkpoint)");
+                for (size_t q = 0; q < mid_ids.size(); q++) {
+                    at2[mid_ids[q]] = 1;
+                    unsettled[mid_ids[q]] = badm[q];
+                }
+                if (redo_trace)
+                    fprintf(stderr, "  second checkpoint: %zu chunks, %zu still not converged\n", mid_ids.size(),
+                            (size_t)std::count_if(badm.begin(), badm.end(), [](uint8_t x) { return x != 0; }));
+            }
+        }
         // in chunk order: what this round's recomputations are worth
         std::vector<VocWork> rest;      // stage B: the rest of valid chunks that had not converged at their checkpoint
         std::vector<uint32_t> full_ids; // chunks recomputed to their end in this round
@@ -1590,10 +1638,10 @@ int Batch::finish_verify()
                 n_redo_full++;
                 full_ids.push_back(k);
                 VocWork w = work[k];
-                w.t_start = w.t_out = work[k].t_out + vd.ckpt_frames;
-                w.load_state = tmp_state + (size_t)k * stride;
+                w.t_start = w.t_out = work[k].t_out + (at2[k] ? vd.ckpt2_frames : vd.ckpt_frames);
+                w.load_state = (at2[k] ? tmp2_state : tmp_state) + (size_t)k * stride;
                 w.save_warm = nullptr;
-                w.save_ckpt = nullptr;
+                w.save_ckpt = w.save_ckpt2 = nullptr;
                 rest.push_back(w);
             }
         }

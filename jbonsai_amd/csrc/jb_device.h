@@ -167,6 +167,7 @@ struct VocDev {
     double *state;        // optional per-utterance filter state (streaming), or nullptr
     int state_stride;     // doubles per utterance
     uint32_t ckpt_frames; // checkpoint position inside a chunk (frames past t_out); 0 = no checkpoints
+    uint32_t ckpt2_frames; // second checkpoint (long chunks only), 0 = none
 };
 
 // Where the vocoder finds the excitation of frame t of an utterance (base = its first frame in the
@@ -196,6 +197,7 @@ struct VocWork {
     double *save_warm;        // state on entering t_out (after warm-up), or nullptr
     double *save_end;         // state after t_end, or nullptr
     double *save_ckpt;        // state on entering frame t_out + VocDev::ckpt_frames, or nullptr (partial redo)
+    double *save_ckpt2;       // state on entering frame t_out + VocDev::ckpt2_frames, or nullptr
 };
 // A failing chunk is first recomputed only up to VocDev::ckpt_frames frames past its start; if the
 // recomputed state meets the checkpoint the original chunk left there, the rest of the chunk stands.
@@ -203,7 +205,10 @@ struct VocWork {
 // (Batch::build_work).  A redo round lasts as long as the frames to the checkpoint (0.06 ms per frame, one wave per
 // chunk); a hand-off that failed behind 18 frames of warm-up settles there if 18 + 32 frames from zero state are
 // enough, and no position of the CPU study needed more than 43 (tests/tools/warmup_decay.py).  (48 until round 4.)
-constexpr uint32_t kVocCkptFrames = 32, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16;
+// Chunks of 128 frames and more leave a SECOND checkpoint 80 frames in: the rare chunk that has not converged at the
+// first one (4 of 325 failing hand-offs in a batch of 1024 distinct utterances) is recomputed 48 frames further and
+// compared again, instead of to its end (121 frames = 7 ms, the whole round waiting for it).
+constexpr uint32_t kVocCkptFrames = 32, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16, kVocCkpt2Frames = 80;
 
 // Timing experiments only (library built with -DJB_DBG_GATES, never the product): JB_DBG_SKIP is a bit mask of
 // launches to leave out once a launcher has been called JB_DBG_SKIP_AFTER times (default 2: bench.py's warm-up

@@ -80,6 +80,7 @@ struct Batch {
     double verify_tol = 1e-9;
     double *end_state = nullptr, *warm_state = nullptr;
     double *ckpt_state = nullptr, *tmp_state = nullptr; // partial redo: checkpoints / recomputed states
+    double *ckpt2_state = nullptr, *tmp2_state = nullptr; // the same for the second checkpoint of long chunks
     const double **pairs_dev = nullptr;
     uint32_t n_redo_partial = 0, n_redo_full = 0;   // of the last run: settled at the checkpoint / redone to the end
     uint32_t n_recert_failed = 0;                   // successors of fully redone chunks that failed re-certification

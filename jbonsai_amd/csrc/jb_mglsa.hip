@@ -312,6 +312,8 @@ __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, c
             save_state(wk.save_warm);
         if (t == t_out + vd.ckpt_frames && wk.save_ckpt)
             save_state(wk.save_ckpt);
+        if (vd.ckpt2_frames && t == t_out + vd.ckpt2_frames && wk.save_ckpt2)
+            save_state(wk.save_ckpt2);
         // frame setup (mod.rs:148-161): c = previous frame's cc (first frame: the un-filtered one)
         const double *bcur = vd.bcoef + f * (uint64_t)n;
         const double *bprev = (t > 0) ? bcur - n : vd.bfirst + (uint64_t)b * (uint64_t)n;

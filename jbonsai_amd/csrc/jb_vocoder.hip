@@ -1237,6 +1237,8 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
             save_state(wk.save_warm);
         if (t == t_out + vd.ckpt_frames && wk.save_ckpt)
             save_state(wk.save_ckpt);
+        if (vd.ckpt2_frames && t == t_out + vd.ckpt2_frames && wk.save_ckpt2)
+            save_state(wk.save_ckpt2);
         // ---- frame setup (vocoder/mod.rs:116-125) ----
         // c at frame start = previous frame's cc exactly (mod.rs:140); first frame: c = cc.
         const double *bcur = vd.bcoef + f * (uint64_t)nmcp;
@@ -1519,6 +1521,11 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
         }
         if (act && t == wk.t_out + vd.ckpt_frames) {
             double *sc_ = work[item].save_ckpt;
+            if (sc_)
+                save_state(sc_);
+        }
+        if (act && vd.ckpt2_frames && t == wk.t_out + vd.ckpt2_frames) {
+            double *sc_ = work[item].save_ckpt2;
             if (sc_)
                 save_state(sc_);
         }
