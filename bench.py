@@ -746,13 +746,14 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
         nd = 64
         du = [batch_utts[0]] + [synth.synth_utterance(tab, frames, 1000 + i) for i in range(1, nd)]
         bd = J.Batch(vi, [du[i % nd] for i in range(args.batch)], device=R.local_rank)
-        bd.run()
-        bd.sync()
-        t0 = time.perf_counter()
-        for _ in range(3):
+        for _ in range(2):
             bd.run()
             bd.sync()
-        ex["distinct_64"] = {"ms_per_step": (time.perf_counter() - t0) / 3 * 1e3,
+        t0 = time.perf_counter()
+        for _ in range(8):
+            bd.run()
+            bd.sync()
+        ex["distinct_64"] = {"ms_per_step": (time.perf_counter() - t0) / 8 * 1e3, "steps": 8,
                              "chunks_redone": bd.info()["n_redo"],
                              "settled_at_checkpoint": bd.redo_stats()[0], "redone_to_end": bd.redo_stats()[1]}
         bd.close()
@@ -834,10 +835,10 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
 CONFIG45_FRAMES = 6386  # 1024 x 6386 = 6,539,264 frames: config 2's total (256 x 25,546 = 6,539,776)
 
 
-def resident_record(J, vi, R, n_utts, tabs, weights, id0, workload, steps=3):
+def resident_record(J, vi, R, n_utts, tabs, weights, id0, workload, steps=6):
     """One resident batch of n_utts distinct synthetic utterances created from pdf row indices (one voice:
     tabs = [tab]; several: rows of every voice + weights), timed like the headline: `steps` steps after
-    one warm-up, inputs resident.  Carries its own ms_per_step, redo counts and roofline fraction."""
+    two warm-up steps, inputs resident.  Carries its own ms_per_step, redo counts and roofline fraction."""
     from jbonsai_amd import synth
 
     pset = synth.voice_set_pdf_set(tabs, R.local_rank)
@@ -851,8 +852,9 @@ def resident_record(J, vi, R, n_utts, tabs, weights, id0, workload, steps=3):
         b = J.Batch(vi, utts, device=R.local_rank, pdf_set=pset)
         create_ms = (time.perf_counter() - t0) * 1e3
         try:
-            b.run()
-            b.sync()
+            for _ in range(2):
+                b.run()
+                b.sync()
             voc = []
             t0 = time.perf_counter()
             for _ in range(steps):
