@@ -150,8 +150,9 @@ struct VocDev {
     // position (k_exc_table, once per run, the arithmetic of the per-frame pass); the per-frame pass
     // (k_exc_general) then only computes the frames of exc_gen (frames at a voiced/unvoiced boundary, frames
     // whose taps differ, first frames), and the pulse pass writes a row of xin only for frames a pulse reaches.
-    // exc_src[f]: where the vocoder finds frame f's excitation -- 0 its row of xin, 1 the noise stream
-    // (unvoiced behind unvoiced), 2 exc_tab.
+    // exc_src[f]: where the vocoder finds frame f's excitation -- bits 0..1: 0 its row of xin, 1 the noise stream
+    // (unvoiced behind unvoiced), 2 exc_tab; bits 4..7 (with 2): the blocks of bs samples that a pulse reaches and
+    // that therefore have a piece of a row of their own in xin (the pulse pass writes only those: round 4).
     double *exc_tab;          // [maxT * fperiod]
     const uint8_t *lpf_canon; // [sumT] StreamDev::canon of the LPF stream, or nullptr: k_exc_classify compares the rows
     uint8_t *exc_src;         // [sumT]
@@ -170,21 +171,24 @@ struct VocDev {
     uint32_t ckpt2_frames; // second checkpoint (long chunks only), 0 = none
 };
 
-// Where the vocoder finds the excitation of frame t of an utterance (base = its first frame in the
-// concatenated arrays): the stored row of xin, or -- for a frame the excitation kernels skipped -- the
-// shared noise stream at the frame's first sample minus the ring buffer's delay.
-__device__ __forceinline__ const double *exc_frame_ptr(const VocDev &vd, uint64_t base, uint32_t t)
+// Where the vocoder finds the excitation of block q (bs samples) of frame t of an utterance (base = its first
+// frame in the concatenated arrays): the stored row of xin, or -- for a frame the excitation kernels skipped -- the
+// shared noise stream at the frame's first sample minus the ring buffer's delay, or the shared pulse-free table.
+// exc_code: the frame's exc_src byte (or its equivalent where there is none); exc_block_ptr: a pointer p with
+// p[i] = sample i OF THE FRAME, valid for the samples of block q.
+__device__ __forceinline__ uint32_t exc_code(const VocDev &vd, uint64_t base, uint32_t t)
 {
-    if (vd.exc_src) {
-        const uint32_t code = vd.exc_src[base + t];
-        if (code == 1)
-            return vd.noise + ((uint64_t)t * (uint64_t)vd.fperiod - (uint64_t)((vd.nlpf - 1) / 2));
-        if (code == 2)
-            return vd.exc_tab + (uint64_t)t * (uint64_t)vd.fperiod;
-        return vd.xin + (base + t) * (uint64_t)vd.fperiod;
-    }
-    if (vd.skip_unvoiced && t >= 1 && !vd.voiced[base + t] && !vd.voiced[base + t - 1])
+    if (vd.exc_src)
+        return vd.exc_src[base + t];
+    return (vd.skip_unvoiced && t >= 1 && !vd.voiced[base + t] && !vd.voiced[base + t - 1]) ? 1u : 0u;
+}
+__device__ __forceinline__ const double *exc_block_ptr(const VocDev &vd, uint64_t base, uint32_t t, uint32_t code, int q)
+{
+    const uint32_t src = code & 3u;
+    if (src == 1)
         return vd.noise + ((uint64_t)t * (uint64_t)vd.fperiod - (uint64_t)((vd.nlpf - 1) / 2));
+    if (src == 2 && !((code >> (4 + q)) & 1u))
+        return vd.exc_tab + (uint64_t)t * (uint64_t)vd.fperiod;
     return vd.xin + (base + t) * (uint64_t)vd.fperiod;
 }
 

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, c
         const double c0t = bcur[0], c0inc = (c0t - c0) / (double)fp;
         for (int q = 0; q < nblk; q++) {
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)(q * bs);
-            const double xin = lane < bs ? exc_frame_ptr(vd, base, t)[q * bs + lane] : 0.0;
+            const double xin = lane < bs ? exc_block_ptr(vd, base, t, exc_code(vd, base, t), q)[q * bs + lane] : 0.0;
             double ob = 0.0;
             for (int i = 0; i < bs; i++) {
                 double x = sg_readlane(xin, i) * c0; // x *= coefficients[0] (mod.rs:164)

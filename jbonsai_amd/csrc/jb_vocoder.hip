@@ -922,6 +922,14 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     static_assert(kFixFrames * 4 <= 32, "one lane per (frame, mask word), twice");
     const int s0 = lane * kExw; // this lane's samples s0 .. s0+3 of the frame
     const bool own = s0 < fp;
+    // A frame that stood on the shared table gets pieces of a row of its own only for the BLOCKS (bs samples) a pulse
+    // reaches; exc_src tells the vocoder which (a pulse's 31 samples lie in one or two of a frame's four blocks: the
+    // rows were 17 GB written and read back per step of config 2).  Needs a lane's samples in one block and, for the
+    // throughput kernel's pointer hand-over, blocks of an even number of samples; otherwise whole rows as before.
+    const bool blk_rows = bs % kExw == 0 && bs % 2 == 0 && nblk <= 4;
+    int myblk = 0;
+    for (int q = 1; q < nblk; q++)
+        myblk += s0 >= q * bs ? 1 : 0;
     const int tail0 = fp - H; // first sample of the previous frame whose pulse reaches into this one
     unsigned long long mword = 0ull;
     uint32_t vfl = 0, codev = 0; // codev: exc_src of frame jf on lane 4 * jf + 1
@@ -982,6 +990,7 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     static_assert(kFixFrames % kFixGroup == 0, "whole groups");
     for (int j0 = 0; j0 < kFixFrames; j0 += kFixGroup) {
         bool work[kFixGroup], touched[kFixGroup], from_tab[kFixGroup];
+        uint32_t bmask[kFixGroup];
         double tv[kFixGroup], pv[kFixGroup], x[kFixGroup][kExw];
 #pragma unroll
         for (int g = 0; g < kFixGroup; g++) {
@@ -989,6 +998,7 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             const uint32_t fr = (uint32_t)__builtin_amdgcn_readfirstlane(
                 (int)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv));
             work[g] = touched[g] = from_tab[g] = false;
+            bmask[g] = 0;
             tv[g] = pv[g] = 0.0;
 #pragma unroll
             for (int r = 0; r < kExw; r++)
@@ -1002,11 +1012,20 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
             const bool any_p = (m8 & 0xFu) != 0, any_c = (m8 >> 4) != 0;
             bool tch = false;
             each_pulse(jf, m8, [&](int p, int, int) { tch = tch || (s0 + kExw - 1 >= p && s0 <= p + H); });
-            // a frame that stood on the shared table until now (exc_src 2) gets a row of its own: every lane
-            // takes its samples from the table and writes them with the pulse terms added
-            from_tab[g] = __builtin_amdgcn_readlane((int)codev, 4 * jf + 1) == 2;
+            // a frame that stood on the shared table until now (exc_src 2) gets (pieces of) a row of its own: the lanes
+            // of the blocks a pulse reaches take their samples from the table and write them with the pulse terms added
+            from_tab[g] = (__builtin_amdgcn_readlane((int)codev, 4 * jf + 1) & 3) == 2;
             work[g] = true;
-            touched[g] = (tch || from_tab[g]) && own;
+            bool in_blk = true;
+            if (from_tab[g] && blk_rows) {
+                uint32_t bm = 0;
+                for (int q = 0; q < nblk; q++)
+                    if (__ballot(tch && own && myblk == q))
+                        bm |= 1u << q;
+                bmask[g] = bm;
+                in_blk = ((bm >> myblk) & 1u) != 0;
+            }
+            touched[g] = (tch || (from_tab[g] && in_blk)) && own;
             {
                 // taps of the previous frame (lanes 0..31; only if one of its last H samples holds a pulse: one
                 // frame in eight) and of this one (lanes 32..63), lane = tap
@@ -1070,8 +1089,8 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                     *reinterpret_cast<double2 *>(vd.exc + o + 2) = make_double2(x[g][2], x[g][3]);
                 }
             }
-            if (from_tab[g] && lane == 0)
-                vd.exc_src[f] = 0; // the vocoder reads the row
+            if (from_tab[g] && lane == 0) // the vocoder reads the row (whole, or the blocks named in bits 4..7)
+                vd.exc_src[f] = blk_rows ? (uint8_t)(2u | (bmask[g] << 4)) : (uint8_t)0;
         }
     } // groups of frames
 }
@@ -1262,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
             const int i0 = q * bs; // first sample of block within frame
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)i0; // within utterance
             // excitation (gain applied) of this block, lane = sample (k_excite)
-            const double xin = lane < bs ? exc_frame_ptr(vd, base, t)[i0 + lane] : 0.0;
+            const double xin = lane < bs ? exc_block_ptr(vd, base, t, exc_code(vd, base, t), q)[i0 + lane] : 0.0;
             // =========== Phase B: bs serial filter steps ===========
             double ob = 0.0;
             for (int i = 0; i < bs; i++) {
@@ -1545,9 +1564,14 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
                 gqs[ci] = exp((bcur[0] - bprev[0]) / (double)fp);
         }
         JB_LT_FENCE();
-        const double *xp = exc_frame_ptr(vd, base, t);
+        // the excitation of a frame comes block by block (bs samples): its row of xin, the shared table or the
+        // noise stream (exc_block_ptr); a lane without work reads the noise table
+        const uint32_t xcode = act ? exc_code(vd, base, t) : 1u;
+        const int xbs = vd.bs;
+        auto xblock = [&](int q) -> const double * { return act ? exc_block_ptr(vd, base, t, xcode, q) : vd.noise; };
+        const double *xq = xblock(0);
         double *op = vd.pcm + (base + t) * (uint64_t)fp;
-        double xn = act ? xp[0] : 0.0;
+        double xn = act ? xq[0] : 0.0;
         const double gq = gqs[ci];
         // The next sample's excitation is requested at the top of a sample and used at the top of the next
         // one, a whole sample (~1.5 us) later.  Two things made that load cost 3.7 of the kernel's 66 ms
@@ -1559,7 +1583,6 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
         // one sample late -- at the top of a sample, before the load is issued, so that what the wait
         // covers is a whole sample old.  (Moving the excitation through an LDS ring filled by LDS-DMA, and
         // a wait that counts the stores, both cost more than they saved: tools/experiments/.)
-        const double *xq = act ? xp : vd.noise;
         double oA = 0.0, oB = 0.0;
         auto put_pair = [&](int at) { // samples at, at+1 of this frame
             if (vd.pcm16)
@@ -1742,7 +1765,16 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
         };
         // (this form needs an even frame period: checked on the host, which otherwise builds chunks for
         // the wave kernel)
+        int xnext = xbs, xqn = 1; // first sample and number of the next block
         for (int i2 = 0; i2 < fp; i2 += 2) {
+            // the requests of this pair of samples are for samples i2 + 2, i2 + 3: on to the next block's source
+            // (blocks of an even number of samples; with an odd one the pulse pass writes whole rows and the
+            // pointer of block 0 serves the frame)
+            if (i2 + 2 == xnext && xnext < fp) {
+                xq = xblock(xqn);
+                xqn++;
+                xnext += xbs;
+            }
             if (kLtWaves == 8 && i2 % kLtBalance == 0) {
                 // keep level with the wave that shares this SIMD (w ^ 4): post the sample count, read the partner's
                 // (0xffffffff once it has left), and take the higher issue priority if behind.  The LDS queue is
