@@ -819,6 +819,17 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->frame_off[n] = sumT;
     b->sumT = sumT;
     b->maxT = maxT;
+    // one inverse-variance table per distinct variance array (256 copies of an utterance: one table of 2.5 MB that
+    // stays in L2 instead of 256 of them, 640 MB, behind the build's gathers)
+    for (uint32_t si = 0; si < voice->nstream; si++) {
+        std::map<std::pair<const void *, uint32_t>, size_t> first;
+        for (size_t i = 0; i < n; i++) {
+            auto it = first.emplace(std::make_pair((const void *)hu[i].st[si].var, hu[i].S), i).first;
+            const bool shared = hu[i].st[si].var != nullptr && it->second != i;
+            hu[i].ivar_state_off[si] = shared ? hu[it->second].state_off : hu[i].state_off;
+            hu[i].ivar_owner[si] = shared ? 0 : 1;
+        }
+    }
 
     if ((rc = b->flush_uploads()))
         return rc;

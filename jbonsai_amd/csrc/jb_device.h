@@ -39,6 +39,10 @@ struct UttDev {
     uint64_t state_off;       // first state in concatenated state scratch
     const uint32_t *dur;      // [S]
     StreamStatesDev st[kMaxStream];
+    // the inverse-variance table of a stream (StreamDev::ivar) is a function of the variance array alone: utterances
+    // that share one (copies of an utterance: uploads are de-duplicated) share the table of the first of them
+    uint64_t ivar_state_off[kMaxStream]; // first row of this utterance's table
+    uint8_t ivar_owner[kMaxStream];      // 1: this utterance computes it (k_mlpg_ivar)
 };
 
 struct StreamDev {

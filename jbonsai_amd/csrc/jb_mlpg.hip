@@ -320,10 +320,10 @@ __global__ __launch_bounds__(256) void k_mlpg_ivar(BatchDev bd, StreamDev sd, in
     const uint32_t WL = (uint32_t)(sd.W * sd.L);
     const uint64_t n = (uint64_t)up->S * WL;
     const uint64_t e0 = (uint64_t)blockIdx.x * (256u * kIvarPer) + threadIdx.x;
-    if (e0 >= n)
+    if (e0 >= n || !up->ivar_owner[si])
         return;
     const double *var = up->st[si].var;
-    double *out = sd.ivar + up->state_off * (uint64_t)WL;
+    double *out = sd.ivar + up->ivar_state_off[si] * (uint64_t)WL;
     double v[kIvarPer];
 #pragma unroll
     for (int k = 0; k < kIvarPer; k++) {
@@ -390,7 +390,7 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
         f_r[threadIdx.x] = dr;
     }
     __syncthreads();
-    const double *ivt = sd.ivar + up->state_off * (uint64_t)(W * L);
+    const double *ivt = sd.ivar + up->ivar_state_off[si] * (uint64_t)(W * L);
     const double *mnt = st.mean;
     const int pitch = kBuildTF + 1, plane = L * pitch;
     const int WL = W * L;
