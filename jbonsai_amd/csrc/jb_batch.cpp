@@ -1273,11 +1273,20 @@ static hipError_t excite_noise_hook(void *ctx, hipStream_t stream)
     (void)stream;
     hipEventRecord(b->ev_fb, stream); // the MCP band solve is enqueued up to here (the hook runs between it and the GV)
     // the LPF chain starts behind the MCP chain's inverse-variance pass: both stream at HBM rate, and side by
-    // side (with the LF0 band solve) the pass on the critical chain took 3.1 ms instead of 0.5 (-0.45 ms per step)
+    // side (with the LF0 band solve) the pass on the critical chain took 3.1 ms instead of 0.5 (-0.45 ms per step).
+    // (Behind the MCP BUILD instead -- JB_DBG_SCHED bit 2 of the -DJB_DBG_GATES library: -0.5 ms per step on one
+    // box, +0.45 on another for config 2, -0.7 for 1024 x 6,386 frames: not kept.)
     hipStreamWaitEvent(b->stream_lpf, b->ev_ivar, 0);
 #ifdef JB_DBG_GATES
     if (dbg_sched() & 2)
         hipStreamWaitEvent(b->stream_lpf, b->ev_mcpbuild, 0);
+    if (dbg_sched() & 1) { // the LF0 chain's MLPG, pitch and pulse walk behind the MCP build
+        hipStreamWaitEvent(b->stream_lf0, (dbg_sched() & 4) ? b->ev_fb : b->ev_mcpbuild, 0);
+        if ((e = launch_mlpg(b->bd, b->sd[1], 1, b->stream_lf0, nullptr)) != hipSuccess ||
+            (e = launch_pitch(b->bd, b->vd, b->stream_lf0)) != hipSuccess ||
+            (e = launch_pulse(b->bd, b->vd, b->stream_lf0)) != hipSuccess)
+            return e;
+    }
 #endif
     if (b->voice.nstream > 2) {
         if ((e = launch_prep(b->bd, b->sd[2], 2, b->stream_lpf)) != hipSuccess)
@@ -1369,12 +1378,17 @@ int Batch::enqueue_paramgen()
     if ((e = launch_prep(bd, sd[1], 1, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_prep(lf0)");
     hipEventRecord(ev_prep, stream_lf0); // voiced flags of the LF0 stream
+#ifdef JB_DBG_GATES
+    if (!(dbg_sched() & 1))
+#endif
+    {
     if ((e = launch_mlpg(bd, sd[1], 1, stream_lf0, nullptr)) != hipSuccess)
         return hip_fail(e, "k_mlpg(lf0)");
     if ((e = launch_pitch(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_pitch");
     if ((e = launch_pulse(bd, vd, stream_lf0)) != hipSuccess)
         return hip_fail(e, "k_pulse");
+    }
     // MCP chain (the critical path); between its band solve and its GV sweeps the hook enqueues
     // the LPF chain (side stream) and the pulse-free excitation pass (main stream)
     if ((e = launch_prep(bd, sd[0], 0, stream)) != hipSuccess)
