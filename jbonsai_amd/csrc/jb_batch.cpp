@@ -1023,6 +1023,11 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                         break;
                     }
                 vd.lpf_canon = sl.canon;
+                // the canonical rows themselves need not be stored unless the track is a result
+                if (sl.L <= 32 && !(b->flags & JB_BATCH_KEEP_TRACKS)) {
+                    sl.canon_skip_rows = 1;
+                    vd.lpf_sparse = 1;
+                }
             }
         }
         if ((rc = b->dalloc(&vd.exc_tab, std::max<size_t>((size_t)maxT * (size_t)vd.fperiod, 1), false)) ||

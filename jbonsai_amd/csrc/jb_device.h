@@ -97,6 +97,9 @@ struct StreamDev {
     uint8_t *canon;     // [canon_n = sumT]
     uint64_t canon_n;
     uint32_t canon_ref_utt;
+    // 1: k_mlpg_static does not STORE a canonical row (but the batch's first): its readers take row 0 instead
+    // (VocDev::lpf_sparse).  Not with JB_BATCH_KEEP_TRACKS: then the track is a result.
+    int canon_skip_rows;
 };
 
 // Control block of one launch of k_mlpg_gv_gang (zeroed before the launch) and per-gang records.
@@ -159,6 +162,8 @@ struct VocDev {
     // that therefore have a piece of a row of their own in xin (the pulse pass writes only those: round 4).
     double *exc_tab;          // [maxT * fperiod]
     const uint8_t *lpf_canon; // [sumT] StreamDev::canon of the LPF stream, or nullptr: k_exc_classify compares the rows
+    int lpf_sparse;           // 1: rows of vd.lpf exist only for frames with lpf_canon == 0 and for frame 0 of the
+                              // batch, which every canonical frame's row equals bit for bit (lpf_row below)
     uint8_t *exc_src;         // [sumT]
     uint32_t *exc_gen;        // [sumT][2] = (utterance, frame | vcur << 30 | vprev << 31)
     uint32_t *exc_gen_count;  // [1]
@@ -174,6 +179,12 @@ struct VocDev {
     uint32_t ckpt_frames; // checkpoint position inside a chunk (frames past t_out); 0 = no checkpoints
     uint32_t ckpt2_frames; // second checkpoint (long chunks only), 0 = none
 };
+
+// The row of LPF taps of frame f (index in the concatenated arrays), NL taps per row
+__device__ __forceinline__ const double *lpf_row(const VocDev &vd, uint64_t f, int NL)
+{
+    return vd.lpf + ((vd.lpf_sparse && vd.lpf_canon[f]) ? 0ull : f) * (uint64_t)NL;
+}
 
 // Where the vocoder finds the excitation of block q (bs samples) of frame t of an utterance (base = its first
 // frame in the concatenated arrays): the stored row of xin, or -- for a frame the excitation kernels skipped -- the

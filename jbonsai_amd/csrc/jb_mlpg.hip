@@ -734,6 +734,47 @@ __global__ void k_mlpg_solve(BatchDev bd, StreamDev sd, int si)
 // Single static window [c], no GV (the LPF stream): the band system is diagonal,
 // D = c*ivar*c, g = c*ivar*mean, par = g/D (mlpg.rs:25-115 with width 1), so the
 // whole MlpgAdjust::create is elementwise: thread per (frame, dim), no workspace.
+// The same with the canonical-row bookkeeping done per ROW (vector lengths up to 32: the LPF stream): 32 lanes per
+// frame, so that one ballot says whether the whole row equals the batch's first row -- and then the row need not be
+// stored at all (canon_skip_rows: its readers take row 0, VocDev::lpf_sparse): 1.6 GB per step of config 2, where
+// every voiced frame's row is the same.  canon[] is written for every frame (no preset needed).
+__global__ __launch_bounds__(256) void k_mlpg_static_rows(BatchDev bd, StreamDev sd, int si)
+{
+    const int b = blockIdx.y;
+    const UttDev *up = bd.utt + b;
+    struct { uint32_t T; uint64_t frame_off; } u = {up->T, up->frame_off};
+    const int L = sd.L;
+    const uint32_t t = blockIdx.x * 8u + (threadIdx.x >> 5);
+    if (t >= u.T)
+        return; // (a whole row of lanes: the ballot below is per row; an empty utterance has no frame to read)
+    const int m = threadIdx.x & 31;
+    const bool act = m < L;
+    const uint64_t base = u.frame_off;
+    const uint32_t tc = t;
+    const int mc = m < L ? m : 0;
+    const StreamStatesDev st = up->st[si];
+    const uint8_t vo = sd.voiced[base + tc];
+    const uint32_t s = sd.fstate[base + tc];
+    const uint64_t pi = (uint64_t)s * (uint64_t)L + (uint64_t)mc;
+    const double var = st.var[pi], mean = st.mean[pi];
+    const UttDev *ur = bd.utt + sd.canon_ref_utt;
+    const uint64_t pr = (uint64_t)sd.fstate[ur->frame_off] * (uint64_t)L + (uint64_t)mc;
+    const StreamStatesDev sr = ur->st[si];
+    const bool eq = __double_as_longlong(sr.var[pr]) == __double_as_longlong(var) &&
+                    __double_as_longlong(sr.mean[pr]) == __double_as_longlong(mean) && vo == sd.voiced[ur->frame_off];
+    const unsigned long long bal = __ballot(eq || !act);
+    const bool row_eq = (uint32_t)(bal >> (threadIdx.x & 32)) == 0xFFFFFFFFu;
+    const double c = sd.win_coef[0];
+    const double wu = c * with_ivar(var);
+    const double wum = 0.0 + wu * mean;
+    const double d0 = 0.0 + wu * c;
+    const double v = vo ? wum / d0 : kNoData;
+    if (act && !(sd.canon_skip_rows && row_eq && base + t != 0))
+        sd.out[(base + t) * (uint64_t)L + (uint64_t)m] = v;
+    if (m == 0)
+        sd.canon[base + t] = row_eq ? 1 : 0;
+}
+
 __global__ void k_mlpg_static(BatchDev bd, StreamDev sd, int si)
 {
     const int b = blockIdx.y;
@@ -2488,6 +2529,13 @@ static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int
         if (work == 0 || bd.B == 0)
             return hipSuccess;
         dim3 grid((unsigned)((work + 255) / 256), bd.B), block(256);
+        if (sd.canon && sd.canon_n && sd.L <= 32) {
+            dim3 grid_rows((bd.maxT + 7) / 8, bd.B);
+            JB_DBG_SKIP_IF(256, hipLaunchKernelGGL(k_mlpg_static_rows, grid_rows, block, 0, stream, bd, sd, si));
+            if (after_build)
+                (void)hipEventRecord(after_build, stream);
+            return hipGetLastError();
+        }
         if (sd.canon && sd.canon_n) {
             hipError_t e = hipMemsetAsync(sd.canon, 1, sd.canon_n, stream);
             if (e != hipSuccess)

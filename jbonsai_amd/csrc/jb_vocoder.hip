@@ -858,7 +858,7 @@ __global__ __launch_bounds__(256) void k_exc_general(BatchDev bd, VocDev vd)
         const uint64_t fprev = fr > 0 ? f - 1 : f;
         const long n0 = (long)fr * (long)fp;
         double x[kExw];
-        const bool own = exc_pulse_free<NLPF>(vd, fp, n0, vd.lpf + f * (uint64_t)NLPF, vd.lpf + fprev * (uint64_t)NLPF,
+        const bool own = exc_pulse_free<NLPF>(vd, fp, n0, lpf_row(vd, f, NLPF), lpf_row(vd, fprev, NLPF),
                                               vcur, vprev, lane, ec_s[wv], ep_s[wv], xs_s[wv], x);
         if (own) {
             const uint64_t o = base * (uint64_t)fp + (uint64_t)n0 + (uint64_t)(lane * kExw);
@@ -933,6 +933,7 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
     const int tail0 = fp - H; // first sample of the previous frame whose pulse reaches into this one
     unsigned long long mword = 0ull;
     uint32_t vfl = 0, codev = 0; // codev: exc_src of frame jf on lane 4 * jf + 1
+    uint32_t cnv = 0;            // lane 4 * jf + 2 (+ 32): the frame's (the frame before's) LPF row is the canonical one
     {
         const int half = lane >> 5, jf = (lane & 31) / 4, q = lane & 3;
         const long frl = (long)((blockIdx.x * (uint32_t)kFixFrames + (uint32_t)jf) * 4u + (uint32_t)wv) - half;
@@ -941,6 +942,8 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                 vfl = vd.voiced[base + (uint64_t)frl];
             if (q == 1 && half == 0 && vd.exc_src)
                 codev = vd.exc_src[base + (uint64_t)frl];
+            if (q == 2 && vd.lpf_sparse)
+                cnv = vd.lpf_canon[base + (uint64_t)frl];
             if (q < nblk)
                 mword = vd.pmask[(base + (uint64_t)frl) * (uint64_t)nblk + (uint64_t)q];
         }
@@ -1030,8 +1033,11 @@ __global__ __launch_bounds__(256) void k_excite_fix(BatchDev bd, VocDev vd)
                 // taps of the previous frame (lanes 0..31; only if one of its last H samples holds a pulse: one
                 // frame in eight) and of this one (lanes 32..63), lane = tap
                 const int hw = lane >> 5, k = lane & 31;
+                // (a canonical row is not stored: row 0 of the batch holds the same bits)
+                const uint32_t cn_c = (uint32_t)__builtin_amdgcn_readlane((int)cnv, 4 * jf + 2);
+                const uint32_t cn_p = (uint32_t)__builtin_amdgcn_readlane((int)cnv, 32 + 4 * jf + 2);
                 if (k < NLPF && (hw ? any_c : any_p))
-                    tv[g] = vd.lpf[(f - 1 + (uint64_t)hw) * (uint64_t)NLPF + (uint64_t)k];
+                    tv[g] = vd.lpf[((hw ? cn_c : cn_p) ? 0ull : f - 1 + (uint64_t)hw) * (uint64_t)NLPF + (uint64_t)k];
                 // amplitude parameters: lanes 0,1 = cur_start, pinc of the previous frame; 2,3 = of this one
                 if (lane < 4 && ((lane >> 1) ? any_c : any_p)) {
                     const uint64_t ff = f - 1 + (uint64_t)(lane >> 1);
