@@ -918,6 +918,25 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                     uint8_t *ctl;
                     if ((rc = b->dalloc(&ctl, gv_gang_ctl_bytes(gangs), true)))
                         return rc;
+                    // bins of utterances whose rows share a pass of a gang (the frames of an MSD stream's rows are
+                    // counted on the device: its utterances keep a pass each, tiles by their upper bound)
+                    std::vector<uint8_t> has_gv(n);
+                    std::vector<uint32_t> Tb(n);
+                    for (size_t i = 0; i < n; i++) {
+                        has_gv[i] = hu[i].st[si].gv_mean != nullptr;
+                        Tb[i] = sd.is_msd ? maxT : b->T[i];
+                    }
+                    std::vector<GvBinEntry> bins;
+                    gv_gang_bins(Tb.data(), has_gv.data(), order.data(), n, tiles, bins);
+                    GvBinEntry *dbins;
+                    if ((rc = b->dalloc(&dbins, bins.size(), false)))
+                        return rc;
+                    if ((e = hipMemcpy(dbins, bins.data(), sizeof(GvBinEntry) * bins.size(), hipMemcpyHostToDevice)) != hipSuccess)
+                        return hip_fail(e, "hipMemcpy(gv bins)");
+                    sd.gv_bins = dbins;
+                    sd.gv_nbins = (uint32_t)(bins.size() / (size_t)tiles);
+                    if ((uint32_t)gangs > sd.gv_nbins * (uint32_t)sd.L)
+                        gangs = (int)(sd.gv_nbins * (uint32_t)sd.L);
                     sd.gv_gang_ctl = ctl;
                     sd.gv_gang_n = gangs;
                     sd.gv_gang_tiles = tiles;

@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace jb {
 
@@ -68,6 +69,11 @@ struct StreamDev {
     // this batch; null = the multi-launch sweeps (k_mlpg_gv_tp)
     void *gv_gang_ctl;
     int gv_gang_n, gv_gang_tiles;
+    // rows of several SHORT utterances share one pass of a gang (round 4): a bin = utterances whose tiles fit the
+    // gang's, entry [bin][tile] = which utterance and which of its tiles that workgroup works on; the queue hands
+    // out (bin, dim) groups.  (A ragged batch -- BASELINE config 3 -- took 16.4 ms where equal lengths take 8.)
+    const struct GvBinEntry *gv_bins; // [gv_nbins][gv_gang_tiles]
+    uint32_t gv_nbins;
     // ---- per-state scratch written by k_prep_states (concatenated states) ----
     uint32_t *s_start;  // [sumS] first frame of state
     uint32_t *s_vpre;   // [sumS] voiced frames before state (compaction offset)
@@ -102,6 +108,12 @@ struct StreamDev {
     int canon_skip_rows;
 };
 
+// One workgroup's share of a bin (above): utterance b (0xffffffff: none), tile k of its nt tiles, which stand at
+// tiles t0 .. t0 + nt - 1 of the gang; flags bit 0: some utterance of the bin has a GV pdf and frames.
+struct GvBinEntry {
+    uint32_t b;
+    uint8_t k, t0, nt, flags;
+};
 // Control block of one launch of k_mlpg_gv_gang (zeroed before the launch) and per-gang records.
 constexpr int kGvGangMaxTiles = 64; // workgroups per gang (one poller lane each): rows of up to 64 tiles
 struct GvGangCtl {
@@ -293,6 +305,9 @@ hipError_t launch_mlpg(const BatchDev &bd, const StreamDev &sd, int stream_index
 // resident GV: plan (0 = not applicable: row too long for a gang, no device capacity), bytes of the
 // control block for n gangs, launch (memset of the control block + the persistent kernel)
 int gv_gang_plan(int device, uint32_t maxT, uint32_t n_rows, int *tiles_per_gang, int *n_gangs);
+// bins of utterances (first fit in launch order, longest first) for gangs of tiles_per_gang tiles; out: [bins][tiles]
+void gv_gang_bins(const uint32_t *T, const uint8_t *has_gv, const uint32_t *order, size_t n, int tiles_per_gang,
+                  std::vector<GvBinEntry> &out);
 size_t gv_gang_ctl_bytes(int n_gangs);
 hipError_t launch_gv_gang(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream);
 int mlpg_mt_max_dim();      // largest vector length served by the [dim][frame] fast path

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
     __shared__ int sh_i[2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double *xs = xs_all[wv];
-    const uint32_t total_rows = (uint32_t)bd.B * (uint32_t)sd.L;
+    const uint32_t total_rows = sd.gv_nbins * (uint32_t)sd.L; // (bin, dim) groups of rows
 
     // ---- ticket -> (gang, tile) ----
     if (tid == 0)
@@ -427,10 +427,11 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         dead = sh_i[0] == 0;
         kbar++;
     };
-    // the three sums of an exchange, tiles in order (idle tiles contributed zeros)
+    // the three sums of an exchange: the tiles of THIS workgroup's row, in order (its idle tiles contributed zeros)
+    int sum_t0 = 0, sum_t1 = 0;
     auto gather = [&](double &S1, double &S2, double &H) {
         S1 = S2 = H = 0.0;
-        for (int j = 0; j < NTg; j++) {
+        for (int j = sum_t0; j < sum_t1; j++) {
             S1 += recs[j][0];
             S2 += recs[j][1];
             H += recs[j][2];
@@ -470,7 +471,9 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
     struct RowInfo {
         uint32_t n, gvl;
         int m;
-        bool live;
+        bool live;   // this workgroup's row takes part in GV (the reference returns early otherwise)
+        bool active; // some row of the group may: the group runs its six exchanges
+        int k, t0, nt; // tile of the row this workgroup is, the row's tiles in the gang
         uint64_t rowoff, frame_off;
         double gv_mean, gv_vari;
     };
@@ -478,13 +481,20 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         RowInfo ri{};
         if (r >= total_rows)
             return ri;
-        const int b = (int)bd.order[r / (uint32_t)sd.L];
+        const GvBinEntry en = sd.gv_bins[(uint64_t)(r / (uint32_t)sd.L) * (uint64_t)NTg + (uint64_t)tile];
+        ri.active = (en.flags & 1u) != 0;
+        ri.k = en.k;
+        ri.t0 = en.t0;
+        ri.nt = en.nt;
+        if (en.b == 0xffffffffu)
+            return ri; // an idle tile of this bin
+        const int b = (int)en.b;
         ri.m = (int)(r % (uint32_t)sd.L);
         const UttDev *up = bd.utt + b;
         ri.n = sd.Tv[b];
         ri.gvl = sd.gvlen[b];
         const StreamStatesDev st = up->st[si];
-        ri.live = st.gv_mean != nullptr && ri.n > 0 && ri.gvl > 0; // the same answer in every member
+        ri.live = st.gv_mean != nullptr && ri.n > 0 && ri.gvl > 0; // the same answer in every tile of the row
         ri.frame_off = up->frame_off;
         ri.rowoff = up->frame_off * (uint64_t)sd.L + (uint64_t)ri.m * (uint64_t)up->T;
         if (ri.live) {
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         nxt = 0.0;
         if (tile == 0 && tid == 0)
             nxt = (double)atomicAdd(&ctl->next_row, 1u);
-        if (!cur.live) {
+        if (!cur.active) { // (the same answer in every member: from the bin table)
             exchange(false, 0.0, 0.0, 0.0, nxt);
             if (dead)
                 return;
@@ -519,7 +529,9 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
             cur = row_info(row);
             continue;
         }
-        const uint64_t rowoff = cur.rowoff;
+        sum_t0 = cur.t0;
+        sum_t1 = cur.t0 + cur.nt;
+        const uint64_t rowoff = cur.live ? cur.rowoff : 0; // (a workgroup without a live row touches no memory)
         const double *A0 = sd.A[0] + rowoff, *A1 = sd.A[1] + rowoff, *A2 = sd.A[2] + rowoff, *Bv = sd.bvec + rowoff;
         double *P = sd.par + rowoff;
         const uint8_t *sw = sd.vsw + cur.frame_off;
@@ -529,8 +541,8 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         int lane_v = lane;
         asm volatile("" : "+v"(lane_v));
         const int n_i = (int)n;
-        const int own_lo = tile * kGgBlockOwn + wv * kGgOwn; // first frame this wave owns
-        const bool busy = own_lo < n_i;                      // else: an idle tile / wave of a short row
+        const int own_lo = cur.k * kGgBlockOwn + wv * kGgOwn; // first frame this wave owns
+        const bool busy = cur.live && own_lo < n_i;           // else: an idle tile / wave of a short row
         const int ws = own_lo - kGgHalo;                     // first frame of the wave window
         const int t0 = ws + kGgFPT * lane_v;                 // this lane's first frame
 
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         // par[0]), then conv_gv (mlpg.rs:195-203).  Phases 1..5: the ascent iterations
         // (GV_MAX_ITERATION, mlpg.rs:260-292): statistics and HMM objective of the current track, then
         // the step.  One loop body for all six, so that the exchange is expanded once.
-        double K = gg_uni(P[0]);
+        double K = cur.live ? gg_uni(P[0]) : 0.0;
         double step = 0.1, prev = 0.0; // STEPINIT
         uint32_t next_row = total_rows;
 #pragma unroll 1
@@ -815,9 +827,58 @@ int gv_gang_plan(int device, uint32_t maxT, uint32_t n_rows, int *tiles_per_gang
     return 1;
 }
 
+void gv_gang_bins(const uint32_t *T, const uint8_t *has_gv, const uint32_t *order, size_t n, int tiles_per_gang,
+                  std::vector<GvBinEntry> &out)
+{
+    out.clear();
+    std::vector<int> used; // tiles taken per bin
+    const int cap = tiles_per_gang;
+    auto new_bin = [&]() {
+        used.push_back(0);
+        out.resize(out.size() + (size_t)cap, GvBinEntry{0xffffffffu, 0, 0, 0, 0});
+        return used.size() - 1;
+    };
+    for (size_t oi = 0; oi < n; oi++) {
+        const uint32_t b = order ? order[oi] : (uint32_t)oi;
+        int nt = (int)((T[b] + (uint32_t)kGgBlockOwn - 1) / (uint32_t)kGgBlockOwn);
+        if (nt < 1)
+            nt = 1; // (an empty utterance: one idle tile, so that its rows are still "visited")
+        if (nt > cap)
+            nt = cap;
+        size_t bin = used.size();
+        for (size_t j = 0; j < used.size(); j++)
+            if (used[j] + nt <= cap) {
+                bin = j;
+                break;
+            }
+        if (bin == used.size())
+            bin = new_bin();
+        const int t0 = used[bin];
+        for (int k = 0; k < nt; k++) {
+            GvBinEntry &en = out[bin * (size_t)cap + (size_t)(t0 + k)];
+            en.b = b;
+            en.k = (uint8_t)k;
+            en.t0 = (uint8_t)t0;
+            en.nt = (uint8_t)nt;
+        }
+        used[bin] += nt;
+        if (has_gv[b] && T[b] > 0)
+            for (int j = 0; j < cap; j++)
+                out[bin * (size_t)cap + (size_t)j].flags |= 1u;
+    }
+    // (flags were set on the entries that existed when an utterance joined: once more over whole bins)
+    for (size_t bin = 0; bin < used.size(); bin++) {
+        uint8_t f = 0;
+        for (int j = 0; j < cap; j++)
+            f |= out[bin * (size_t)cap + (size_t)j].flags;
+        for (int j = 0; j < cap; j++)
+            out[bin * (size_t)cap + (size_t)j].flags = f;
+    }
+}
+
 hipError_t launch_gv_gang(const BatchDev &bd, const StreamDev &sd, int si, hipStream_t stream)
 {
-    if (!sd.gv_gang_ctl || sd.gv_gang_n <= 0 || bd.B == 0)
+    if (!sd.gv_gang_ctl || sd.gv_gang_n <= 0 || bd.B == 0 || !sd.gv_bins || sd.gv_nbins == 0)
         return hipErrorInvalidValue;
     GvGangCtl *ctl = (GvGangCtl *)sd.gv_gang_ctl;
     GvGang *gangs = (GvGang *)(ctl + 1);
