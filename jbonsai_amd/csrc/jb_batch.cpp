@@ -1162,7 +1162,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         if (opts && opts->chunk_frames)
             lt_waves_per_simd = it <= 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave() ? 1 : 2;
     }
-    // the checkpoint a failed chunk is first recomputed to (finish_verify): 32 frames into chunks of 64 and more, 24 into
+    // the checkpoint a failed chunk is first recomputed to (finish_verify): 48 frames into chunks of 96 and more, 24 into
     // chunks of 36 and more, 16 into chunks of 24 and more (a single 128 s utterance, 799 chunks of 32 frames: all six
     // failing hand-offs settle there and the redo is one round of 16 frames, 10.2 -> 9.2 ms per call; 8 frames into
     // 16-frame chunks settle three in four but the rest still take their rounds: same time, not done)
@@ -1170,6 +1170,11 @@ int Batch::build_work(const jb_batch_opts *opts)
                      : ch >= kVocCkptFramesShort + 12 ? kVocCkptFramesShort
                      : ch >= kVocCkptFramesTiny + 8 ? kVocCkptFramesTiny : 0;
     vd.ckpt2_frames = (vd.ckpt_frames == kVocCkptFrames && ch >= kVocCkpt2Frames + 48) ? kVocCkpt2Frames : 0;
+#ifdef JB_DBG_GATES
+    if (const char *c1 = getenv("JB_DBG_CKPT1")) // measurement aid: another first checkpoint for long chunks
+        if (vd.ckpt2_frames && atoi(c1) >= 16 && atoi(c1) + 12 <= (int)vd.ckpt2_frames)
+            vd.ckpt_frames = (uint32_t)atoi(c1);
+#endif
     work.clear();
     const int stride = vd.state_stride;
     for (int i = 0; i < B; i++) {
@@ -1502,6 +1507,8 @@ int Batch::finish_verify()
     if (!verify_pending)
         return JB_OK;
     verify_pending = false;
+    const auto tv0 = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv0).count(); };
     uint32_t nbad = 0;
     hipError_t e = hipMemcpy(&nbad, nbad_dev, sizeof nbad, hipMemcpyDeviceToHost);
     if (e != hipSuccess)
@@ -1530,19 +1537,26 @@ int Batch::finish_verify()
         if (round.empty())
             return JB_OK;
         hipError_t he;
+        const double t_a = since();
 
         if ((he = hipMemcpy(redo_dev, round.data(), sizeof(VocWork) * round.size(), hipMemcpyHostToDevice)) !=
             hipSuccess)
             return hip_fail(he, "hipMemcpy(redo)");
+        const double t_b = since();
         if ((he = launch_vocoder(bd, vd, redo_dev, (uint32_t)round.size(), stream_voc)) != hipSuccess)
             return hip_fail(he, "k_vocoder(redo)");
+        const double t_c = since();
         if ((he = hipStreamSynchronize(stream_voc)) != hipSuccess)
             return hip_fail(he, "redo sync");
+        if (getenv("JB_REDO_TRACE"))
+            fprintf(stderr, "  {copy %.3f launch %.3f wait %.3f} ", t_b - t_a, t_c - t_b, since() - t_c);
         return JB_OK;
     };
     std::vector<uint8_t> pending(bad);
     pending[0] = 0;
     const bool redo_trace = getenv("JB_REDO_TRACE") != nullptr; // debugging aid: one line per redo round on stderr
+    if (redo_trace)
+        fprintf(stderr, "redo: lists and scratch ready after %.3f ms\n", since());
     for (;;) {
         // This round: every failing chunk whose predecessor is final, AND -- speculatively -- a failing chunk
         // behind a failing chunk: it starts from the end state its predecessor left in the FIRST pass.  That state
@@ -1589,8 +1603,11 @@ int Batch::finish_verify()
             w.save_ckpt = w.save_ckpt2 = nullptr;
             round.push_back(w);
         }
+        const double tr0 = since();
         if ((rc = run_round(round)))
             return rc;
+        if (redo_trace)
+            fprintf(stderr, "  [stage A: built by %.3f, ran until %.3f ms] ", tr0, since());
         // does the recomputed state meet the checkpoint?
         std::vector<uint8_t> unsettled(n_items, 0);
         if (!part.empty()) {
@@ -1699,6 +1716,8 @@ int Batch::finish_verify()
         for (uint32_t k : ids)
             if (final_now[k])
                 pending[k] = 0;
+        if (redo_trace)
+            fprintf(stderr, "  (%.3f ms since the check was read) ", since());
         if (redo_trace)
             fprintf(stderr, "redo round: %zu items (%zu to a checkpoint), %zu continue past it, %u settled so far, %u to the end so far\n",
                     ids.size(), part.size(), rest.size(), n_redo_partial, n_redo_full);

@@ -232,14 +232,17 @@ struct VocWork {
 };
 // A failing chunk is first recomputed only up to VocDev::ckpt_frames frames past its start; if the
 // recomputed state meets the checkpoint the original chunk left there, the rest of the chunk stands.
-// 32 frames into chunks of 64 frames and more, 24 into chunks of 36 to 63, 16 into chunks of 24 to 35, none below
+// 48 frames into chunks of 96 frames and more, 24 into chunks of 36 to 95, 16 into chunks of 24 to 35, none below
 // (Batch::build_work).  A redo round lasts as long as the frames to the checkpoint (0.06 ms per frame, one wave per
-// chunk); a hand-off that failed behind 18 frames of warm-up settles there if 18 + 32 frames from zero state are
-// enough, and no position of the CPU study needed more than 43 (tests/tools/warmup_decay.py).  (48 until round 4.)
-// Chunks of 128 frames and more leave a SECOND checkpoint 80 frames in: the rare chunk that has not converged at the
-// first one (4 of 325 failing hand-offs in a batch of 1024 distinct utterances) is recomputed 48 frames further and
-// compared again, instead of to its end (121 frames = 7 ms, the whole round waiting for it).
-constexpr uint32_t kVocCkptFrames = 32, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16, kVocCkpt2Frames = 80;
+// chunk) and ALL of a round's chunks wait for the one that goes furthest.  A hand-off that failed behind 18 frames
+// of warm-up settles at the checkpoint if 18 + 48 frames from zero state are enough.  Tried in round 4: 32 frames
+// (-1 ms per round) -- but about 1 % of the failing hand-offs have not converged there, and a batch of 512 or 1024
+// distinct utterances (BASELINE configs 3 to 5: ~300 failing hand-offs) then nearly always has one and pays the
+// second stage: 2.0 + 3.0 ms instead of 2.9 (tools/ckpt_sweep.sh: 1024 x 6,386 frames 86.6 / 86.3 / 83.9 / 84.6 ms
+// per step with the first checkpoint at 32 / 40 / 48 / 56).
+// Chunks of 144 frames and more leave a SECOND checkpoint 96 frames in: the rare chunk that has not converged at
+// the first one is recomputed 48 frames further and compared again, instead of to its end (105 frames = 6.4 ms).
+constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16, kVocCkpt2Frames = 96;
 
 // Timing experiments only (library built with -DJB_DBG_GATES, never the product): JB_DBG_SKIP is a bit mask of
 // launches to leave out once a launcher has been called JB_DBG_SKIP_AFTER times (default 2: bench.py's warm-up

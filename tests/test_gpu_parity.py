@@ -199,7 +199,7 @@ def test_chunk_handoff_check_triggers_redo(oracle_voice, have_gpu):
 
 
 def test_partial_redo_at_checkpoint(ctx_long, have_gpu):
-    """Chunks of >= 64 frames leave a checkpoint state 32 frames in.  A failing chunk is first
+    """Chunks of >= 96 frames leave a checkpoint state 48 frames in.  A failing chunk is first
     recomputed only up to it; where the recomputed state meets the checkpoint the rest of the
     chunk stands (certified to the same tolerance as an ordinary hand-off), elsewhere the
     recomputation runs on to the end.  With a 6-frame warm-up most hand-offs fail; both outcomes
@@ -218,8 +218,8 @@ def test_partial_redo_at_checkpoint(ctx_long, have_gpu):
         print(kern, "hand-offs failing", info["n_redo"], "settled at checkpoint", n_part, "to the end", n_full,
               "rel RMS vs serial", e)
         assert e <= 1e-9
-    # the second checkpoint (80 frames into chunks of 128 and more): with a 2-frame warm-up and a tolerance of 1e-12
-    # some chunks have not converged 32 frames in and go on to the second checkpoint (JB_REDO_TRACE=1 shows them);
+    # the second checkpoint (96 frames into chunks of 144 and more): with a 2-frame warm-up and a tolerance of 1e-12
+    # some chunks have not converged 48 frames in and go on to the second checkpoint (JB_REDO_TRACE=1 shows them);
     # with a tolerance below the rounding differences of the two kernels nothing ever settles and every chunk is
     # recomputed to its end through both checkpoints.  Either way the result is the serial recursion's.
     for tol, all_full in ((1e-12, False), (1e-17, True)):
@@ -233,7 +233,7 @@ def test_partial_redo_at_checkpoint(ctx_long, have_gpu):
               "to the end", n_full, "rel RMS vs serial", e)
         assert info["n_redo"] >= 10 and e <= 1e-11
         assert (n_full >= 10 and n_part == 0) if all_full else n_part >= 10
-    # the shorter checkpoints: 24 frames into chunks of 36-63 frames, 16 into chunks of 24-35 (a few long utterances)
+    # the shorter checkpoints: 24 frames into chunks of 36-95 frames, 16 into chunks of 24-35 (a few long utterances)
     for chunk in (40, 32):
         with J.Batch(vi, [u], chunk_frames=chunk, warmup_frames=10, verify_tol=1e-9, kernel="wave") as b:
             b.run()
