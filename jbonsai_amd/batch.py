@@ -153,6 +153,12 @@ class IndexUtterance:
         self.durations = np.ascontiguousarray(self.durations, dtype=np.uint32)
 
     def c_struct(self):
+        # marshalled once per object (the struct only points into arrays this object owns; an utterance is not
+        # edited after its first use): a job that creates its batches again every pass -- bench.py's config-3
+        # job -- spent 12 of the 27 ms of a 512-utterance creation building these
+        c = self.__dict__.get("_c")
+        if c is not None:
+            return c
         u = F.IndexUtt()
         u.num_states = len(self.durations)
         u.durations = self.durations.ctypes.data_as(C.POINTER(C.c_uint32))
@@ -165,6 +171,7 @@ class IndexUtterance:
             d.gv_mean, d.gv_var = _dp(s.gv_mean), _dp(s.gv_var)
             d.gv_switch = s.gv_switch.ctypes.data_as(C.POINTER(C.c_uint8)) if s.gv_switch is not None else None
             d.gv_weight, d.msd_threshold = s.gv_weight, s.msd_threshold
+        self.__dict__["_c"] = u
         return u
 
 

@@ -441,7 +441,15 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
     }
     const uint32_t ns = voice->nstream;
     out.assign(n * ns, StreamStatesDev{});
+    const bool gtrace = getenv("JB_CREATE_TRACE") != nullptr;
+    const auto tg0 = std::chrono::steady_clock::now();
+    auto gmark = [&](const char *what) {
+        if (gtrace)
+            fprintf(stderr, "    gather: %-24s at %.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tg0).count());
+    };
     std::vector<GatherJob> jobs;
+    std::vector<size_t> share(n * ns, (size_t)-1); // job whose arrays (utterance, stream) uses
     std::map<std::string, size_t> seen;
     uint64_t max_elems = 0;
     int rc;
@@ -474,11 +482,13 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
                     set_error("pdf row indices missing or table row length mismatch");
                     return JB_ERR_INVALID;
                 }
+                uint32_t rmax = 0; // (a plain maximum: the loop vectorises)
                 for (uint32_t s = 0; s < u.num_states; s++)
-                    if (is.row[v][s] >= ps.n_rows[t]) {
-                        set_error("pdf row index out of range");
-                        return JB_ERR_INVALID;
-                    }
+                    rmax = std::max(rmax, is.row[v][s]);
+                if (u.num_states && rmax >= ps.n_rows[t]) {
+                    set_error("pdf row index out of range");
+                    return JB_ERR_INVALID;
+                }
                 j.tab[v] = ps.tab[t];
                 j.w[v] = is.weight[v];
                 key.append((const char *)&is.row[v], sizeof(void *));
@@ -486,35 +496,61 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
             }
             auto it = seen.find(key);
             if (it != seen.end()) {
-                const GatherJob &o = jobs[it->second];
-                out[i * ns + si].mean = o.mean;
-                out[i * ns + si].var = o.var;
-                out[i * ns + si].msd = o.msd;
+                share[i * ns + si] = it->second;
                 continue;
             }
+            share[i * ns + si] = jobs.size();
             for (uint32_t v = 0; v < ps.nv; v++) {
                 const void *dp;
                 if ((rc = upload(is.row[v], sizeof(uint32_t) * u.num_states, &dp)))
                     return rc;
                 j.row[v] = (const uint32_t *)dp;
             }
-            if ((rc = dalloc(&j.mean, (size_t)u.num_states * WL, false)) ||
-                (rc = dalloc(&j.var, (size_t)u.num_states * WL, false)))
-                return rc;
-            if (sdsc.is_msd && (rc = dalloc(&j.msd, u.num_states, false)))
-                return rc;
+            // (the arrays of all jobs come out of ONE allocation, carved below: three pool allocations per
+            // (utterance, stream) were most of the 9 ms this function took for 512 utterances)
             max_elems = std::max<uint64_t>(max_elems, (uint64_t)u.num_states * WL);
             seen[key] = jobs.size();
-            out[i * ns + si].mean = j.mean;
-            out[i * ns + si].var = j.var;
-            out[i * ns + si].msd = j.msd;
             jobs.push_back(j);
         }
     }
+    gmark("jobs listed, rows staged");
     if (jobs.empty())
         return JB_OK;
+    {
+        auto up32 = [](size_t x) { return (x + 31) / 32 * 32; }; // 256-byte pieces
+        size_t total = 0;
+        for (const GatherJob &j : jobs)
+            total += 2 * up32((size_t)j.S * j.WL) + (j.has_msd ? up32(j.S) : 0);
+        double *slab;
+        if ((rc = dalloc(&slab, total, false)))
+            return rc;
+        size_t off = 0;
+        for (size_t q = 0; q < jobs.size(); q++) {
+            GatherJob &j = jobs[q];
+            j.mean = slab + off;
+            off += up32((size_t)j.S * j.WL);
+            j.var = slab + off;
+            off += up32((size_t)j.S * j.WL);
+            if (j.has_msd) {
+                j.msd = slab + off;
+                off += up32(j.S);
+            }
+        }
+        // every (utterance, stream) gets the arrays of the job it shares
+        for (size_t i = 0; i < n; i++)
+            for (uint32_t si = 0; si < ns; si++) {
+                const size_t q = share[i * ns + si];
+                if (q == (size_t)-1)
+                    continue;
+                out[i * ns + si].mean = jobs[q].mean;
+                out[i * ns + si].var = jobs[q].var;
+                out[i * ns + si].msd = jobs[q].msd;
+            }
+    }
+    gmark("outputs carved");
     if ((rc = flush_uploads())) // the index rows the gather reads
         return rc;
+    gmark("rows uploaded");
     GatherJob *jd;
     if ((rc = dalloc(&jd, jobs.size(), false)))
         return rc;
@@ -527,8 +563,10 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
         if ((e = launch_gather(jd + j0, nj, max_elems, stream)) != hipSuccess)
             return hip_fail(e, "k_gather_blend");
     }
+    gmark("kernels launched");
     if ((e = hipStreamSynchronize(stream)) != hipSuccess)
         return hip_fail(e, "k_gather_blend");
+    gmark("done");
     return JB_OK;
 }
 
@@ -608,6 +646,14 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     int rc = check_voice(voice, trk == nullptr, trk && trk->vocoder_level);
     if (rc)
         return rc;
+    // JB_CREATE_TRACE=1: where the creation of a batch spends its time (stderr)
+    const bool ctrace = getenv("JB_CREATE_TRACE") != nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
+    auto cmark = [&](const char *what) {
+        if (ctrace)
+            fprintf(stderr, "  create: %-28s at %.3f ms\n", what,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+    };
     // Parameter tracks as the source (SpeechGenerator::new, src/speech.rs:25-50).  The kernels behind the
     // frame prologue want the LF0 stream's voiced flags and voiced runs, which the state walk of that
     // stream produces: give it the track's runs of voiced / unvoiced frames (a frame is voiced where
@@ -737,8 +783,10 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     const int B = (int)n;
     b->B = B;
     std::vector<StreamStatesDev> gathered; // indexed source: per-state Gaussians produced on the device
+    cmark("streams and events made");
     if (idx && (rc = b->gather_states(voice, *idx, n, gathered)))
         return rc;
+    cmark("states gathered on the device");
     b->T.resize(n);
     b->frame_off.resize(n + 1);
     std::vector<UttDev> hu(n);
@@ -831,8 +879,10 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         }
     }
 
+    cmark("descriptors, uploads staged");
     if ((rc = b->flush_uploads()))
         return rc;
+    cmark("uploads flushed");
     UttDev *dutt;
     if ((rc = b->dalloc(&dutt, n, false)))
         return rc;
@@ -956,6 +1006,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
             }
     }
 
+    cmark("stream workspaces allocated");
     // ---- vocoder ----
     VocDev &vd = b->vd;
     memset(&vd, 0, sizeof vd);
@@ -1064,6 +1115,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.noise_len = b->noise->len;
     if (vd.beta > 0.0 && (e = launch_pf_table(vd, b->stream)) != hipSuccess)
         return hip_fail(e, "k_pf_table");
+    cmark("vocoder buffers allocated");
     if ((rc = b->build_work(opts)))
         return rc;
     if ((rc = b->flush_uploads()))
@@ -1072,11 +1124,13 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         c.host.reset(); // staging copies are not needed any more
     // uploads and memsets ran on the legacy stream, the gather and the constant tables on the batch's
     // own: wait for those two, not for the device (another batch may be running a step)
+    cmark("work list built");
     e = hipStreamSynchronize(nullptr);
     if (e == hipSuccess)
         e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess)
         return hip_fail(e, "upload");
+    cmark("synchronised");
     *out = b.release();
     return JB_OK;
 }
