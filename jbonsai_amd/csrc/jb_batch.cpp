@@ -359,6 +359,47 @@ template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
     return JB_OK;
 }
 
+// pinned staging chunks of the upload arenas (all of one size), reused between batches
+static std::mutex g_pin_mu;
+static std::vector<uint8_t *> g_pin_free;
+static constexpr size_t kPinChunk = 8u << 20, kPinKeep = 16;
+bool Batch::PinnedChunk::acquire(size_t bytes)
+{
+    reset();
+    if (bytes != kPinChunk)
+        return false;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (!g_pin_free.empty()) {
+            p = g_pin_free.back();
+            g_pin_free.pop_back();
+            return true;
+        }
+    }
+    void *v = nullptr;
+    if (hipHostMalloc(&v, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    p = (uint8_t *)v;
+    return true;
+}
+void Batch::PinnedChunk::reset()
+{
+    if (!p)
+        return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        if (g_pin_free.size() < kPinKeep) {
+            g_pin_free.push_back(p);
+            p = nullptr;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+    p = nullptr;
+}
+
 // upload with de-duplication on (host pointer, byte size)
 int Batch::upload(const void *host, size_t bytes, const void **dev)
 {
@@ -389,7 +430,10 @@ int Batch::upload(const void *host, size_t bytes, const void **dev)
             UploadChunk c;
             if ((rc = dalloc(&c.dev, kChunk, false)))
                 return rc;
-            c.host.reset(new uint8_t[kChunk]);
+            if (!c.host.acquire(kChunk)) {
+                set_error("hipHostMalloc(upload arena)");
+                return JB_ERR_DEVICE;
+            }
             up_chunks.push_back(std::move(c));
         }
         UploadChunk &c = up_chunks.back();
