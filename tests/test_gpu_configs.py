@@ -101,6 +101,29 @@ def test_config3_mixed_lengths(ctx):
         assert rel_rms(g, ref) <= 1e-9, T
 
 
+def test_gv_rows_of_short_utterances_share_a_gang_pass(ctx):
+    """Resident GV (jb_gv_gang.hip): the rows of several short utterances are packed into one pass of a gang (bins by
+    first fit in launch order).  A ragged batch whose longest utterance needs three tiles: every MCP track must be
+    the one the same utterance gets in a batch of its own -- bit for bit, the sums have a fixed shape per row --
+    and match the oracle's (mlpg.rs:145-292) to the MCP gate."""
+    eng, tab, vi = ctx
+    lens = [9000, 700, 4100, 3000, 2500, 1, 3905, 800, 5200, 60]
+    utts = [synth.synth_utterance(tab, T, 300 + i) for i, T in enumerate(lens)]
+    with J.Batch(vi, utts, keep_tracks=True) as b:
+        b.run()
+        b.sync()
+        together = [b.track(i, 0) for i in range(len(utts))]
+    for i in (0, 2, 3, 6, 8, 9):
+        with J.Batch(vi, [utts[i]], keep_tracks=True) as b:
+            b.run()
+            b.sync()
+            alone = b.track(0, 0)
+        assert np.array_equal(together[i], alone), lens[i]
+        _, tr = oracle_pcm(vi, utts[i])
+        scale = np.abs(tr[0]).max(axis=0)
+        assert (np.abs(together[i] - tr[0]).max(axis=0) <= 1e-12 * scale + 1e-13).all(), lens[i]
+
+
 def test_config5_two_voice_interpolation_states(ctx):
     """Config 5 shape: two-voice blend (alpha = 0.5).  The blend is pre-boundary in the
     reference (voice_set.rs:80-95), done by the host front half; the blended states go
