@@ -465,7 +465,8 @@ def roofline_block(samples_per_launch, voc_ms, info, batch, frames):
     traffic = tr.get("hbm_bytes_per_launch") if tr is not None else None
     if tr is None and why:
         stale.append(why)
-    lt = bool(info["chunk_frames"]) and info["n_items"] >= 16384
+    # (the library takes the lane-triple kernel from 100 k frames per batch: jb_batch.cpp, Batch::build_work)
+    lt = bool(info["chunk_frames"]) and samples_per_launch >= 100000 * 240 and info["n_items"] > 1024
     return {
         "bound": "valu_f64", "kernel": "k_vocoder_lt" if lt else "k_vocoder",
         "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,

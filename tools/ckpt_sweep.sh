@@ -1,4 +1,7 @@
 #!/bin/bash
+# First checkpoint of the redo round at 32 / 40 / 48 / 56 frames (JB_DBG_CKPT1 of the -DJB_DBG_GATES library:
+# tools/build_variant.sh gates -DJB_DBG_GATES) on a ragged batch and on 1024 distinct utterances, with the trace of
+# the rounds (JB_REDO_TRACE=1): which stages a round went through and what the step took.
 cd "$(dirname "$0")/.."
 cp jbonsai_amd/libjbonsai_amd.so /tmp/_keep.so
 trap 'cp /tmp/_keep.so jbonsai_amd/libjbonsai_amd.so' EXIT

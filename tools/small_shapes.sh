@@ -1,4 +1,6 @@
 #!/bin/bash
+# Mid-size batches of distinct utterances by vocoder kernel and chunk length (GPU box): the library's own choice,
+# then the lane-triple kernel with its own and with shorter chunks (bench.py --kernel / --chunk-frames).
 cd "$(dirname "$0")/.."
 run() { python bench.py "$@" --distinct 64 --steps 6 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | python -c "
 import sys,json
