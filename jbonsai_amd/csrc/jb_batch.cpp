@@ -1727,13 +1727,6 @@ int Batch::finish_verify()
                 return hip_fail(e, "hipMemcpy(bad2)");
             for (size_t q = 0; q < part.size(); q++)
                 unsettled[ids[part[q]]] = bad2[q];
-            // the exact end state of a chunk recomputed to its end goes where the first pass left its own
-            for (size_t q = 0; q < part.size(); q++) {
-                const uint32_t k = ids[part[q]];
-                if (spec_end[k] && (e = hipMemcpyAsync(work[k].save_end, tmp_state + (size_t)k * stride, sizeof(double) * stride,
-                                                       hipMemcpyDeviceToDevice, stream_voc)) != hipSuccess)
-                    return hip_fail(e, "hipMemcpy(end state)");
-            }
         }
         // second checkpoint: a chunk that had not converged at the first one goes on to it and is compared again
         std::vector<uint8_t> at2(n_items, 0);
@@ -1785,7 +1778,6 @@ int Batch::finish_verify()
         std::vector<uint8_t> final_now(n_items, 0);
         for (uint32_t k : ids) {
             // valid: started from a final state -- the predecessor was final before the round, or it was in the
-            // round, valid itself, and settled at its checkpoint (its first-pass end state stands)
             // round, valid itself, and its first-pass end state stands (settled at its checkpoint / met by the end
             // state of its recomputation)
             const bool pred_in = in_round[k - 1] && pending[k - 1];
@@ -1809,6 +1801,14 @@ int Batch::finish_verify()
                 rest.push_back(w);
             }
         }
+        // the exact end state of a VALID chunk recomputed to its end goes where the first pass left its own (an
+        // invalid one started from a state that is being replaced: its dump keeps the first pass's state, the better
+        // start for its successor's next attempt)
+        for (uint32_t k : ids)
+            if (final_now[k] && spec_end[k] &&
+                (e = hipMemcpyAsync(work[k].save_end, tmp_state + (size_t)k * stride, sizeof(double) * stride,
+                                    hipMemcpyDeviceToDevice, stream_voc)) != hipSuccess)
+                return hip_fail(e, "hipMemcpy(end state)");
         if ((rc = run_round(rest)))
             return rc;
         for (uint32_t k : ids)
