@@ -497,6 +497,12 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
     std::map<std::string, size_t> seen;
     uint64_t max_elems = 0;
     int rc;
+    double acc_check = 0, acc_key = 0, acc_up = 0;
+    auto tick = [&]() { return gtrace ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); };
+    auto tock = [&](std::chrono::steady_clock::time_point t0, double &acc) {
+        if (gtrace)
+            acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    };
     for (size_t i = 0; i < n; i++) {
         const jb_index_utt &u = idx.utts[i];
         for (uint32_t si = 0; si < ns; si++) {
@@ -520,6 +526,7 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
             std::string key((const char *)&u.num_states, sizeof u.num_states);
             key.append((const char *)&si, sizeof si);
             key.append((const char *)&j.lf0_offset, sizeof j.lf0_offset);
+            const auto tk0 = tick();
             for (uint32_t v = 0; v < ps.nv; v++) {
                 const size_t t = (size_t)v * ps.ns + si;
                 if (!is.row[v] || ps.row_len[t] != want_len) {
@@ -538,18 +545,23 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
                 key.append((const char *)&is.row[v], sizeof(void *));
                 key.append((const char *)&is.weight[v], sizeof(double));
             }
+            tock(tk0, acc_check);
+            const auto tk1 = tick();
             auto it = seen.find(key);
             if (it != seen.end()) {
                 share[i * ns + si] = it->second;
                 continue;
             }
             share[i * ns + si] = jobs.size();
+            tock(tk1, acc_key);
+            const auto tk2 = tick();
             for (uint32_t v = 0; v < ps.nv; v++) {
                 const void *dp;
                 if ((rc = upload(is.row[v], sizeof(uint32_t) * u.num_states, &dp)))
                     return rc;
                 j.row[v] = (const uint32_t *)dp;
             }
+            tock(tk2, acc_up);
             // (the arrays of all jobs come out of ONE allocation, carved below: three pool allocations per
             // (utterance, stream) were most of the 9 ms this function took for 512 utterances)
             max_elems = std::max<uint64_t>(max_elems, (uint64_t)u.num_states * WL);
@@ -558,6 +570,8 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
         }
     }
     gmark("jobs listed, rows staged");
+    if (gtrace)
+        fprintf(stderr, "    gather: of that checks + key %.3f, map %.3f, staging %.3f ms\n", acc_check, acc_key, acc_up);
     if (jobs.empty())
         return JB_OK;
     {
