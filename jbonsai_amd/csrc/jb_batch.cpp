@@ -1221,14 +1221,16 @@ int Batch::build_work(const jb_batch_opts *opts)
     } else if (ch == 0 && lp_mode) {
         // two waves on every SIMD: 8 XCDs x 32 CUs x 4 SIMDs x 2 -- or ONE, while the batch is too small to give
         // every SIMD two waves of chunks that are long against their warm-up.  The launch takes as long as one
-        // chunk-with-warm-up at the rate a wave gets: a lone wave issues an instruction every 6.7 cycles, one of a
-        // pair every 8.9 (tools/lt_clocks.sh); compare the two at the chunk length each would get (floor below).
+        // chunk-with-warm-up at the rate a wave gets: a lone wave issues an instruction every 6-6.7 cycles, one of a
+        // pair every 8.9-9.7 (tools/lt_clocks.sh); compare the two at the chunk length each would get (floor below).
         constexpr uint64_t cfloor = 16;
         const uint64_t slots1 = 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave();
-        auto launch_cost = [&](uint64_t slots, double cycles) {
-            return (double)(std::max<uint64_t>((sumT + slots - 1) / slots, cfloor) + warmup_frames) * cycles;
+        auto launch_cost = [&](uint64_t slots, double us_per_sample) {
+            return (double)(std::max<uint64_t>((sumT + slots - 1) / slots, cfloor) + warmup_frames) * us_per_sample;
         };
-        lt_waves_per_simd = launch_cost(slots1, 6.7) < launch_cost(2 * slots1, 8.9) ? 1 : 2;
+        // (per sample and wave, measured: 0.90 us alone on a SIMD, 1.39-1.46 us beside a second wave -- 64 x 11,000
+        // frames 18.1 ms per step with one wave per SIMD and 33-frame chunks, 19.8 with two and 17-frame chunks)
+        lt_waves_per_simd = launch_cost(slots1, 0.90) < launch_cost(2 * slots1, 1.42) ? 1 : 2;
         const uint64_t target = slots1 * (uint64_t)lt_waves_per_simd;
         uint64_t c = (sumT + target - 1) / target;
         // while the batch cannot fill the chip the time of the launch is that of ONE chunk (chunk +
