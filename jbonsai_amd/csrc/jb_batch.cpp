@@ -377,7 +377,7 @@ bool Batch::PinnedChunk::acquire(size_t bytes)
         }
     }
     void *v = nullptr;
-    if (hipHostMalloc(&v, bytes, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(&v, bytes, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
