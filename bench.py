@@ -82,6 +82,7 @@ def parse_args():
     ap.add_argument("--kernel", choices=("auto", "wave", "triple"), default="auto",
                     help="vocoder kernel of the timed batch (auto = the library's choice by batch size; measurement aid)")
     ap.add_argument("--chunk-frames", type=int, default=0, help="chunk length of the timed batch (0 = the library's choice)")
+    ap.add_argument("--warmup-frames", type=int, default=0, help="warm-up of a chunk in frames (0 = the library's choice)")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="batches in flight per GPU (2: one batch's parameter generation overlaps the "
                          "other's vocoder on separate HIP streams; 1: strictly one step at a time)")
@@ -941,8 +942,8 @@ def run_rank(args):
         batch_utts = [synth.synth_utterance(tab, T, 2000 + i) for i, T in enumerate(lens)]
     else:
         batch_utts = [utts[i % nd] for i in range(args.batch)]
-    batches = [J.Batch(vi, batch_utts, device=R.local_rank, kernel=args.kernel, chunk_frames=args.chunk_frames)
-               for _ in range(depth)]
+    batches = [J.Batch(vi, batch_utts, device=R.local_rank, kernel=args.kernel, chunk_frames=args.chunk_frames,
+                       warmup_frames=args.warmup_frames) for _ in range(depth)]
     batch = batches[0]
     samples_per_step = batch.total_samples
 

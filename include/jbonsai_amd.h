@@ -98,7 +98,7 @@ typedef struct jb_batch_opts {
     int32_t device;         /* HIP device ordinal; -1 = current */
     uint32_t flags;         /* JB_BATCH_* */
     uint32_t chunk_frames;  /* vocoder time-chunk length in frames; 0 = auto */
-    uint32_t warmup_frames; /* frames each chunk starts early from zero state; 0 = default (18) */
+    uint32_t warmup_frames; /* frames each chunk starts early from zero state; 0 = default (18; 14 for batches with 1000 and more distinct hand-off positions) */
     double verify_tol;      /* chunk hand-off check: max|state diff| <= tol*max|state|; 0 = default (1e-9) */
     uint32_t reserved0;     /* must be 0 (rounds 1-3: mlpg_cus_per_xcd, a CU partition that lost at every split; removed) */
     uint32_t reserved;

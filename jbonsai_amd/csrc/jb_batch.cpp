@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <tuple>
 #include <numeric>
 #include <thread>
@@ -925,6 +926,14 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->frame_off[n] = sumT;
     b->sumT = sumT;
     b->maxT = maxT;
+    // distinct utterances (copies share their uploaded / gathered arrays): what the vocoder's warm-up length goes by
+    {
+        std::set<std::tuple<const void *, uint32_t, const void *, const void *>> seen_utts;
+        b->first_of_kind.assign(n, 0);
+        for (size_t i = 0; i < n; i++)
+            b->first_of_kind[i] = seen_utts.emplace((const void *)hu[i].dur, hu[i].S, (const void *)hu[i].st[0].mean,
+                                                    (const void *)(voice->nstream > 1 ? hu[i].st[1].mean : nullptr)).second;
+    }
     // one inverse-variance table per distinct variance array (256 copies of an utterance: one table of 2.5 MB that
     // stays in L2 instead of 256 of them, 640 MB, behind the build's gathers)
     for (uint32_t si = 0; si < voice->nstream; si++) {
@@ -1204,7 +1213,18 @@ int Batch::build_work(const jb_batch_opts *opts)
     // 17: 93.0 / 92.6 (at 17 a hand-off of config 2's own utterance fails in all 256 copies; with distinct
     // utterances a few hundred fail at every length and settle at their checkpoint).  24 -> 20 earlier in the
     // round: vocoder 67.8 -> 66.3 ms, 136 -> 220 failing hand-offs with distinct utterances.
-    warmup_frames = (opts && opts->warmup_frames) ? opts->warmup_frames : 18;
+    // Round 4, the other side of that trade: wherever a redo round is certain anyway -- any batch with more than a
+    // few hundred DISTINCT hand-off positions has failing ones at every length up to ~40 frames -- a shorter warm-up
+    // is cheaper as long as the failing chunks still get a SIMD each in the redo launch (<= 1024): same box, ms per
+    // step at 18 / 16 / 14 / 12 frames: 512 mixed lengths 84.5 / 83.8 / 83.2 / 84.7, 1024 x 6,386 distinct 83.5 /
+    // 82.6 / 82.3 / 83.5, 64 distinct x 4 copies 82.4 / 81.3 / 80.5 / 82.2, 64 x 2,000 10.9 / 9.6 / 9.2 (at 14:
+    // 1.7 % of the hand-offs fail, 720-810 chunks; at 12: 1,400-1,470, two to a SIMD).  Copies of ONE utterance
+    // keep 18: their 167 positions fail for all copies or for none, config 2's own have none at 18, and the
+    // expectation over utterances differs by 0.5 ms either way.  Decided below, once the
+    // chunk length is known: 14 frames from 1000 distinct hand-off positions (the chance that none of them fails at
+    // 18 frames is then under 0.1 %), else 18 -- small requests keep the geometry they had.
+    const bool warmup_given = opts && opts->warmup_frames;
+    warmup_frames = warmup_given ? opts->warmup_frames : 18;
     verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
     uint32_t ch = opts ? opts->chunk_frames : 0;
     // lane-triple throughput kernel: worth it once the batch holds enough frames to give every SIMD two
@@ -1268,6 +1288,14 @@ int Batch::build_work(const jb_batch_opts *opts)
         ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
+    if (!warmup_given && ch != 0) {
+        uint64_t positions = 0;
+        for (int i = 0; i < B; i++)
+            if ((size_t)i >= first_of_kind.size() || first_of_kind[(size_t)i])
+                positions += (T[(size_t)i] + ch - 1) / ch;
+        if (positions >= 1000)
+            warmup_frames = 14;
+    }
     if (lp_mode && ch != 0) {
         // (a chunk length given by the caller: one wave per SIMD if the items fit)
         uint64_t it = 0;

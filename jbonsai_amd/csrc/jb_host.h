@@ -88,6 +88,7 @@ struct Batch {
     uint8_t *bad_dev = nullptr;
     uint32_t *nbad_dev = nullptr;
     bool verify_pending = false;
+    std::vector<uint8_t> first_of_kind; // [B] 1: no earlier utterance of the batch was made from the same arrays
     bool lp_mode = false;            // lane-triple throughput kernel
     int lt_waves_per_simd = 2;       // its waves per SIMD: 2 (eight-wave workgroups) or 1 (build_work)
     uint32_t *order_dev = nullptr;   // its launch permutation
