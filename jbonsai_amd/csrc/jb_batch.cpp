@@ -849,7 +849,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     b->T.resize(n);
     b->frame_off.resize(n + 1);
     std::vector<UttDev> hu(n);
-    uint64_t sumT = 0, sumS = 0;
+    uint64_t sumT = 0, sumS = 0, sum_mt = 0; // sum_mt: frames of the [dim][frame] workspace, rows padded to 16
     uint32_t maxT = 0, maxS = 0;
     for (size_t i = 0; i < n; i++) {
         const jb_state_utt &u = utts[i];
@@ -868,6 +868,9 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         hu[i].T = (uint32_t)T;
         hu[i].frame_off = sumT;
         hu[i].state_off = sumS;
+        hu[i].mt_rs = (uint32_t)((T + 15) / 16 * 16);
+        hu[i].mt_off = sum_mt;
+        sum_mt += hu[i].mt_rs;
         sumT += T;
         sumS += u.num_states;
         maxT = std::max(maxT, (uint32_t)T);
@@ -1000,7 +1003,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         // MCP, non-MSD, [dim][frame]: its transpose is fused with mc2b (enqueue_paramgen)
         // (Stage::NonZero reads the [frame][dim] track itself: k_stage_coef)
         sd.defer_out = (si == 0 && sd.mt && !sd.is_msd && voice->stage == 0 && !trk) ? 1 : 0;
-        const size_t nf = (size_t)sumT, nfl = nf * (size_t)sd.L, nst = (size_t)sumS;
+        const size_t nf = (size_t)sumT, nfl = std::max((size_t)sumT, (size_t)sum_mt) * (size_t)sd.L, nst = (size_t)sumS;
         if ((rc = b->dalloc(&sd.s_start, nst, false)) || (rc = b->dalloc(&sd.s_vpre, nst, false)) ||
             (rc = b->dalloc(&sd.s_rstart, nst, false)) || (rc = b->dalloc(&sd.s_rend, nst, false)) ||
             (rc = b->dalloc(&sd.s_voiced, nst, false)) || (rc = b->dalloc(&sd.run_list, nst, false)) ||

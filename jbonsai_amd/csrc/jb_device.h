@@ -44,7 +44,14 @@ struct UttDev {
     // that share one (copies of an utterance: uploads are de-duplicated) share the table of the first of them
     uint64_t ivar_state_off[kMaxStream]; // first row of this utterance's table
     uint8_t ivar_owner[kMaxStream];      // 1: this utterance computes it (k_mlpg_ivar)
+    // [dim][frame] workspace (StreamDev::mt): row m of this utterance starts at element mt_off * L + m * mt_rs of
+    // A / bvec / F / g / par.  mt_rs = T rounded up to 16 frames and mt_off a multiple of 16: every row starts on a
+    // 128-byte line, so that the 16-frame pieces the build, the band solve's movers and the GV kernel move are whole
+    // lines (with rows at frame_off * L + m * T a piece straddled two: 12-15 % more bytes written than stored)
+    uint64_t mt_off;
+    uint32_t mt_rs;
 };
+__device__ __forceinline__ uint64_t mt_row0(const UttDev *up, int L) { return up->mt_off * (uint64_t)L; }
 
 struct StreamDev {
     int L, W, is_msd, use_gv;

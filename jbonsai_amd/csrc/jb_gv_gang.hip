@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kGgNT, JB_GG_WPS) void k_mlpg_gv_gang(BatchDev bd, 
         const StreamStatesDev st = up->st[si];
         ri.live = st.gv_mean != nullptr && ri.n > 0 && ri.gvl > 0; // the same answer in every tile of the row
         ri.frame_off = up->frame_off;
-        ri.rowoff = up->frame_off * (uint64_t)sd.L + (uint64_t)ri.m * (uint64_t)up->T;
+        ri.rowoff = mt_row0(up, sd.L) + (uint64_t)ri.m * (uint64_t)up->mt_rs;
         if (ri.live) {
             ri.gv_mean = st.gv_mean[ri.m] * st.gv_weight; // mlpg.rs:135-137
             ri.gv_vari = st.gv_var[ri.m];

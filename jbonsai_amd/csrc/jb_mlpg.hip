@@ -530,7 +530,7 @@ __global__ void k_mlpg_build_mt2(BatchDev bd, StreamDev sd, int si)
             run(std::false_type{});
     }
     __syncthreads();
-    const uint64_t row0 = base * (uint64_t)L, Tu = up->T;
+    const uint64_t row0 = mt_row0(up, L), Tu = up->mt_rs;
     for (int e = threadIdx.x; e < kBuildTF * L; e += blockDim.x) {
         const int m = e / kBuildTF, kl = e % kBuildTF;
         const uint32_t k = k0 + (uint32_t)kl;
@@ -836,12 +836,11 @@ __global__ __launch_bounds__(64) void k_mlpg_solve3(BatchDev bd, StreamDev sd, i
     const StreamStatesDev st = up->st[si];
     struct { uint32_t S, T; uint64_t frame_off, state_off; const uint32_t *dur; } u = {
         up->S, up->T, up->frame_off, up->state_off, up->dur};
-    const uint32_t T = u.T;
     const uint32_t n = sd.Tv[b];
     const uint64_t base = u.frame_off;
     // element k of this lane's dim: [frame][dim] rows (stride L) or its own [dim][frame] row
     // (MT is a template parameter so that the stride-1 form can use wide per-lane loads)
-    const uint64_t o0 = base * (uint64_t)L + (MT ? (uint64_t)m * (uint64_t)T : (uint64_t)m);
+    const uint64_t o0 = MT ? mt_row0(up, L) + (uint64_t)m * (uint64_t)up->mt_rs : base * (uint64_t)L + (uint64_t)m;
     const uint64_t Ls = MT ? 1ull : (uint64_t)L;
     const bool fuse_out = NONMSD && !MT; // `out` is [frame][dim]: only then is par's slot also out's
 #define IX(k) (o0 + (uint64_t)(k) * Ls)
@@ -1336,8 +1335,8 @@ __global__ __launch_bounds__(kFlNT, 1) void k_mlpg_fb_lds(BatchDev bd, StreamDev
     if (n == 0)
         return;
     const int L = sd.L;
-    const uint64_t row0 = up->frame_off * (uint64_t)L;
-    const uint64_t rs = up->T; // row stride of the [dim][frame] workspace
+    const uint64_t row0 = mt_row0(up, L);
+    const uint64_t rs = up->mt_rs; // row stride of the [dim][frame] workspace
     // The solver's dependent chain is the critical path of the kernel (and of the step): it gets
     // the highest issue priority on its SIMD, the movers the next one, so that throughput kernels
     // sharing the CU (the excitation pass runs concurrently) fill the gaps instead of taking turns.
@@ -1955,7 +1954,7 @@ __device__ __forceinline__ void gv_tp_body(const BatchDev &bd, const StreamDev &
         return;
     const int L = sd.L, B = bd.B;
     const uint32_t NT = sd.gv_ntile;
-    const uint64_t row = up->frame_off * (uint64_t)L + (uint64_t)m * (uint64_t)up->T;
+    const uint64_t row = mt_row0(up, L) + (uint64_t)m * (uint64_t)up->mt_rs;
     const uint8_t *sw = sd.vsw + up->frame_off;
     const double *A0 = sd.A[0] + row, *A1 = sd.A[1] + row, *A2 = sd.A[2] + row, *Bv = sd.bvec + row;
     const double *P = src + row;
@@ -2208,7 +2207,6 @@ __global__ __launch_bounds__(256) void k_mlpg_scatter_mt(BatchDev bd, StreamDev 
         return;
     const uint64_t base = up->frame_off, sb = up->state_off;
     const int L = sd.L;
-    const uint64_t row0 = base * (uint64_t)L;
     for (int e = threadIdx.x; e < 64 * L; e += blockDim.x) {
         const int m = e >> 6, tl = e & 63;
         const uint32_t t = t0 + (uint32_t)tl;
@@ -2219,7 +2217,7 @@ __global__ __launch_bounds__(256) void k_mlpg_scatter_mt(BatchDev bd, StreamDev 
                 const uint32_t s_ = sd.fstate[base + t];
                 k = sd.s_vpre[sb + s_] + (t - sd.s_start[sb + s_]);
             }
-            v = sd.par[row0 + (uint64_t)m * T + k];
+            v = sd.par[mt_row0(up, L) + (uint64_t)m * up->mt_rs + k];
         }
         tile[m * 65 + tl] = v;
     }
@@ -2423,11 +2421,10 @@ __global__ __launch_bounds__(256) void k_mc2b_mt(BatchDev bd, StreamDev sd, VocD
         return;
     const uint64_t base = up->frame_off;
     const int L = sd.L;
-    const uint64_t row0 = base * (uint64_t)L;
     const uint32_t nt = T - t0 < 64u ? T - t0 : 64u;
     for (int e = threadIdx.x; e < 64 * L; e += blockDim.x) {
         const int m = e >> 6, tl = e & 63;
-        tile[m * 65 + tl] = (uint32_t)tl < nt ? sd.par[row0 + (uint64_t)m * T + t0 + (uint32_t)tl] : 0.0;
+        tile[m * 65 + tl] = (uint32_t)tl < nt ? sd.par[mt_row0(up, L) + (uint64_t)m * up->mt_rs + t0 + (uint32_t)tl] : 0.0;
     }
     __syncthreads();
     const uint64_t o0 = (base + t0) * (uint64_t)L;
