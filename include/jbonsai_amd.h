@@ -242,6 +242,10 @@ int jb_batch_info(const jb_batch *b, uint32_t *chunk_frames, uint32_t *warmup_fr
 /* Of the chunks that failed the hand-off check in the last run: how many were settled by
  * recomputing only up to their checkpoint (48 frames) and how many had to be recomputed to the end. */
 int jb_batch_redo_stats(const jb_batch *b, uint32_t *n_partial, uint32_t *n_full);
+/* Which vocoder kernel the last run's work list was built for: *lane_triple = 1 the throughput kernel
+ * (k_vocoder_lt: one time-chunk per lane triple), 0 the wave kernel (k_vocoder: one chunk per wave);
+ * *waves_per_simd = 1 or 2 (four- / eight-wave workgroups of the throughput kernel; 0 for the wave kernel). */
+int jb_batch_kernel_info(const jb_batch *b, uint32_t *lane_triple, uint32_t *waves_per_simd);
 /* Times the resident GV kernel of this batch gave up in formation and the step was redone with the
  * multi-launch sweeps (0 in normal operation; see jb_gv_gang.hip "Liveness"). */
 uint32_t jb_batch_gang_fallbacks(const jb_batch *b);
@@ -335,6 +339,9 @@ void jb_comm_free(jb_comm *c);
  * tests/fake_rccl that lets several ranks share one device). */
 int jb_gather_pcm(jb_comm *c, jb_batch *b, int root, jb_gathered **out, float *ms);
 size_t jb_gathered_samples(const jb_gathered *g, int rank);
+/* Bytes per sample of the gathered slabs: 8 (f64) or 2 (the 16-bit sink) -- what the SENDING ranks' batches
+ * were made with (a root whose own batch is empty takes it from them). */
+size_t jb_gathered_sample_bytes(const jb_gathered *g);
 void *jb_gathered_device(const jb_gathered *g, int rank);
 /* Device-to-host copy of rank r's slab (cap in BYTES). */
 int jb_gathered_read(const jb_gathered *g, int rank, void *dst, size_t cap_bytes);

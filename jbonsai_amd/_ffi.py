@@ -132,7 +132,7 @@ SYMBOLS = [
     "jb_batch_create", "jb_batch_run", "jb_batch_sync", "jb_batch_run_timed", "jb_batch_last_timing", "jb_batch_size",
     "jb_batch_num_frames", "jb_batch_num_samples", "jb_batch_total_samples", "jb_batch_read_pcm",
     "jb_batch_read_pcm_i16", "jb_batch_read_pcm_all", "jb_batch_read_pcm_i16_all", "jb_pdf_set_create", "jb_pdf_set_free", "jb_batch_create_indexed", "jb_batch_read_track", "jb_release_cached_memory", "jb_set_cached_memory_limit", "jb_batch_read_coefficients", "jb_batch_read_first_coefficients", "jb_batch_read_excitation", "jb_batch_device_pcm", "jb_batch_pcm_offset",
-    "jb_batch_info", "jb_batch_redo_stats", "jb_batch_gang_fallbacks", "jb_batch_free", "jb_paramgen_vocode_batch",
+    "jb_batch_info", "jb_batch_kernel_info", "jb_batch_redo_stats", "jb_batch_gang_fallbacks", "jb_batch_free", "jb_paramgen_vocode_batch",
     "jb_mlpg_batch", "jb_batch_create_from_tracks", "jb_vocode_tracks_batch",
     "jb_engine_load", "jb_engine_load_from_bytes", "jb_engine_new", "jb_engine_free",
     "jb_engine_set_sampling_frequency", "jb_engine_get_sampling_frequency",
@@ -150,7 +150,7 @@ SYMBOLS = [
     "jb_generator_new", "jb_generator_new_from_tracks", "jb_vocoder_synthesize_batch", "jb_generator_fperiod", "jb_generator_synthesized_frames",
     "jb_generator_total_frames", "jb_generator_step", "jb_generator_step_n", "jb_generator_free",
     "jb_comm_unique_id", "jb_comm_init", "jb_comm_rank", "jb_comm_size", "jb_comm_free", "jb_gather_pcm",
-    "jb_gathered_samples", "jb_gathered_device", "jb_gathered_read", "jb_gathered_free",
+    "jb_gathered_samples", "jb_gathered_sample_bytes", "jb_gathered_device", "jb_gathered_read", "jb_gathered_free",
     "jb_lpt_partition", "jb_paramgen_vocode_batch_multi", "jb_synthesize_batch_multi", "jb_synthesize_batch_i16_multi",
     "jb_last_error", "jb_device_count", "jb_device_arch", "jb_version",
 ]
@@ -214,6 +214,7 @@ def lib():
     L.jb_batch_device_pcm.argtypes = [vp, C.POINTER(sz)]
     L.jb_batch_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.jb_batch_redo_stats.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.jb_batch_kernel_info.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.jb_batch_gang_fallbacks.argtypes = [vp]
     L.jb_batch_gang_fallbacks.restype = C.c_uint32
     L.jb_batch_free.argtypes = [vp]
@@ -240,6 +241,8 @@ def lib():
     L.jb_gather_pcm.argtypes = [vp, vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_float)]
     L.jb_gathered_samples.argtypes = [vp, C.c_int]
     L.jb_gathered_samples.restype = sz
+    L.jb_gathered_sample_bytes.argtypes = [vp]
+    L.jb_gathered_sample_bytes.restype = sz
     L.jb_gathered_device.argtypes = [vp, C.c_int]
     L.jb_gathered_device.restype = vp
     L.jb_gathered_read.argtypes = [vp, C.c_int, vp, sz]

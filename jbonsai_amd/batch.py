@@ -268,6 +268,12 @@ class Batch:
         F.check(self._L.jb_batch_info(self._h, *[C.byref(x) for x in v]))
         return dict(chunk_frames=v[0].value, warmup_frames=v[1].value, n_items=v[2].value, n_redo=v[3].value)
 
+    def kernel_info(self):
+        """(kernel name, waves per SIMD) of the vocoder kernel the work list was built for."""
+        lt, w = C.c_uint32(), C.c_uint32()
+        F.check(self._L.jb_batch_kernel_info(self._h, C.byref(lt), C.byref(w)))
+        return ("k_vocoder_lt" if lt.value else "k_vocoder"), w.value
+
     def num_samples(self, i):
         return self._L.jb_batch_num_samples(self._h, i)
 

@@ -62,8 +62,11 @@ class Comm:
         # batch = None: this rank's local work failed; it still joins, and every rank gets an error
         F.check(self._L.jb_gather_pcm(self._h, batch._h if batch is not None else None, root, C.byref(out),
                                       C.byref(ms)))
-        dt = np.int16 if (batch.flags & F.BATCH_PCM_I16) else np.float64
-        return (Gathered(out, self._L, self.n_ranks, dt) if out else None), ms.value
+        if not out:
+            return None, ms.value
+        # the sample size is the SENDERS' (a root with an empty batch of the other kind takes theirs)
+        dt = np.int16 if self._L.jb_gathered_sample_bytes(out) == 2 else np.float64
+        return Gathered(out, self._L, self.n_ranks, dt), ms.value
 
     def close(self):
         if getattr(self, "_h", None):

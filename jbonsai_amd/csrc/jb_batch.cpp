@@ -2457,6 +2457,18 @@ int jb_batch_info(const jb_batch *hb, uint32_t *chunk_frames, uint32_t *warmup_f
     return JB_OK;
 }
 
+int jb_batch_kernel_info(const jb_batch *hb, uint32_t *lane_triple, uint32_t *waves_per_simd)
+{
+    const Batch *b = (const Batch *)hb;
+    if (!b)
+        return JB_ERR_INVALID;
+    if (lane_triple)
+        *lane_triple = b->lp_mode ? 1u : 0u;
+    if (waves_per_simd)
+        *waves_per_simd = b->lp_mode ? (uint32_t)b->lt_waves_per_simd : 0u;
+    return JB_OK;
+}
+
 int jb_batch_redo_stats(const jb_batch *hb, uint32_t *n_partial, uint32_t *n_full)
 {
     const Batch *b = (const Batch *)hb;

@@ -495,13 +495,22 @@ int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float 
             jb::set_error("rank " + std::to_string(p) + " could not contribute its PCM: the gather was abandoned on every rank");
             return JB_ERR_DEVICE;
         }
+    // f64 against 16-bit is decided from the exchanged words ALONE, the same way on every rank (a rank with an
+    // empty batch has no say: its own sample size must not hide a mix between its peers, nor size the root's
+    // receive slabs): mixed = two ranks with samples to send differ; the gather's sample size = the senders'.
     std::vector<uint64_t> counts((size_t)c->n_ranks);
-    bool mixed = false;
+    bool mixed = false, any = false, any_i16 = false;
     for (int p = 0; p < c->n_ranks; p++) {
         counts[(size_t)p] = words[(size_t)p] & ~kI16;
-        if (counts[(size_t)p] && ((words[(size_t)p] & kI16) != 0) != (elem == 2) && ns)
+        if (!counts[(size_t)p])
+            continue;
+        const bool i16 = (words[(size_t)p] & kI16) != 0;
+        if (any && i16 != any_i16)
             mixed = true; // f64 and 16-bit slabs in one gather
+        any = true;
+        any_i16 = any_i16 || i16;
     }
+    const size_t gelem = any ? (any_i16 ? 2 : 8) : elem; // (nobody sends anything: this rank's own, for the record)
     // the root's receive slabs, then one more word from everybody: can the transfer start?
     std::unique_ptr<jb::Gathered> g;
     uint64_t my_status = mixed ? 2 : 0;
@@ -509,7 +518,7 @@ int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float 
         g.reset(new jb::Gathered());
         g->device = c->device;
         g->n_ranks = c->n_ranks;
-        g->elem = elem;
+        g->elem = gelem;
         g->slab.assign((size_t)c->n_ranks, nullptr);
         g->owned.assign((size_t)c->n_ranks, 0);
         g->samples.assign(counts.begin(), counts.end());
@@ -517,7 +526,7 @@ int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float 
             if (p == root) {
                 g->slab[(size_t)p] = slab; // no copy: valid while the batch lives
             } else if (counts[(size_t)p]) {
-                if ((he = hipMalloc(&g->slab[(size_t)p], counts[(size_t)p] * elem)) != hipSuccess) {
+                if ((he = hipMalloc(&g->slab[(size_t)p], counts[(size_t)p] * gelem)) != hipSuccess) {
                     (void)hipGetLastError();
                     my_status = 1;
                 } else {
@@ -543,9 +552,9 @@ int jb_gather_pcm(jb_comm *hc, jb_batch *hb, int root, jb_gathered **out, float 
         if (c->rank == root) {
             for (int p = 0; p < c->n_ranks && e == ncclSuccess; p++)
                 if (p != root && counts[(size_t)p])
-                    e = r->Recv(g->slab[(size_t)p], counts[(size_t)p] * elem, ncclUint8, p, c->comm, c->stream);
+                    e = r->Recv(g->slab[(size_t)p], counts[(size_t)p] * gelem, ncclUint8, p, c->comm, c->stream);
         } else if (ns) {
-            e = r->Send(slab, ns * elem, ncclUint8, root, c->comm, c->stream);
+            e = r->Send(slab, ns * gelem, ncclUint8, root, c->comm, c->stream);
         }
         ncclResult_t e2 = r->GroupEnd(); // always: a group left open would take the next call with it
         if (e != ncclSuccess || e2 != ncclSuccess)
@@ -564,6 +573,8 @@ size_t jb_gathered_samples(const jb_gathered *g, int rank)
     const jb::Gathered *x = (const jb::Gathered *)g;
     return (x && rank >= 0 && rank < x->n_ranks) ? x->samples[(size_t)rank] : 0;
 }
+
+size_t jb_gathered_sample_bytes(const jb_gathered *g) { return g ? ((const jb::Gathered *)g)->elem : 0; }
 
 void *jb_gathered_device(const jb_gathered *g, int rank)
 {

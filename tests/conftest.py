@@ -20,3 +20,24 @@ def oracle_voice():
     from oracle import oracle as O
 
     return O.Voice(VOICE)
+
+
+def tohoku_voices():
+    """The two voice files of the reference's only multi-voice golden (`bonsai_multi`, src/lib.rs:77-91):
+    models/tohoku-f01/tohoku-f01-{neutral,happy}.htsvoice.  The reference tree carries them as an un-fetched git
+    submodule (.gitmodules:1-3) and nothing here fetches anything: point JB_TOHOKU_DIR at a directory holding the
+    two files (or drop them into tests/golden/voice/tohoku-f01/) and the skipped tests run."""
+    cands = [Path(os.environ["JB_TOHOKU_DIR"])] if os.environ.get("JB_TOHOKU_DIR") else []
+    cands.append(ROOT / "tests" / "golden" / "voice" / "tohoku-f01")
+    for d in cands:
+        paths = [d / "tohoku-f01-neutral.htsvoice", d / "tohoku-f01-happy.htsvoice"]
+        if all(p.is_file() for p in paths):
+            return paths
+    pytest.skip("tohoku-f01-neutral/happy.htsvoice not found (the reference's models/tohoku-f01 submodule is empty): "
+                "set JB_TOHOKU_DIR to the directory that holds them to pin the two-voice blend")
+
+
+# Engine::load([neutral, happy]) + the weights of src/lib.rs:80-84 (GV weights stay at InterporationWeight::new's
+# equal split, src/model/interporation_weight.rs:48-60)
+BONSAI_MULTI_WEIGHTS = {"duration": [0.7, 0.3], "parameter": [[0.7, 0.3], [0.7, 0.3], [1.0, 0.0]]}
+BONSAI_MULTI_GOLDEN = {"len": 74880, 2000: 2.3158134981607754e-5, 30000: 6459.375032316974}  # src/lib.rs:88-90

@@ -55,6 +55,21 @@ def test_is_this_bonsai_fast():
     assert abs(speech[71199] - 7.840225089163972) < EPS
 
 
+def test_bonsai_multi():
+    """src/lib.rs:77-91 through the GPU engine: two DIFFERENT voices blended on the device (k_gather_blend).
+    Skipped until the tohoku-f01 files are supplied (tests/conftest.py: JB_TOHOKU_DIR)."""
+    from tests.conftest import BONSAI_MULTI_GOLDEN, BONSAI_MULTI_WEIGHTS, tohoku_voices
+
+    e = J.Engine.load(tohoku_voices())
+    e.condition.set_interpolation_duration(BONSAI_MULTI_WEIGHTS["duration"])
+    for i, w in enumerate(BONSAI_MULTI_WEIGHTS["parameter"]):
+        e.condition.set_interpolation_parameter(i, w)
+    speech = e.synthesize(SAMPLE_SENTENCE_1)
+    assert len(speech) == BONSAI_MULTI_GOLDEN["len"]
+    assert abs(speech[2000] - BONSAI_MULTI_GOLDEN[2000]) < EPS
+    assert abs(speech[30000] - BONSAI_MULTI_GOLDEN[30000]) < EPS
+
+
 def test_empty():
     e = J.Engine.load([VOICE])
     assert len(e.synthesize([])) == 0

@@ -40,7 +40,10 @@ def run_world(tmp_path, double, world, root, mode):
     return outs
 
 
-@pytest.mark.parametrize("world,root,mode", [(4, 0, "f64"), (4, 2, "f64"), (3, 1, "i16"), (2, 0, "f64")])
+@pytest.mark.parametrize("world,root,mode", [(4, 0, "f64"), (4, 2, "f64"), (3, 1, "i16"), (2, 0, "f64"),
+                                             # an empty f64 batch on the root, 16-bit senders: not a mix,
+                                             # and the receive slabs are sized by what the senders send
+                                             (3, 1, "i16_f64_empty"), (3, 0, "i16_f64_empty")])
 def test_gather_with_several_ranks_on_one_device(tmp_path, double, world, root, mode):
     outs = run_world(tmp_path, double, world, root, mode)
     assert all((tmp_path / f"done_{r}").read_text() == "ok" for r in range(world))

@@ -164,6 +164,18 @@ def test_is_this_bonsai_fast(oracle_voice):
     assert abs(s[71199] - 7.840225089163972) <= EPS
 
 
+def test_bonsai_multi():
+    """src/lib.rs:77-91 -- the reference's ONLY pin of VoiceSet::weighted on two different voices (BASELINE config
+    5, SURVEY f-1).  Skipped until the tohoku-f01 files are supplied (tests/conftest.py: JB_TOHOKU_DIR)."""
+    from tests.conftest import BONSAI_MULTI_GOLDEN, BONSAI_MULTI_WEIGHTS, tohoku_voices
+
+    vs = O.VoiceSet(tohoku_voices(), BONSAI_MULTI_WEIGHTS)
+    s = vs.synthesize(SAMPLE_SENTENCE_1)
+    assert len(s) == BONSAI_MULTI_GOLDEN["len"]
+    assert abs(s[2000] - BONSAI_MULTI_GOLDEN[2000]) <= EPS
+    assert abs(s[30000] - BONSAI_MULTI_GOLDEN[30000]) <= EPS
+
+
 def test_empty(oracle_voice):
     assert len(oracle_voice.synthesize([])) == 0
     assert len(oracle_voice.synthesize([], speed=1.2)) == 0

@@ -2,7 +2,9 @@
 a fresh process, no torch, RCCL = the test double (JB_RCCL_LIBRARY).  Rank 0 makes the communicator id and
 leaves it in the exchange directory; every rank runs a small batch of its own, joins the gather, and the root
 checks every slab against what the ranks left behind.
-usage: gather_worker.py DIR WORLD RANK ROOT MODE      MODE = f64 | i16 | fail:<rank> | mixed"""
+usage: gather_worker.py DIR WORLD RANK ROOT MODE      MODE = f64 | i16 | fail:<rank> | mixed | i16_f64_empty
+(i16_f64_empty: every rank with samples makes 16-bit PCM, rank 1 -- whose batch is empty -- an f64 batch: not a
+mix, and the slabs are sized by the senders, whichever rank is the root)"""
 import sys
 import time
 from pathlib import Path
@@ -37,7 +39,7 @@ tab, vi = synth.VoiceTables(eng), eng.voice_info()
 # ragged shares: rank r holds r + 1 utterances of different lengths; rank 1 holds none (an empty slab)
 n_utts = 0 if rank == 1 else rank + 1
 utts = [synth.synth_utterance(tab, 150 + 90 * ((rank * 7 + i) % 5), 900 + 10 * rank + i) for i in range(n_utts)]
-i16 = mode == "i16" or (mode == "mixed" and rank == world - 1)
+i16 = mode == "i16" or (mode == "mixed" and rank == world - 1) or (mode == "i16_f64_empty" and rank != 1)
 batch = J.Batch(vi, utts, pcm_i16=i16)
 batch.run()
 batch.sync()
@@ -66,6 +68,7 @@ if rank == root:
         want = np.load(d / f"slab_{p}.npy")
         assert g.samples(p) == len(want), (p, g.samples(p), len(want))
         got = g.read(p)
+        assert got.dtype == want.dtype or len(want) == 0, (p, got.dtype, want.dtype)
         assert np.array_equal(got, want), p
     print(f"rank {rank} (root): {world} slabs, {[g.samples(p) for p in range(world)]} samples, {ms:.2f} ms")
     g.close()

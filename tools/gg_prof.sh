@@ -1,7 +1,12 @@
 #!/bin/bash
-# where the resident GV kernel spends its time: -DJB_GG_PROFILE build, one-stream run (VARIANT = extra -D flags)
+# where the resident GV kernel spends its time: a -DJB_GG_PROFILE build of the library, one-stream run.
+# The variant is built BEFOREHAND, where hipcc runs without a GPU (tools/build_variant.sh ggprof -DJB_GG_PROFILE=1
+# [more -D flags] -> tools/_ab_ggprof/libjbonsai_amd.so, which travels to the GPU box); this script only swaps it
+# in for one bench run and puts the product library back.
 cd "$(dirname "$0")/.."
-trap 'rm -f jbonsai_amd/csrc/build/jb_gv_gang.o && bash jbonsai_amd/csrc/build.sh > /dev/null' EXIT
-(cd jbonsai_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DJB_GG_PROFILE=1 $VARIANT -x hip -c jb_gv_gang.hip -o build/jb_gv_gang.o \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o ../libjbonsai_amd.so build/*.o) || exit 1
+V=${1:-tools/_ab_ggprof/libjbonsai_amd.so}
+[ -f "$V" ] || { echo "$V missing: run tools/build_variant.sh ggprof -DJB_GG_PROFILE=1 first"; exit 1; }
+cp jbonsai_amd/libjbonsai_amd.so /tmp/_keep_ggprof.so
+trap 'cp /tmp/_keep_ggprof.so jbonsai_amd/libjbonsai_amd.so' EXIT
+cp "$V" jbonsai_amd/libjbonsai_amd.so
 JB_ONE_STREAM=1 JB_GG_PROFILE_PRINT=1 python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 2>&1 | grep "ticks" | tail -1

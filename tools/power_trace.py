@@ -1,19 +1,26 @@
-"""Socket power and shader clock while bench.py runs (GPU box): samples the hwmon files of the device every few ms in
-a thread (amdgpu: power1_average / power1_input in microwatts, freq1_input in Hz) and prints the distribution.
+"""Socket power and shader clock of THE CARD UNDER TEST while bench.py runs (GPU box).  Every GPU of the host shows
+in sysfs and one is ours: the card is found by the PCI bus id HIP reports for device 0 (asked in a child process, so
+that the sampler itself never initialises the GPU), not by guessing from the readings (round 4 read a neighbour).
+Samples the card's hwmon files every few ms in a thread (amdgpu: power1_average / power1_input in microwatts,
+freq1_input = sclk in Hz) and prints the distribution over the timed steps.
 Usage: python tools/power_trace.py [bench.py arguments]"""
-import glob, subprocess, sys, threading, time, statistics as st
+import glob, os, subprocess, sys, threading, time, statistics as st
 
-def cards():
-    """hwmon directories of every amdgpu device the box shows (all GPUs of the host appear in sysfs, one is ours)"""
-    out = []
-    for h in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')):
-        d = {}
+def our_bus_id():
+    code = ("import ctypes;h=ctypes.CDLL('libamdhip64.so');b=ctypes.create_string_buffer(64);"
+            "rc=h.hipDeviceGetPCIBusId(b,64,0);print(b.value.decode() if rc==0 else '')")
+    try:
+        return subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=120).stdout.strip().lower()
+    except Exception:
+        return ''
+
+def hwmon_of(bus):
+    d = {}
+    for h in sorted(glob.glob(f'/sys/bus/pci/devices/{bus}/hwmon/hwmon*')):
         for name in ('power1_average', 'power1_input', 'freq1_input', 'power1_cap'):
             for p in glob.glob(h + '/' + name):
                 d[name] = p
-        if 'power1_average' in d or 'power1_input' in d:
-            out.append(d)
-    return out
+    return d
 
 def rd(p):
     try:
@@ -21,29 +28,28 @@ def rd(p):
     except Exception:
         return None
 
-C = cards()
-allsamples, stop = [[] for _ in C], False
+bus = our_bus_id()
+F = hwmon_of(bus) if bus else {}
+print('device 0 PCI bus id:', bus or 'unknown', '| hwmon files:', {k: v for k, v in F.items()})
+if not F:
+    print('no hwmon directory for that bus id is visible on this box (cards visible:',
+          len(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')), ')')
+samples, stop = [], False
 def loop():
+    pw = F.get('power1_average') or F.get('power1_input', '')
     while not stop:
-        for F, sm in zip(C, allsamples):
-            sm.append((time.time(), rd(F.get('power1_average') or F.get('power1_input', '')), rd(F.get('freq1_input', ''))))
+        samples.append((time.time(), rd(pw), rd(F.get('freq1_input', ''))))
         time.sleep(0.004)
 t = threading.Thread(target=loop); t.start()
-args = sys.argv[1:] or ['--no-cpu-baseline', '--no-extras', '--steps', '30', '--warmup', '3']
-t0 = time.time()
+args = sys.argv[1:] or ['--no-cpu-baseline', '--no-extras', '--steps', '60', '--warmup', '3']
 r = subprocess.run([sys.executable, 'bench.py'] + args, capture_output=True, text=True)
-t1 = time.time()
 stop = True; t.join()
 print(r.stdout.strip().splitlines()[-1][:300] if r.stdout.strip() else r.stderr[-500:])
-# ours is the device whose power moved most during the run
-spread = [max([s[1] or 0 for s in sm] or [0]) - min([s[1] or 0 for s in sm] or [0]) for sm in allsamples]
-k = spread.index(max(spread)); F, samples = C[k], allsamples[k]
-print('device', k, 'of', len(C), F.get('power1_input') or F.get('power1_average'))
 print('power cap (W):', (rd(F['power1_cap']) or 0) / 1e6 if 'power1_cap' in F else None)
 # the timed steps are the last part of the run: take the last 30 % of the samples
 n = len(samples); tail = samples[int(n * 0.7):]
 pw = [s[1] / 1e6 for s in tail if s[1]]; fq = [s[2] / 1e6 for s in tail if s[2]]
-if pw: print('power W (last 30 %% of the run, %d samples): min %.0f median %.0f max %.0f' % (len(pw), min(pw), st.median(pw), max(pw)))
-if fq: print('sclk MHz: min %.0f median %.0f max %.0f' % (min(fq), st.median(fq), max(fq)))
+if pw: print('power W (last 30 %% of the run = timed steps, %d samples): min %.0f median %.0f max %.0f' % (len(pw), min(pw), st.median(pw), max(pw)))
+if fq: print('sclk MHz (same window): min %.0f median %.0f max %.0f' % (min(fq), st.median(fq), max(fq)))
 pw_all = [s[1] / 1e6 for s in samples if s[1]]
-if pw_all: print('power W over the whole run: max %.0f' % max(pw_all))
+if pw_all: print('power W over the whole run: min %.0f max %.0f' % (min(pw_all), max(pw_all)))
