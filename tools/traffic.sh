@@ -29,13 +29,18 @@ for ln in open(f"{out}/fetch_calibration.txt"):
     m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+(\S+)\s+reported.*reported/known\s+([\d.]+)", ln)
     if m:
         cal[m.group(2)] = float(m.group(3))
+# Every coalesced shape measured -- 4, 8 and 16 B per lane, and 128-byte pieces of rows 200 KB apart -- reports exactly
+# half its bytes (requests of 128 B tallied at 64 B), so the raw figure is divided by that for EVERY kernel.  The
+# lane-stream shape (one stream per lane, 8 B per access: the vocoder's excitation reads) is not a counter calibration
+# but an over-fetch measurement -- the microbenchmark's lanes evict each other's lines and fetch 8x their bytes -- and
+# is kept in the file as such; the vocoder kernel's own figure is given with its lower bound (the raw tally).
+RD8 = "rd<HIP_vector_type<unsigned int, 2u> >"
 shape_of = {  # how a kernel reads its bulk (jb_mlpg.hip, jb_gv_gang.hip, jb_vocoder.hip)
     "k_mlpg_fb_lds": "rd8_rows", "k_mlpg_gv_gang": "rd8_rows", "k_mc2b_mt": "rd8_rows", "k_mlpg_fb_runs": "rd8_rows",
-    "k_mlpg_gv_vt": "rd<uint2>", "k_vocoder_lt": "rd8_lane_stream", "k_vocoder": "rd<uint2>",
 }
 def shape(k):
     base = k.replace("jb::", "").split("<")[0]
-    return shape_of.get(base, "rd<uint2>")
+    return shape_of.get(base, RD8)
 acc = {c: collections.defaultdict(float) for c in ("FETCH_SIZE", "WRITE_SIZE")}
 cnt = collections.Counter()
 for c in acc:
@@ -67,7 +72,7 @@ allk = {}
 for k in sorted(acc["FETCH_SIZE"]):
     base = k.replace("jb::", "").split("<")[0]
     sh = shape(k)
-    f = cal.get(sh) or cal.get("rd<uint2>") or 1.0
+    f = cal.get(sh) or cal.get(RD8) or 0.5
     raw = acc["FETCH_SIZE"][k]
     rec = {"fetch_bytes_raw": raw, "access_shape": sh, "reported_over_known": f, "fetch_bytes": raw / f,
            "write_bytes": acc["WRITE_SIZE"][k], "launches": cnt[k]}
@@ -75,6 +80,10 @@ for k in sorted(acc["FETCH_SIZE"]):
         rec["expected_read_bytes"], rec["expected_read_what"] = must_read[base]
         rec["implied_factor_if_compulsory_only"] = raw / must_read[base][0]
         rec["reads_ge_expected"] = bool(rec["fetch_bytes"] >= 0.98 * must_read[base][0])
+    if base.startswith("k_vocoder"):
+        rec["fetch_bytes_lower_bound"] = raw
+        rec["fetch_note"] = ("lane-private 8-byte reads: if some of its requests are partial lines (64 B) they are tallied "
+                             "in full and the true figure lies between the raw tally and its double")
     if base in must_write:
         rec["expected_write_bytes"], rec["expected_write_what"] = must_write[base]
     allk[k] = rec
@@ -92,8 +101,9 @@ res = {
     "algorithmic_bytes_per_launch": 8.67 * samples,
     "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KB x 1024), bench.py --steps 1 --warmup 0. "
             "fetch_bytes = fetch_bytes_raw / reported_over_known, the factor measured in the same call on known byte counts "
-            "of the kernel's access shape (tools/microbench/fetch_calib.hip); expected_read_bytes = the arrays a kernel must "
-            "read (DESIGN.md section 3).  WRITE_SIZE is taken as reported (calibrated in the same file).",
+            "(tools/microbench/fetch_calib.hip: every coalesced shape -- 4, 8, 16 B per lane, 128-byte pieces of far-apart rows "
+            "-- reports 0.500 of its bytes); expected_read_bytes = the arrays a kernel must read (DESIGN.md section 3).  "
+            "WRITE_SIZE is taken as reported (1.000 for 8 and 16 B per lane in the same file).",
     "all_kernels": allk,
 }
 json.dump(res, open(f"profiles/{R}_traffic.json", "w"), indent=1)
