@@ -80,8 +80,11 @@ def parse_args():
                          "of seed-fixed lengths U[400, 25546] frames, resident before the timed region")
     ap.add_argument("--gather", action="store_true",
                     help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
-                         "(point-to-point over xGMI) and report its time as gather_ms; "
-                         "never part of `value` (SURVEY 8e)")
+                         "(point-to-point over xGMI): the 16-bit slab (a quarter of the bytes: at N = 8 the f64 "
+                         "slabs are 88 GB into the root per step, more than its seven links carry in a step), alone "
+                         "(gather_ms) and beside the next step on two alternating batches "
+                         "(gather_overlapped_ms_per_step); never part of `value` (SURVEY 8e)")
+    ap.add_argument("--gather-f64", action="store_true", help="gather the f64 slabs instead (link-bound at N = 8)")
     ap.add_argument("--beta", type=float, default=0.0,
                     help="post-filter coefficient (off-config: BASELINE's metric is quoted at beta = 0)")
     ap.add_argument("--kernel", choices=("auto", "wave", "triple"), default="auto",
@@ -408,10 +411,13 @@ class Ranks:
         del bufs
         return ms
 
-    def gather_native(self, J, batch):
+    def gather_native(self, J, batch, pair=None):
         """jb_gather_pcm: every rank's PCM slab onto rank 0 through the library's RCCL binding (no torch
         tensor involved; torch.distributed only hands the 128-byte communicator id to the ranks).  Returns
-        the max-over-ranks time of the exchange in ms; the communicator setup is not part of it."""
+        (max-over-ranks time of one exchange alone in ms, ms per step with the gather of step k beside step k + 1 on
+        the two alternating batches of `pair` or None); the communicator setup is not part of either."""
+        import threading
+
         ids = [J.comm.unique_id() if self.rank == 0 else None]
         self.dist.broadcast_object_list(ids, src=0)
         c = J.comm.Comm(ids[0], self.world, self.rank, device=self.local_rank)
@@ -421,8 +427,46 @@ class Ranks:
         if g is not None:
             assert sum(g.samples(r) for r in range(self.world)) >= batch.total_samples
             g.close()
+        overlapped = None
+        if pair is not None:
+            # step k + 1 on one batch while the slab of step k (the other batch) travels: the gather runs on the
+            # communicator's own stream from a thread of its own (jb_gather_pcm waits for ITS batch only); every rank
+            # issues its gathers in the same order, so the collective matches up
+            errs = []
+
+            def gather(j):
+                try:
+                    gj, _ = c.gather_pcm(pair[j], root=0)
+                    if gj is not None:
+                        gj.close()
+                except Exception as e:  # noqa: BLE001
+                    errs.append(repr(e))
+
+            for b_ in pair:  # warm-up: pools filled
+                b_.run()
+                b_.sync()
+            nst = 6
+            th = [None, None]
+            self.barrier()
+            t0 = time.perf_counter()
+            for k in range(nst):
+                j = k % 2
+                if th[j] is not None:
+                    th[j].join()  # this batch's slab has left: it may be overwritten
+                pair[j].run()
+                if k >= 1:
+                    th[1 - j] = threading.Thread(target=gather, args=(1 - j,))
+                    th[1 - j].start()
+            last = (nst - 1) % 2
+            if th[1 - last] is not None:
+                th[1 - last].join()
+            gather(last)
+            self.barrier()
+            overlapped = self.max((time.perf_counter() - t0) / nst * 1e3)
+            if errs:
+                raise RuntimeError(errs[0])
         c.close()
-        return ms
+        return ms, overlapped
 
     def close(self):
         if self.dist is not None:
@@ -1029,7 +1073,8 @@ def run_rank(args):
             b_.sync()
     dt, voc_ms = timed_steps(batches, args.steps, R)
 
-    gather_ms = None
+    gather_ms = gather_ovl = None
+    gather_dtype = "f64" if args.gather_f64 else "i16"
     if args.gather and R.world > 1:
         # optional sink of north_star: PCM of all ranks on GPU 0 (rank 0 needs world x 12.6 GB of HBM for
         # config 2).  The library's own gather: grouped ncclSend / ncclRecv over xGMI (jb_gather_pcm); the
@@ -1037,10 +1082,21 @@ def run_rank(args):
         # rehearsal (gloo) RCCL cannot run: there the slabs go through torch.distributed on the host.
         # With JB_RCCL_LIBRARY = the test double of tests/fake_rccl (several ranks on one device) the rehearsal
         # takes the library's own gather too: functional only, its time says nothing about xGMI.
+        # Default: the 16-bit slab (north_star's sink is PCM; 3.1 GB per rank instead of 12.6), also measured beside
+        # the next step: two batches alternate, as in `host_visible`.
         if R.rehearse and not os.environ.get("JB_RCCL_LIBRARY"):
             gather_ms = R.gather_slabs(pcm_slab_tensor(batch))
+            gather_dtype = "f64"
         else:
-            gather_ms = R.gather_native(J, batch)
+            i16 = not args.gather_f64
+            pair = [J.Batch(vi, batch_utts, device=R.local_rank, pcm_i16=i16) for _ in range(2)]
+            try:
+                pair[0].run()
+                pair[0].sync()
+                gather_ms, gather_ovl = R.gather_native(J, pair[0], pair)
+            finally:
+                for b_ in pair:
+                    b_.close()
 
     info = batch.info()
     info["kernel"], info["waves_per_simd"] = batch.kernel_info()
@@ -1075,7 +1131,9 @@ def run_rank(args):
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
             "realtime_factor": value / vi.sampling_frequency,
-            **({"gather_ms": gather_ms} if gather_ms is not None else {}),
+            **({"gather_ms": gather_ms, "gather_overlapped_ms_per_step": gather_ovl, "gather_dtype": gather_dtype,
+                "gather_bytes_into_root": (R.world - 1) * samples_per_step * (8 if gather_dtype == "f64" else 2)}
+               if gather_ms is not None else {}),
             "roofline": roofline_block(samples_per_step, voc_avg_ms, info, args.batch, frames),
             "kernel_sources_sha16": kernel_sources_sha16(),
         }

@@ -142,6 +142,12 @@ class IndexStreamStates:
         self.gv_mean, self.gv_var = f(self.gv_mean, np.float64), f(self.gv_var, np.float64)
         self.gv_switch = f(self.gv_switch, np.uint8)
 
+    def __setattr__(self, name, value):
+        # every assignment bumps a version: an IndexUtterance that has marshalled this stream marshals it again
+        # (replacing an ELEMENT of `rows` in place is not seen: assign the list)
+        object.__setattr__(self, name, value)
+        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1)
+
 
 @dataclass
 class IndexUtterance:
@@ -156,8 +162,10 @@ class IndexUtterance:
         # marshalled once per object (the struct only points into arrays this object owns; an utterance is not
         # edited after its first use): a job that creates its batches again every pass -- bench.py's config-3
         # job -- spent 12 of the 27 ms of a 512-utterance creation building these
+        # -- until one is: assigning a field of the utterance or of one of its streams drops the cached struct
+        ver = sum(st.__dict__.get("_version", 0) for st in self.streams)
         c = self.__dict__.get("_c")
-        if c is not None:
+        if c is not None and self.__dict__.get("_c_ver") == ver:
             return c
         u = F.IndexUtt()
         u.num_states = len(self.durations)
@@ -172,7 +180,12 @@ class IndexUtterance:
             d.gv_switch = s.gv_switch.ctypes.data_as(C.POINTER(C.c_uint8)) if s.gv_switch is not None else None
             d.gv_weight, d.msd_threshold = s.gv_weight, s.msd_threshold
         self.__dict__["_c"] = u
+        self.__dict__["_c_ver"] = ver
         return u
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, name, value)
+        self.__dict__.pop("_c", None)
 
 
 @dataclass

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <set>
 #include <tuple>
 #include <numeric>
@@ -267,8 +268,10 @@ void stream_release(int device, hipStream_t st)
 
 } // namespace
 
+static void release_pinned_chunks();
 void release_cached_memory()
 {
+    release_pinned_chunks(); // the pinned staging chunks kept between batches (up to 16 x 8 MB of locked host memory)
     std::lock_guard<std::mutex> lk(g_pool_mu);
     int cur = -1;
     (void)hipGetDevice(&cur);
@@ -364,6 +367,16 @@ template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
 static std::mutex g_pin_mu;
 static std::vector<uint8_t *> g_pin_free;
 static constexpr size_t kPinChunk = 8u << 20, kPinKeep = 16;
+static void release_pinned_chunks()
+{
+    std::vector<uint8_t *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        drop.swap(g_pin_free);
+    }
+    for (uint8_t *q : drop)
+        (void)hipHostFree(q);
+}
 bool Batch::PinnedChunk::acquire(size_t bytes)
 {
     reset();
@@ -374,21 +387,33 @@ bool Batch::PinnedChunk::acquire(size_t bytes)
         if (!g_pin_free.empty()) {
             p = g_pin_free.back();
             g_pin_free.pop_back();
+            pageable = false;
             return true;
         }
     }
     void *v = nullptr;
     if (hipHostMalloc(&v, bytes, hipHostMallocPortable) != hipSuccess) {
+        // no pinned memory to be had (a locked-memory limit, a host short of it): a pageable buffer does -- hipMemcpy
+        // takes either, the copy is just slower (what every batch did until round 4)
         (void)hipGetLastError();
-        return false;
+        p = new (std::nothrow) uint8_t[bytes];
+        pageable = p != nullptr;
+        return p != nullptr;
     }
     p = (uint8_t *)v;
+    pageable = false;
     return true;
 }
 void Batch::PinnedChunk::reset()
 {
     if (!p)
         return;
+    if (pageable) {
+        delete[] p;
+        p = nullptr;
+        pageable = false;
+        return;
+    }
     {
         std::lock_guard<std::mutex> lk(g_pin_mu);
         if (g_pin_free.size() < kPinKeep) {
@@ -1222,10 +1247,12 @@ int Batch::build_work(const jb_batch_opts *opts)
     // step at 18 / 16 / 14 / 12 frames: 512 mixed lengths 84.5 / 83.8 / 83.2 / 84.7, 1024 x 6,386 distinct 83.5 /
     // 82.6 / 82.3 / 83.5, 64 distinct x 4 copies 82.4 / 81.3 / 80.5 / 82.2, 64 x 2,000 10.9 / 9.6 / 9.2 (at 14:
     // 1.7 % of the hand-offs fail, 720-810 chunks; at 12: 1,400-1,470, two to a SIMD).  Copies of ONE utterance
-    // keep 18: their 167 positions fail for all copies or for none, config 2's own have none at 18, and the
-    // expectation over utterances differs by 0.5 ms either way.  Decided below, once the
-    // chunk length is known: 14 frames from 1000 distinct hand-off positions (the chance that none of them fails at
-    // 18 frames is then under 0.1 %), else 18 -- small requests keep the geometry they had.
+    // keep 18: their 167 positions fail for all copies or for none, and over the FAMILY of such batches 18 is the
+    // cheaper length -- round 5, BASELINE config 2 for the utterances of seeds 0..3, ms per step at 18 / 14 frames, same
+    // box: 76.6 / 78.4, 79.5 / 80.5 (three positions fail at 18, seven at 14), 79.3 / 78.3, 76.2 / 78.1; mean 77.9
+    // against 78.8 (profiles/r05_seed_sweep_before.txt; two of the four have no failing position at 18, all have at
+    // 14).  Decided below, once the chunk length is known: 14 frames from 1000 distinct hand-off positions (the chance
+    // that none of them fails at 18 frames is then under 0.1 %), else 18 -- small requests keep the geometry they had.
     const bool warmup_given = opts && opts->warmup_frames;
     warmup_frames = warmup_given ? opts->warmup_frames : 18;
     verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
@@ -1253,6 +1280,17 @@ int Batch::build_work(const jb_batch_opts *opts)
         };
         // (per sample and wave, measured: 0.90 us alone on a SIMD, 1.39-1.46 us beside a second wave -- 64 x 11,000
         // frames 18.1 ms per step with one wave per SIMD and 33-frame chunks, 19.8 with two and 17-frame chunks)
+        // (the warm-up the chunks will get -- 14 frames from 1000 distinct hand-off positions, decided for good
+        // below -- enters the comparison: estimated here from the chunk length two waves per SIMD would give)
+        if (!warmup_given) {
+            const uint64_t c2 = std::max<uint64_t>((sumT + 2 * slots1 - 1) / (2 * slots1), cfloor);
+            uint64_t positions = 0;
+            for (int i = 0; i < B; i++)
+                if ((size_t)i >= first_of_kind.size() || first_of_kind[(size_t)i])
+                    positions += (T[(size_t)i] + c2 - 1) / c2;
+            if (positions >= 1000)
+                warmup_frames = 14;
+        }
         lt_waves_per_simd = launch_cost(slots1, 0.90) < launch_cost(2 * slots1, 1.42) ? 1 : 2;
         const uint64_t target = slots1 * (uint64_t)lt_waves_per_simd;
         uint64_t c = (sumT + target - 1) / target;
@@ -1279,6 +1317,9 @@ int Batch::build_work(const jb_batch_opts *opts)
         };
         for (int guard = 0; guard < 256 && c >= cmin && items_at(ch) > target; guard++)
             ch += 1;
+        // (still more items than one wave per SIMD holds: the second wave takes them rather than a tail launch)
+        if (lt_waves_per_simd == 1 && items_at(ch) > slots1)
+            lt_waves_per_simd = 2;
     } else if (ch == 0) {
         // auto (wave kernel): one item per SIMD, two once the batch is large.  The launch takes as long
         // as ONE item (warm-up + chunk frames at 0.25 us per sample; 0.47 with two items on a SIMD), so a
@@ -1292,6 +1333,7 @@ int Batch::build_work(const jb_batch_opts *opts)
     }
     chunk_frames = ch;
     if (!warmup_given && ch != 0) {
+        warmup_frames = 18;
         uint64_t positions = 0;
         for (int i = 0; i < B; i++)
             if ((size_t)i >= first_of_kind.size() || first_of_kind[(size_t)i])

@@ -99,13 +99,21 @@ struct Batch {
     // PINNED staging chunks of the upload arena, kept in a process-wide list between batches (a chunk allocated
     // with new[] for every batch made the arena's H2D copy a pageable one of fresh pages: 14 ms of a 28 ms
     // creation when sub-batches of a job are created one after the other)
-    struct PinnedChunk {
+    struct PinnedChunk { // staging buffer of an upload arena: pinned if the host grants it, else pageable
         uint8_t *p = nullptr;
+        bool pageable = false;
         PinnedChunk() = default;
         PinnedChunk(const PinnedChunk &) = delete;
         PinnedChunk &operator=(const PinnedChunk &) = delete;
-        PinnedChunk(PinnedChunk &&o) noexcept : p(o.p) { o.p = nullptr; }
-        PinnedChunk &operator=(PinnedChunk &&o) noexcept { reset(); p = o.p; o.p = nullptr; return *this; }
+        PinnedChunk(PinnedChunk &&o) noexcept : p(o.p), pageable(o.pageable) { o.p = nullptr; }
+        PinnedChunk &operator=(PinnedChunk &&o) noexcept
+        {
+            reset();
+            p = o.p;
+            pageable = o.pageable;
+            o.p = nullptr;
+            return *this;
+        }
         ~PinnedChunk() { reset(); }
         bool acquire(size_t bytes);
         void reset();

@@ -1968,10 +1968,16 @@ hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t
     // pass; it still does for a voice whose LPF taps differ from frame to frame).  Fixed grid: three
     // workgroups per CU of the device, each wave taking list entries in turn.
     constexpr size_t pad = 32 * 1024;
+    // (the CU count of a device is asked once per process, not once per step)
+    static int cus_of[64] = {0};
     int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         cus = 256;
+    else if ((cus = cus_of[dev]) == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        cus_of[dev] = cus;
+    }
     const dim3 ggen((unsigned)(3 * cus));
     if (vd.nlpf == 31) {
         hipLaunchKernelGGL(k_exc_classify<31>, gcls, block, 0, stream, bd, vd);

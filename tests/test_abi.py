@@ -121,3 +121,24 @@ def test_library_asks_for_hardware_queues_in_a_fresh_process():
     r = subprocess.run([sys.executable, "-c", code, str(J.LIB_PATH)], capture_output=True, text=True,
                        env=dict(env, JB_LEAVE_HIP_ENV="1"), timeout=120)
     assert r.returncode == 0 and "None" in r.stdout, r.stdout + r.stderr
+
+
+def test_index_utterance_struct_cache_follows_assignments():
+    """IndexUtterance.c_struct() is marshalled once per object: assigning a field of the utterance or of
+    one of its streams must drop the cached struct, or the next Batch silently uploads the old arrays."""
+    import numpy as np
+
+    from jbonsai_amd.batch import IndexStreamStates, IndexUtterance
+
+    st = IndexStreamStates(rows=[np.arange(5, dtype=np.uint32)], weights=np.ones(1))
+    u = IndexUtterance(durations=np.full(5, 3, dtype=np.uint32), streams=[st], lf0_offset=0.0)
+    c0 = u.c_struct()
+    assert u.c_struct() is c0 and c0.num_states == 5
+    u.durations = np.full(7, 2, dtype=np.uint32)
+    c1 = u.c_struct()
+    assert c1 is not c0 and c1.num_states == 7 and c1.durations[0] == 2
+    new_rows = np.arange(10, 17, dtype=np.uint32)
+    st.rows = [new_rows]
+    c2 = u.c_struct()
+    assert c2 is not c1 and c2.stream[0].row[0][0] == 10
+    assert u.c_struct() is c2
