@@ -20,4 +20,8 @@ JB_ONE_STREAM=1 STEPS=4 bash tools/kstats.sh > $out/${R}_kernel_ms_per_step_one_
 KERNEL=k_mlpg_gv_gang bash tools/pmc_voc.sh > $out/${R}_pmc_sq_k_mlpg_gv_gang.txt 2>&1
 bash tools/gg_prof.sh > $out/${R}_gv_gang_sections.txt 2>&1
 bash tools/shapes.sh > $out/${R}_shapes.txt 2>&1
+bash tools/small_shapes.sh > $out/${R}_small_shapes.txt 2>&1
+python tools/power_trace.py > $out/${R}_power.txt 2>&1
+bash tools/seed_sweep.sh > $out/${R}_seed_sweep.txt 2>&1
+python tools/latency_single.py > $out/${R}_latency_single.txt 2>&1
 ls -la $out
