@@ -1986,6 +1986,36 @@ int Batch::sync()
                         "%.0f) step %.0f store %.0f\n",
                         c.prof[0] / nb, c.prof[1] / nb, c.prof[2] / nb, c.prof[3] / nb, c.prof[6] / nb, c.prof[4] / nb,
                         c.prof[5] / nb);
+#ifdef JB_GG_PROFILE
+                // who a gang waits for: per exchange of gangs 0, 9, 18 the arrival of each tile (its sums ready) behind the
+                // gang's first arrival, and how long after the LAST arrival the last tile had the exchange over (100 MHz clock)
+                const int nt = std::min(sd[si].gv_gang_tiles, 8);
+                for (int gi : {0, 9, 18}) {
+                    if (gi >= sd[si].gv_gang_n)
+                        continue;
+                    GvGang gg;
+                    hipMemcpy(&gg, (const uint8_t *)sd[si].gv_gang_ctl + sizeof(GvGangCtl) + sizeof(GvGang) * (size_t)gi, sizeof gg,
+                              hipMemcpyDeviceToHost);
+                    fprintf(stderr, "gang %d: exchange | arrival of tiles 0..%d behind the first, us | last arrival -> all done, us | since previous exchange, us\n", gi, nt - 1);
+                    unsigned long long prev_first = 0;
+                    for (int e = 0; e < 96; e++) {
+                        unsigned long long first = ~0ull, last = 0, done = 0;
+                        for (int t = 0; t < nt; t++) {
+                            first = std::min(first, gg.stamp[0][t][e]);
+                            last = std::max(last, gg.stamp[0][t][e]);
+                            done = std::max(done, gg.stamp[1][t][e]);
+                        }
+                        if (first == 0)
+                            break;
+                        fprintf(stderr, "  %2d |", e);
+                        for (int t = 0; t < nt; t++)
+                            fprintf(stderr, " %5.2f", (double)(gg.stamp[0][t][e] - first) / 100.0);
+                        fprintf(stderr, " | %5.2f | %6.2f\n", (double)(done - last) / 100.0,
+                                prev_first ? (double)(first - prev_first) / 100.0 : 0.0);
+                        prev_first = first;
+                    }
+                }
+#endif
             }
         }
     gang_check_pending = false;

@@ -135,6 +135,12 @@ struct GvGang {
     uint32_t pad[31];
     // {S1, S2, H, next row} per tile as four 16-byte granules {value, value ^ tag}, two alternating slots
     unsigned long long rec[2][kGvGangMaxTiles][8];
+#ifdef JB_GG_PROFILE
+    // measurement aid (-DJB_GG_PROFILE builds of every translation unit): the 100 MHz real-time clock of thread 0 of
+    // each of the gang's first 8 tiles at its first 96 exchanges -- [0]: its sums are ready (arrival), [1]: the
+    // exchange is over
+    unsigned long long stamp[2][8][96];
+#endif
 };
 
 struct VocDev {

@@ -9,4 +9,4 @@ V=${1:-tools/_ab_ggprof/libjbonsai_amd.so}
 cp jbonsai_amd/libjbonsai_amd.so /tmp/_keep_ggprof.so
 trap 'cp /tmp/_keep_ggprof.so jbonsai_amd/libjbonsai_amd.so' EXIT
 cp "$V" jbonsai_amd/libjbonsai_amd.so
-JB_ONE_STREAM=1 JB_GG_PROFILE_PRINT=1 python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 2>&1 | grep "ticks" | tail -1
+JB_ONE_STREAM=1 JB_GG_PROFILE_PRINT=1 python bench.py --no-cpu-baseline --no-extras --steps 2 --warmup 1 2>&1 | grep -A 300 "ticks" | head -330
