@@ -354,13 +354,50 @@ template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
     }
     allocs.emplace_back(v, got);
     bytes_alloc += n * sizeof(T);
-    if (zero) {
-        e = hipMemset(v, 0, n * sizeof(T));
-        if (e != hipSuccess)
-            return hip_fail(e, "hipMemset");
-    }
+    if (zero)
+        zero_list.emplace_back(v, std::min(got, (n * sizeof(T) + 15) / 16 * 16));
     *p = (T *)v;
     return JB_OK;
+}
+
+// up to kZeroSegs blocks of memory cleared by one launch: segment blockIdx.y, 16 bytes per thread and trip
+constexpr int kZeroSegs = 40;
+struct ZeroSegs {
+    uint4 *p[kZeroSegs];
+    unsigned long long n16[kZeroSegs]; // 16-byte units
+};
+__global__ __launch_bounds__(256) void k_zero_segments(ZeroSegs z)
+{
+    uint4 *p = z.p[blockIdx.y];
+    const unsigned long long n = z.n16[blockIdx.y];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < n;
+         i += (unsigned long long)gridDim.x * 256u)
+        p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+int Batch::flush_zero()
+{
+    if (zero_list.empty())
+        return JB_OK;
+    for (size_t i0 = 0; i0 < zero_list.size(); i0 += kZeroSegs) {
+        ZeroSegs z{};
+        const size_t cnt = std::min(zero_list.size() - i0, (size_t)kZeroSegs);
+        unsigned long long biggest = 0;
+        for (size_t i = 0; i < cnt; i++) {
+            z.p[i] = (uint4 *)zero_list[i0 + i].first; // (pool blocks are aligned far beyond 16 bytes)
+            z.n16[i] = (zero_list[i0 + i].second + 15) / 16;
+            biggest = std::max(biggest, z.n16[i]);
+        }
+        const unsigned gx = (unsigned)std::min<unsigned long long>((biggest + 255) / 256, 2048ull);
+        hipLaunchKernelGGL(k_zero_segments, dim3(std::max(gx, 1u), (unsigned)cnt), dim3(256), 0, nullptr, z);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess)
+            return hip_fail(e, "k_zero_segments");
+    }
+    zero_list.clear();
+    // (the legacy stream does not order itself with the batch's non-blocking streams: whoever uses a block right
+    // away -- the redo rounds -- needs it cleared NOW; creation waits for the legacy stream at its end anyway)
+    hipError_t e = hipStreamSynchronize(nullptr);
+    return e == hipSuccess ? JB_OK : hip_fail(e, "k_zero_segments");
 }
 
 // pinned staging chunks of the upload arenas (all of one size), reused between batches
@@ -1213,6 +1250,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     cmark("vocoder buffers allocated");
     if ((rc = b->build_work(opts)))
         return rc;
+    if ((rc = b->flush_zero())) // (legacy stream, like the uploads: in order with them)
+        return rc;
     if ((rc = b->flush_uploads()))
         return rc;
     for (auto &c : b->up_chunks)
@@ -1327,9 +1366,19 @@ int Batch::build_work(const jb_batch_opts *opts)
         // call; below 16 the extra hand-off positions and their occasional redo round cost more than
         // they save) -- but never more items than SIMDs: the kernel's four-wave workgroups are what puts
         // exactly one on each.  (64 x 2000 frames: 16.0 ms with 1344 items of 96 frames, 11.6 with 1000 of 128.)
+        // Round 5: a request of ONE or a few sentences fills a fraction of the SIMDs whatever its chunk length, and its
+        // time is that of one item = (chunk + 18 warm-up frames) x 240 samples x 0.25 us: shorter chunks down to 6-8
+        // frames, while the hand-off positions stay few enough for a redo round to be rare (same box, chunk 16 / 8 /
+        // 6 / 4 frames at 18 of warm-up, ms per run: the reference's three benchmark sentences -- 277, 420, 742 frames
+        // -- 2.38 / 1.88 / 1.75 / 1.62, 2.47 / 1.97 / 1.85 / 1.73, 3.66 / 2.68 / 2.47 / 2.54; 8 x 400 frames 2.59 /
+        // 2.68 / 2.43 / 2.20; one utterance of 2,000 frames 3.86 / 2.89 / 3.12 / 3.12: tools/small_geometry_sweep.py,
+        // profiles/r05_small_geometry_sweep.txt).  A shorter warm-up does not pay there: at 10 frames and below the
+        // failing hand-offs cost a redo round more often than the frames saved.
         const uint64_t target = sumT >= 400000 ? 2048 : 1024;
-        ch = (uint32_t)std::max<uint64_t>((sumT + target - 1) / target, 16);
-        ch = (ch + 7) / 8 * 8;
+        const uint64_t floor_w = sumT < 1024 ? 6 : sumT < 8192 ? 8 : 16;
+        ch = (uint32_t)std::max<uint64_t>((sumT + target - 1) / target, floor_w);
+        if (ch >= 16)
+            ch = (ch + 7) / 8 * 8;
     }
     chunk_frames = ch;
     if (!warmup_given && ch != 0) {
@@ -1718,7 +1767,7 @@ int Batch::finish_verify()
     if (!redo_dev && (rc = dalloc(&redo_dev, n_items, false)))
         return rc;
     if (!tmp_state && ((rc = dalloc(&tmp_state, (size_t)n_items * stride, true)) ||
-                       (rc = dalloc(&pairs_dev, 2 * (size_t)n_items, false))))
+                       (rc = dalloc(&pairs_dev, 2 * (size_t)n_items, false)) || (rc = flush_zero())))
         return rc;
     auto run_round = [&](const std::vector<VocWork> &round) -> int {
         if (round.empty())
@@ -1824,7 +1873,7 @@ int Batch::finish_verify()
             std::vector<uint32_t> mid_ids;
             for (uint32_t k : ids)
                 if (work[k].save_ckpt && work[k].save_ckpt2 && unsettled[k]) {
-                    if (!tmp2_state && (rc = dalloc(&tmp2_state, (size_t)n_items * stride, true)))
+                    if (!tmp2_state && ((rc = dalloc(&tmp2_state, (size_t)n_items * stride, true)) || (rc = flush_zero())))
                         return rc;
                     VocWork w = work[k];
                     w.t_start = w.t_out = work[k].t_out + vd.ckpt_frames;

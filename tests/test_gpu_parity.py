@@ -173,9 +173,10 @@ def test_chunked_equals_serial(oracle_voice, have_gpu):
     chk, info_c = _run(v, utts, chunk_frames=64, warmup_frames=32)
     assert info_c["chunk_frames"] == 64 and info_c["n_items"] == 7 + 5 and info_c["n_redo"] == 0
     dflt, info_d = _run(v, utts)
-    # a batch this small is a latency case: 16-frame chunks (an item per SIMD), 18-frame warm-up (14 from 1000
-    # distinct hand-off positions: tests/test_gpu_benchshapes.py runs such batches)
-    assert info_d["chunk_frames"] == 16 and info_d["warmup_frames"] == 18
+    # a batch this small (697 frames) is a latency case: 6-frame chunks (below 1,024 frames; 8 below 8,192; 16
+    # above: round 5), 18-frame warm-up (14 from 1000 distinct hand-off positions: tests/test_gpu_benchshapes.py
+    # runs such batches)
+    assert info_d["chunk_frames"] == 6 and info_d["warmup_frames"] == 18
     ref = [oracle_run(v, d2, s2)[1], oracle_run(v, d1, s1)[1]]
     for i in range(2):
         assert rel_rms(chk[i], ser[i]) <= 1e-12
