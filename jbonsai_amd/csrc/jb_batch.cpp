@@ -510,6 +510,42 @@ int Batch::upload(const void *host, size_t bytes, const void **dev)
     return JB_OK;
 }
 
+template <class T> int Batch::stage(const T *host, size_t n, T **dev)
+{
+    constexpr size_t kChunk = 8u << 20;
+    *dev = nullptr;
+    const size_t bytes = n * sizeof(T);
+    if (bytes > kChunk / 4 || bytes == 0) { // (large, or nothing: a block and a copy of its own)
+        int rc = dalloc(dev, n, false);
+        if (rc)
+            return rc;
+        if (bytes) {
+            hipError_t e = hipMemcpy(*dev, host, bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess)
+                return hip_fail(e, "hipMemcpy(H2D)");
+        }
+        return JB_OK;
+    }
+    const size_t need = (bytes + 255) / 256 * 256;
+    if (up_chunks.empty() || up_chunks.back().used + need > kChunk) {
+        UploadChunk c;
+        int rc = dalloc(&c.dev, kChunk, false);
+        if (rc)
+            return rc;
+        if (!c.host.acquire(kChunk)) {
+            set_error("host memory for the upload arena");
+            return JB_ERR_DEVICE;
+        }
+        up_chunks.push_back(std::move(c));
+    }
+    UploadChunk &c = up_chunks.back();
+    memcpy(c.host.get() + c.used, host, bytes);
+    *dev = (T *)(c.dev + c.used);
+    c.used += need;
+    bytes_input += bytes;
+    return JB_OK;
+}
+
 int Batch::flush_uploads()
 {
     for (UploadChunk &c : up_chunks) {
@@ -669,15 +705,13 @@ int Batch::gather_states(const jb_voice_desc *voice, const IndexSrc &idx, size_t
             }
     }
     gmark("outputs carved");
-    if ((rc = flush_uploads())) // the index rows the gather reads
+    GatherJob *jd;
+    if ((rc = stage(jobs.data(), jobs.size(), &jd)))
+        return rc;
+    if ((rc = flush_uploads())) // the index rows the gather reads, and its job list
         return rc;
     gmark("rows uploaded");
-    GatherJob *jd;
-    if ((rc = dalloc(&jd, jobs.size(), false)))
-        return rc;
-    hipError_t e = hipMemcpy(jd, jobs.data(), jobs.size() * sizeof(GatherJob), hipMemcpyHostToDevice);
-    if (e != hipSuccess)
-        return hip_fail(e, "hipMemcpy(gather jobs)");
+    hipError_t e;
     // grid.y is limited to 65535 jobs per launch
     for (size_t j0 = 0; j0 < jobs.size(); j0 += 65535) {
         const uint32_t nj = (uint32_t)std::min<size_t>(65535, jobs.size() - j0);
@@ -1016,20 +1050,16 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         return rc;
     cmark("uploads flushed");
     UttDev *dutt;
-    if ((rc = b->dalloc(&dutt, n, false)))
+    if ((rc = b->stage(hu.data(), n, &dutt)))
         return rc;
-    if (n)
-        hipMemcpy(dutt, hu.data(), sizeof(UttDev) * n, hipMemcpyHostToDevice);
     // launch order: longest utterance first (LPT within the GPU)
     std::vector<uint32_t> order(n);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(),
                      [&](uint32_t a, uint32_t c) { return b->T[a] > b->T[c]; });
     uint32_t *dord;
-    if ((rc = b->dalloc(&dord, n, false)))
+    if ((rc = b->stage(order.data(), n, &dord)))
         return rc;
-    if (n)
-        hipMemcpy(dord, order.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice);
     b->bd.B = B;
     b->bd.utt = dutt;
     b->bd.order = dord;
@@ -1111,10 +1141,8 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                     std::vector<GvBinEntry> bins;
                     gv_gang_bins(Tb.data(), has_gv.data(), order.data(), n, tiles, bins);
                     GvBinEntry *dbins;
-                    if ((rc = b->dalloc(&dbins, bins.size(), false)))
+                    if ((rc = b->stage(bins.data(), bins.size(), &dbins)))
                         return rc;
-                    if ((e = hipMemcpy(dbins, bins.data(), sizeof(GvBinEntry) * bins.size(), hipMemcpyHostToDevice)) != hipSuccess)
-                        return hip_fail(e, "hipMemcpy(gv bins)");
                     sd.gv_bins = dbins;
                     sd.gv_nbins = (uint32_t)(bins.size() / (size_t)tiles);
                     if ((uint32_t)gangs > sd.gv_nbins * (uint32_t)sd.L)
@@ -1437,7 +1465,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         });
     n_items = (uint32_t)work.size();
     int rc;
-    if ((rc = dalloc(&work_dev, n_items, false)) || (rc = dalloc(&bad_dev, n_items, true)) ||
+    if ((rc = dalloc(&bad_dev, n_items, true)) ||
         (rc = dalloc(&nbad_dev, 1, true)))
         return rc;
     if (ch != 0) {
@@ -1467,8 +1495,8 @@ int Batch::build_work(const jb_batch_opts *opts)
                                ? ckpt2_state + (size_t)k * stride : nullptr;
         }
     }
-    if (n_items)
-        hipMemcpy(work_dev, work.data(), sizeof(VocWork) * n_items, hipMemcpyHostToDevice);
+    if ((rc = stage(work.data(), n_items, &work_dev))) // (with the arena's next flush: create() ends with one)
+        return rc;
     if (lp_mode) {
         // launch permutation: equal-length chunks share a wave (lanes run in lock step)
         std::vector<uint32_t> ord(n_items);
@@ -1476,10 +1504,8 @@ int Batch::build_work(const jb_batch_opts *opts)
         std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) {
             return (work[x].t_end - work[x].t_start) > (work[y].t_end - work[y].t_start);
         });
-        if ((rc = dalloc(&order_dev, n_items, false)))
+        if ((rc = stage(ord.data(), n_items, &order_dev)))
             return rc;
-        if (n_items)
-            hipMemcpy(order_dev, ord.data(), sizeof(uint32_t) * n_items, hipMemcpyHostToDevice);
     }
     return JB_OK;
 }

@@ -134,6 +134,10 @@ struct Batch {
     std::vector<std::pair<void *, size_t>> zero_list;
     int flush_zero();
     int upload(const void *host, size_t bytes, const void **dev);
+    // the same arena without the de-duplication: for descriptor arrays put together in temporaries of create() (a
+    // synchronous hipMemcpy of its own each -- nine of them -- was 0.2 ms of a one-sentence request); the bytes reach
+    // the device with the next flush_uploads()
+    template <class T> int stage(const T *host, size_t n, T **dev);
     bool from_tracks = false;        // created from parameter tracks: run() starts at the frame prologue
     bool gang_check_pending = false; // a resident GV kernel has been enqueued since its error flag was last read
     // the resident GV kernel of the pending run gave up in formation (flag read, not cleared: sync() acts on it);
