@@ -2200,6 +2200,19 @@ int Batch::read_pcm_split(void *const *dst, size_t elem)
     for (int u = 0; u <= B; u++)
         uoff[u] = (size_t)frame_off[u] * voice.fperiod * elem;
     const size_t nchunks = (total + kStageSlot - 1) / kStageSlot;
+    if (nchunks == 1) {
+        // a small request (one sentence: 0.5 MB): one copy into the first slot and the scatter on the calling
+        // thread -- no worker threads to start and join (0.1 ms of a 2 ms call)
+        e = hipMemcpyAsync(ring->slot[0], slab, total, hipMemcpyDeviceToHost, ring->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ring->stream);
+        if (e != hipSuccess)
+            return hip_fail(e, "staged D2H");
+        for (int u = 0; u < B; u++)
+            if (uoff[(size_t)u + 1] > uoff[(size_t)u] && dst[u])
+                memcpy(dst[u], (const char *)ring->slot[0] + uoff[(size_t)u], uoff[(size_t)u + 1] - uoff[(size_t)u]);
+        return JB_OK;
+    }
     enum { FREE = 0, ISSUED = 1 };
     std::atomic<int> state[kStageSlots];
     for (auto &st : state)
