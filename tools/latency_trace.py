@@ -8,6 +8,10 @@ import jbonsai_amd as J  # noqa: E402
 from tests.conftest import VOICE  # noqa: E402
 from tests.golden.labels import SAMPLE_SENTENCE_1  # noqa: E402
 
+from tests.golden.labels import SAMPLE_SENTENCE_2  # noqa: E402
+
 eng = J.Engine.load([VOICE])
+reps = int(os.environ.get("JB_TRACE_REPS", "0"))  # 0: the 8-label sentence; n: n x the 20-label sentence (2.1 s each)
+lab = list(SAMPLE_SENTENCE_2) * reps if reps else SAMPLE_SENTENCE_1
 for _ in range(5):
-    eng.synthesize(SAMPLE_SENTENCE_1)
+    eng.synthesize(lab)
