@@ -407,10 +407,22 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
 {
     const Condition &c = e.cond;
     const Voice &v0 = *e.voices[0];
+    // JB_FRONT_TRACE=1: phases of the front half of one utterance on stderr (like JB_CREATE_TRACE / JB_REDO_TRACE)
+    static const bool trace = getenv("JB_FRONT_TRACE") && atoi(getenv("JB_FRONT_TRACE")) != 0;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto fmark = [&](const char *what) {
+        if (!trace)
+            return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "front half: %-28s %8.3f ms (%zu labels, %u threads)\n", what,
+                std::chrono::duration<double, std::milli>(t - t_prev).count(), n, label_threads);
+        t_prev = t;
+    };
     ParsedLabels pl;
     int rc = parse_labels(c, lines, n, pl);
     if (rc)
         return rc;
+    fmark("labels parsed");
     const size_t nl = pl.labels.size(), ns = (size_t)v0.meta.num_states, S = nl * ns;
     st.dur.assign(S, 0);
     try {
@@ -427,6 +439,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                     dp[i * ns + s] = {tmp[s], tmp[s + ns]};
             }
         });
+        fmark("duration pdfs");
         if (S) {
             if (c.phoneme_alignment) {
                 // create_with_alignment (duration.rs:41-65)
@@ -456,6 +469,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                 }
             }
         }
+        fmark("durations");
         st.utt.num_states = (uint32_t)S;
         st.utt.durations = st.dur.data();
         // Models::stream / gv (model/mod.rs:98-146)
@@ -510,6 +524,7 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                     }
                 });
             }
+            fmark("stream pdfs");
             jb_stream_states &o = st.utt.stream[si];
             o.mean = st.mean[si].data();
             o.var = st.var[si].data();
