@@ -426,10 +426,28 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
     const size_t nl = pl.labels.size(), ns = (size_t)v0.meta.num_states, S = nl * ns;
     st.dur.assign(S, 0);
     try {
-        // Models::duration (model/mod.rs:80-92)
+        // Models::duration (model/mod.rs:80-92) and Models::stream (:98-118) of every label in ONE parallel pass
+        // (round 5: four passes, each starting and joining its own threads, were most of the front half of a
+        // 200-label text -- 1.2 ms, of which the tree searches are 0.2 on six threads)
         std::vector<MV> dp(S);
+        const size_t nsx = std::min(v0.streams.size(), (size_t)kMaxStream);
+        size_t plen_max = 0;
+        for (size_t si = 0; si < nsx; si++) {
+            const StreamModel &sm = v0.streams[si];
+            const size_t WL = (size_t)sm.vector_length * (size_t)sm.num_windows;
+            plen_max = std::max(plen_max, 2 * WL + (sm.is_msd ? 1 : 0));
+            if (indexed) {
+                for (size_t v = 0; v < e.voices.size(); v++)
+                    st.rows[si][v].assign(S, 0);
+                st.weights[si] = c.w_param[si];
+            } else {
+                st.mean[si].assign(S * WL, 0.0);
+                st.var[si].assign(S * WL, 0.0);
+                st.msd[si].assign(S, DBL_MAX);
+            }
+        }
         parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
-            std::vector<double> tmp(2 * ns);
+            std::vector<double> tmp(2 * ns), buf(plen_max);
             QuestionMemo memo; // question results of the current label, per model
             for (size_t i = lo; i < hi; i++) {
                 memo.reset();
@@ -437,9 +455,35 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
                       [&](const Voice &v) { return v.duration.get_parameter(2, pl.labels[i], &memo); });
                 for (size_t s = 0; s < ns; s++)
                     dp[i * ns + s] = {tmp[s], tmp[s + ns]};
+                for (size_t si = 0; si < nsx; si++) {
+                    const StreamModel &sm = v0.streams[si];
+                    const size_t WL = (size_t)sm.vector_length * (size_t)sm.num_windows;
+                    const size_t plen = 2 * WL + (sm.is_msd ? 1 : 0);
+                    for (size_t s = 0; s < ns; s++) {
+                        const size_t row = i * ns + s;
+                        if (indexed) {
+                            for (size_t v = 0; v < e.voices.size(); v++) {
+                                const Model &m = e.voices[v]->streams[si].stream;
+                                int tp, pi;
+                                m.get_index((int)(2 + s), pl.labels[i], tp, pi, &memo);
+                                if (tp < 0 || pi < 1 || pi > m.npdf[(size_t)tp])
+                                    throw ModelError("index not found"); // reference: todo!() (voice/model.rs:76-79)
+                                st.rows[si][v][row] = e.cat[v * nsx + si].tree_off[(size_t)tp] + (uint32_t)(pi - 1);
+                            }
+                        } else {
+                            blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
+                                return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i], &memo);
+                            });
+                            std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
+                            std::copy(buf.begin() + WL, buf.begin() + 2 * WL, st.var[si].begin() + row * WL);
+                            if (sm.is_msd)
+                                st.msd[si][row] = buf[2 * WL];
+                        }
+                    }
+                }
             }
         });
-        fmark("duration pdfs");
+        fmark("pdfs of all models");
         if (S) {
             if (c.phoneme_alignment) {
                 // create_with_alignment (duration.rs:41-65)
@@ -475,56 +519,12 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
         // Models::stream / gv (model/mod.rs:98-146)
         for (size_t si = 0; si < v0.streams.size() && si < (size_t)kMaxStream; si++) {
             const StreamModel &sm = v0.streams[si];
-            const size_t WL = (size_t)sm.vector_length * (size_t)sm.num_windows;
-            const size_t plen = 2 * WL + (sm.is_msd ? 1 : 0);
             if (indexed) {
-                const size_t nsx = std::min(v0.streams.size(), (size_t)kMaxStream);
-                for (size_t v = 0; v < e.voices.size(); v++)
-                    st.rows[si][v].assign(S, 0);
-                st.weights[si] = c.w_param[si];
-                parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
-                    QuestionMemo memo;
-                    for (size_t i = lo; i < hi; i++) {
-                        memo.reset();
-                        for (size_t s = 0; s < ns; s++)
-                            for (size_t v = 0; v < e.voices.size(); v++) {
-                                const Model &m = e.voices[v]->streams[si].stream;
-                                int tp, pi;
-                                m.get_index((int)(2 + s), pl.labels[i], tp, pi, &memo);
-                                if (tp < 0 || pi < 1 || pi > m.npdf[(size_t)tp])
-                                    throw ModelError("index not found"); // reference: todo!() (voice/model.rs:76-79)
-                                st.rows[si][v][i * ns + s] =
-                                    e.cat[v * nsx + si].tree_off[(size_t)tp] + (uint32_t)(pi - 1);
-                            }
-                    }
-                });
                 jb_index_stream &io = st.iutt.stream[si];
                 for (size_t v = 0; v < e.voices.size(); v++)
                     io.row[v] = st.rows[si][v].data();
                 io.weight = st.weights[si].data();
-            } else {
-                st.mean[si].assign(S * WL, 0.0);
-                st.var[si].assign(S * WL, 0.0);
-                st.msd[si].assign(S, DBL_MAX);
-                parallel_labels(nl, label_threads, [&](size_t lo, size_t hi) {
-                    std::vector<double> buf(plen);
-                    QuestionMemo memo;
-                    for (size_t i = lo; i < hi; i++) {
-                        memo.reset();
-                        for (size_t s = 0; s < ns; s++) {
-                            blend(e, c.w_param[si], plen, buf.data(), [&](const Voice &v) {
-                                return v.streams[si].stream.get_parameter((int)(2 + s), pl.labels[i], &memo);
-                            });
-                            const size_t row = i * ns + s;
-                            std::copy(buf.begin(), buf.begin() + WL, st.mean[si].begin() + row * WL);
-                            std::copy(buf.begin() + WL, buf.begin() + 2 * WL, st.var[si].begin() + row * WL);
-                            if (sm.is_msd)
-                                st.msd[si][row] = buf[2 * WL];
-                        }
-                    }
-                });
             }
-            fmark("stream pdfs");
             jb_stream_states &o = st.utt.stream[si];
             o.mean = st.mean[si].data();
             o.var = st.var[si].data();
