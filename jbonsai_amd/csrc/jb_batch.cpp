@@ -360,8 +360,9 @@ template <class T> int Batch::dalloc(T **p, size_t n, bool zero)
     return JB_OK;
 }
 
-// up to kZeroSegs blocks of memory cleared by one launch: segment blockIdx.y, 16 bytes per thread and trip
-constexpr int kZeroSegs = 40;
+// up to kZeroSegs blocks of memory cleared by one launch: segment blockIdx.y, 16 bytes per thread and trip.
+// (24: an ordinary batch has 25-30 such blocks, so that the second launch of the loop below is what every test runs)
+constexpr int kZeroSegs = 24;
 struct ZeroSegs {
     uint4 *p[kZeroSegs];
     unsigned long long n16[kZeroSegs]; // 16-byte units
@@ -2200,17 +2201,29 @@ int Batch::read_pcm_split(void *const *dst, size_t elem)
     for (int u = 0; u <= B; u++)
         uoff[u] = (size_t)frame_off[u] * voice.fperiod * elem;
     const size_t nchunks = (total + kStageSlot - 1) / kStageSlot;
-    if (nchunks == 1) {
-        // a small request (one sentence: 0.5 MB): one copy into the first slot and the scatter on the calling
-        // thread -- no worker threads to start and join (0.1 ms of a 2 ms call)
-        e = hipMemcpyAsync(ring->slot[0], slab, total, hipMemcpyDeviceToHost, ring->stream);
-        if (e == hipSuccess)
-            e = hipStreamSynchronize(ring->stream);
-        if (e != hipSuccess)
+    if (nchunks <= 4 && nchunks <= (size_t)kStageSlots) {
+        // a small request (one sentence: 0.5 MB; a 21 s text: 8 MB): its few copies issued at once and scattered on
+        // the calling thread as they land -- no worker threads to start and join (0.1-0.2 ms of such a call)
+        for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
+            const size_t lo = c * kStageSlot, n = std::min(total, lo + kStageSlot) - lo;
+            e = hipMemcpyAsync(ring->slot[c], slab + lo, n, hipMemcpyDeviceToHost, ring->stream);
+            if (e == hipSuccess)
+                e = hipEventRecord(ring->ev[c], ring->stream);
+        }
+        for (size_t c = 0; c < nchunks && e == hipSuccess; c++) {
+            e = hipEventSynchronize(ring->ev[c]);
+            const size_t lo = c * kStageSlot, hi = std::min(total, lo + kStageSlot);
+            size_t u = (size_t)(std::upper_bound(uoff.begin(), uoff.end(), lo) - uoff.begin()) - 1;
+            for (; e == hipSuccess && u < (size_t)B && uoff[u] < hi; u++) {
+                const size_t a = std::max(lo, uoff[u]), b2 = std::min(hi, uoff[u + 1]);
+                if (b2 > a && dst[u])
+                    memcpy((char *)dst[u] + (a - uoff[u]), (const char *)ring->slot[c] + (a - lo), b2 - a);
+            }
+        }
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(ring->stream); // (nothing of this call stays in flight into the ring)
             return hip_fail(e, "staged D2H");
-        for (int u = 0; u < B; u++)
-            if (uoff[(size_t)u + 1] > uoff[(size_t)u] && dst[u])
-                memcpy(dst[u], (const char *)ring->slot[0] + uoff[(size_t)u], uoff[(size_t)u + 1] - uoff[(size_t)u]);
+        }
         return JB_OK;
     }
     enum { FREE = 0, ISSUED = 1 };
