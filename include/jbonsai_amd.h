@@ -39,7 +39,9 @@ extern "C" {
 typedef enum jb_status {
     JB_OK = 0,
     JB_ERR_INVALID = -1,     /* bad argument / shape (reference: panics in src/speech.rs:32-40) */
-    JB_ERR_UNSUPPORTED = -2, /* stages above 8, nlpf > 63, frame periods without a block divisor: off every BASELINE config */
+    JB_ERR_UNSUPPORTED = -2, /* shapes no kernel is built for: nmcp > 61, window widths above 5, stages above 256, nlpf > 2047, other
+                                than three streams (frame periods, stages and low-pass orders are otherwise free: rounds 1-4 refused
+                                stages above 8, nlpf > 63 and frame periods without a divisor <= 64 that is >= nlpf - 1) */
     JB_ERR_DEVICE = -3,      /* HIP error or no gfx950 device: the product never falls back to CPU */
     JB_ERR_MODEL = -4,       /* ModelError (src/model/mod.rs:31-46) */
     JB_ERR_LABEL = -5,       /* LabelError (src/label.rs:8-23) */
@@ -68,7 +70,7 @@ typedef struct jb_voice_desc {
     uint32_t sampling_frequency;  /* rate */
     uint32_t fperiod;
     uint32_t nstream;             /* 3: MCP, LF0, LPF (src/engine.rs:303-313 needs stream 2) */
-    uint32_t stage;               /* 0: MLSA (mel-cepstra); 1..8: Stage::NonZero, gamma = -1/stage, spectrum = [gain, LSP...],
+    uint32_t stage;               /* 0: MLSA (mel-cepstra); 1..256: Stage::NonZero, gamma = -1/stage, spectrum = [gain, LSP...],
                                      MGLSA filter (vocoder/mod.rs:90-107,142-176; parity unpinned: no reference test reaches it) */
     uint32_t use_log_gain;        /* ignored when stage==0 */
     double alpha, beta, volume;   /* beta > 0: post-filter per frame (stage 0: cepstrum.rs:23-37; stage > 0: lsp.rs:113-139) */

@@ -730,8 +730,9 @@ static int check_voice(const jb_voice_desc *v, bool need_windows = true, bool vo
 {
     if (!v)
         return JB_ERR_INVALID;
-    if (v->stage > 8) {
-        set_error("Stage::NonZero: stages above 8 are not supported");
+    if (v->stage > (uint32_t)mglsa_max_stage()) {
+        // (the delay lines of a chunk's stages share one CU's LDS: 64 taps x 8 B x stage)
+        set_error("Stage::NonZero: stages above " + std::to_string(mglsa_max_stage()) + " are not supported");
         return JB_ERR_UNSUPPORTED;
     }
     if (!(v->beta >= 0.0)) {
@@ -755,16 +756,14 @@ static int check_voice(const jb_voice_desc *v, bool need_windows = true, bool vo
     // SpeechGenerator::new panics on an even LPF length, 0 included (speech.rs:38-40): the ring-buffer-less
     // branch of Excitation::get (excitation.rs:87-100) can be reached through Vocoder::synthesize alone,
     // never through Engine / SpeechGenerator, which is the boundary this library mirrors
-    if (p.vector_length % 2 == 0 && !(vocoder_level && p.vector_length == 0)) {
-        if (vocoder_level) { // Vocoder::new takes any nlpf; the kernels here are built for odd counts and for none
-            set_error("an even, non-zero number of low-pass filter coefficients is not supported");
-            return JB_ERR_UNSUPPORTED;
-        }
+    // (Vocoder::new takes any nlpf: an even count has its noise tap at (nlpf - 1) / 2 like an odd one, excitation.rs:137-140)
+    if (p.vector_length % 2 == 0 && !vocoder_level) {
         set_error("The number of low-pass filter coefficient must be odd numbers."); // speech.rs:38-40
         return JB_ERR_INVALID;
     }
-    if (p.vector_length > 63) {
-        set_error("nlpf > 63 is not supported");
+    if (p.vector_length > (uint32_t)excite_max_nlpf()) {
+        // (k_excite_any keeps a block's 256 + nlpf - 1 source samples in LDS)
+        set_error("nlpf > " + std::to_string(excite_max_nlpf()) + " is not supported");
         return JB_ERR_UNSUPPORTED;
     }
     if (m.vector_length < 2 || m.vector_length - 1 > (uint32_t)(kGroups * kMaxTPL)) {
@@ -833,7 +832,7 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
                 set_error("The size of lf0 static vector must be 1."); // speech.rs:35-37
                 return JB_ERR_INVALID;
             }
-            if (t.n_lpf && t.lpf_width % 2 == 0 && !(trk->vocoder_level && t.lpf_width == 0)) {
+            if (t.n_lpf && t.lpf_width % 2 == 0 && !trk->vocoder_level) {
                 set_error("The number of low-pass filter coefficient must be odd numbers."); // speech.rs:38-40
                 return JB_ERR_INVALID;
             }
@@ -1175,15 +1174,20 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
     vd.fperiod = (int)voice->fperiod;
     vd.nmcp = (int)voice->stream[0].vector_length;
     vd.nlpf = (int)voice->stream[2].vector_length;
+    // A frame's samples in blocks of bs <= 64 (one pulse-mask word and one wave pass of lane = sample per block).
+    // The largest divisor of the frame period that is <= 64 where there is a useful one (every BASELINE shape: 240 ->
+    // 4 x 60; the split excitation kernels and the lane-triple vocoder are built on equal blocks); otherwise -- a
+    // prime frame period, 75 = 3 x 25 under a 31-tap filter -- blocks of ceil(fperiod / nblk) samples with a shorter
+    // LAST block (block q = samples [q bs, min(fperiod, (q + 1) bs)): sample i is bit i % bs of word i / bs either way).
     int bs = std::min(64, vd.fperiod);
     while (vd.fperiod % bs)
         bs--;
-    if (bs < vd.nlpf - 1) {
-        set_error("fperiod has no block divisor >= nlpf-1 (unsupported frame period)");
-        return JB_ERR_UNSUPPORTED;
+    if ((bs < vd.nlpf - 1 || bs < 16) && bs < std::min(64, vd.fperiod)) {
+        const int nblk = (vd.fperiod + 63) / 64;
+        bs = (vd.fperiod + nblk - 1) / nblk;
     }
     vd.bs = bs;
-    vd.nblk = vd.fperiod / bs;
+    vd.nblk = (vd.fperiod + bs - 1) / bs;
     vd.alpha = voice->alpha;
     vd.volume = voice->volume;
     // postfilter_mcp acts only for beta > 0 and more than two coefficients (cepstrum.rs:24)
@@ -1221,10 +1225,6 @@ int Batch::create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n
         rc = b->dalloc(&vd.pcm, mlpg_only ? 1 : b->total_samples, false);
     if (rc)
         return rc;
-    if (vd.nlpf - 1 > 64) {
-        set_error("nlpf > 65 is not supported");
-        return JB_ERR_UNSUPPORTED;
-    }
     if ((b->flags & JB_BATCH_KEEP_TRACKS) && !mlpg_only)
         if ((rc = b->dalloc(&vd.exc, b->total_samples, false)))
             return rc;

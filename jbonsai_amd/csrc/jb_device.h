@@ -365,6 +365,8 @@ hipError_t launch_stage_coef(const BatchDev &bd, const VocDev &vd, hipStream_t s
 hipError_t launch_vocoder_mglsa(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                                 hipStream_t stream);
 int mglsa_state_doubles(int stage);
+int excite_max_nlpf(); // low-pass taps the excitation kernels take (jb_vocoder.hip)
+int mglsa_max_stage(); // Stage::NonZero: 1..8 with the delay lines in registers, up to this many with them in LDS
 // bad[j] = 1 (and ++*n_bad) when states pairs[2j] and pairs[2j+1] differ by more than tol * max|state|
 hipError_t launch_voc_verify_pairs(const double *const *pairs_dev, uint32_t n_pairs, int state_doubles, int ntaps,
                                    double tol, uint8_t *bad, uint32_t *n_bad, hipStream_t stream);

@@ -18,6 +18,8 @@
 // product with c[i+1] is a DPP sum; the stages are sequential (each subtracts its y from x).
 #include "jb_device.h"
 
+#include <algorithm>
+
 namespace jb {
 
 constexpr int kSgMaxN = 64; // nmcp <= 64 (check_voice: <= 61)
@@ -252,11 +254,17 @@ __device__ __forceinline__ double sg_readlane(double v, int lane)
 // state layout (doubles): d[stage][64], lane = tap
 int mglsa_state_doubles(int stage) { return 64 * stage; }
 
+// STAGE = 1..8: the delay lines of the stages in registers, four waves (items) per workgroup.  STAGE = 0: any number
+// of stages (Stage::NonZero is generic in it, stage.rs:24-39), the delay lines in the wave's rows of dynamic LDS
+// ([stage][64] doubles per wave, lane = tap: no lane reads another's row), `wpb` waves per workgroup.
+constexpr int kSgRegStages = 8;
+constexpr int kSgMaxStage = 256; // one wave per workgroup: 256 x 512 B = 128 KB of a CU's 160 KB
 template <int STAGE>
 __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, const VocWork *__restrict__ work,
-                                                       uint32_t n_items)
+                                                       uint32_t n_items, uint32_t wpb)
 {
-    const uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6);
+    extern __shared__ double sg_lds[];
+    const uint32_t item = blockIdx.x * wpb + (threadIdx.x >> 6);
     if (item >= n_items)
         return;
     const VocWork wk = work[item];
@@ -290,19 +298,18 @@ __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, c
     const bool upd = lane >= 1 && lane <= n - 2; // taps the in-place update touches
     const bool dot = lane <= n - 2;              // taps of the dot product (with c[lane + 1])
 
-    double d[STAGE];
-#pragma unroll
-    for (int s = 0; s < STAGE; s++)
-        d[s] = 0.0;
-    if (wk.load_state) {
-#pragma unroll
-        for (int s = 0; s < STAGE; s++)
-            d[s] = wk.load_state[64 * s + lane];
-    }
+    const int nstage = STAGE ? STAGE : vd.stage;
+    constexpr int kUn = STAGE ? STAGE : 1; // (a run-time stage count: the stage loops stay loops)
+    double dreg[STAGE ? STAGE : 1];
+    double *const dl = sg_lds + (size_t)(threadIdx.x >> 6) * 64 * (size_t)(STAGE ? 0 : nstage) + lane;
+#define SG_D(s) (*(STAGE ? &dreg[STAGE ? (s) : 0] : &dl[64 * (s)]))
+#pragma unroll kUn
+    for (int s = 0; s < nstage; s++)
+        SG_D(s) = wk.load_state ? wk.load_state[64 * s + lane] : 0.0;
     auto save_state = [&](double *sp) {
-#pragma unroll
-        for (int s = 0; s < STAGE; s++)
-            sp[64 * s + lane] = d[s];
+#pragma unroll kUn
+        for (int s = 0; s < nstage; s++)
+            sp[64 * s + lane] = SG_D(s);
     };
 
     for (uint32_t t = t_begin; t < t_end; t++) {
@@ -324,15 +331,17 @@ __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, c
         const double c0t = bcur[0], c0inc = (c0t - c0) / (double)fp;
         for (int q = 0; q < nblk; q++) {
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)(q * bs);
-            const double xin = lane < bs ? exc_block_ptr(vd, base, t, exc_code(vd, base, t), q)[q * bs + lane] : 0.0;
+            const int blen = min(bs, fp - q * bs); // (a shorter last block where bs does not divide the frame period)
+            const double xin = lane < blen ? exc_block_ptr(vd, base, t, exc_code(vd, base, t), q)[q * bs + lane] : 0.0;
             double ob = 0.0;
-            for (int i = 0; i < bs; i++) {
+            for (int i = 0; i < blen; i++) {
                 double x = sg_readlane(xin, i) * c0; // x *= coefficients[0] (mod.rs:164)
-#pragma unroll
-                for (int s = 0; s < STAGE; s++) {
+#pragma unroll kUn
+                for (int s = 0; s < nstage; s++) {
                     // dff (mglsa.rs:23-41)
-                    const double dn1 = sg_dpp<0x130>(d[s]); // d[i + 1] (wave_shl:1)
-                    double e = upd ? fma(a, dn1, d[s]) : (lane == 0 ? d[s] : 0.0);
+                    const double ds = SG_D(s);
+                    const double dn1 = sg_dpp<0x130>(ds); // d[i + 1] (wave_shl:1)
+                    double e = upd ? fma(a, dn1, ds) : (lane == 0 ? ds : 0.0);
                     // d'[i] = e[i] - a d'[i - 1]: weighted inclusive scan
                     e = fma(c1, sg_dpp<0x111>(e), e);
                     e = fma(c2, sg_dpp<0x112>(e), e);
@@ -340,7 +349,7 @@ __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, c
                     e = fma(c8, sg_dpp<0x118>(e), e);
                     e = fma(cb15, sg_dpp<0x142>(e), e);
                     e = fma(cb31, sg_dpp<0x143>(e), e);
-                    const double dnew = upd ? e : d[s]; // taps 0 and n - 1 (and idle lanes) keep their value
+                    const double dnew = upd ? e : ds; // taps 0 and n - 1 (and idle lanes) keep their value
                     double y = dot ? dnew * ck : 0.0;
                     y += sg_dpp<0x111>(y);
                     y += sg_dpp<0x112>(y);
@@ -351,13 +360,13 @@ __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, c
                     x -= sg_readlane(y, 63);
                     // shift by one tap, new head (mglsa.rs:36-40)
                     const double dm1 = sg_dpp<0x138>(dnew); // d[i - 1] (wave_shr:1)
-                    d[s] = lane == 0 ? fma(a, dnew, aa * x) : (lane <= n - 1 ? dm1 : 0.0);
+                    SG_D(s) = lane == 0 ? fma(a, dnew, aa * x) : (lane <= n - 1 ? dm1 : 0.0);
                 }
                 ck += ckinc;
                 c0 += c0inc;
                 ob = (lane == i) ? x * vol : ob;
             }
-            if (lane < bs && emit) {
+            if (lane < blen && emit) {
                 if (vd.pcm16) {
                     double v = fmin(ob, 32767.0);
                     v = fmax(v, -32768.0);
@@ -370,7 +379,10 @@ __global__ __launch_bounds__(256) void k_vocoder_mglsa(BatchDev bd, VocDev vd, c
     }
     if (wk.save_end)
         save_state(wk.save_end);
+#undef SG_D
 }
+
+int mglsa_max_stage() { return kSgMaxStage; }
 
 hipError_t launch_vocoder_mglsa(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev, uint32_t n_items,
                                 hipStream_t stream)
@@ -378,10 +390,26 @@ hipError_t launch_vocoder_mglsa(const BatchDev &bd, const VocDev &vd, const VocW
     if (n_items == 0)
         return hipSuccess;
     dim3 grid((n_items + 3) / 4), block(256);
+    if (vd.stage > kSgRegStages) {
+        if (vd.stage > kSgMaxStage)
+            return hipErrorInvalidValue;
+        // as many waves per workgroup as 128 KB of delay lines hold (stage 9..64: four)
+        const size_t per_wave = (size_t)vd.stage * 64 * sizeof(double);
+        uint32_t wpb = (uint32_t)std::min<size_t>(4, (128u << 10) / per_wave);
+        if (wpb == 3)
+            wpb = 2;
+        static const hipError_t attr = hipFuncSetAttribute((const void *)k_vocoder_mglsa<0>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+        if (attr != hipSuccess)
+            return attr;
+        hipLaunchKernelGGL(k_vocoder_mglsa<0>, dim3((n_items + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, stream, bd,
+                           vd, work_dev, n_items, wpb);
+        return hipGetLastError();
+    }
     switch (vd.stage) {
 #define JB_SG_CASE(S)                                                                                              \
     case S:                                                                                                        \
-        hipLaunchKernelGGL(k_vocoder_mglsa<S>, grid, block, 0, stream, bd, vd, work_dev, n_items);                 \
+        hipLaunchKernelGGL(k_vocoder_mglsa<S>, grid, block, 0, stream, bd, vd, work_dev, n_items, 4u);             \
         break;
         JB_SG_CASE(1)
         JB_SG_CASE(2)

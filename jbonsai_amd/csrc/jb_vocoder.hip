@@ -321,7 +321,8 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
             // than four mask words: the closed form above keeps a frame's words in registers); the pulse bits
             // are gathered in two 32-bit halves
             uint32_t mlo = 0, mhi = 0;
-            const int b32 = bs < 32 ? bs : 32;
+            const int blen = min(bs, fp - q * bs); // (the last block of a frame period that bs does not divide is shorter)
+            const int b32 = blen < 32 ? blen : 32;
 #pragma unroll 4
             for (int j = 0; j < b32; j++) {
                 counter += 1.0;
@@ -331,7 +332,7 @@ __device__ __forceinline__ void pulse_run(const BatchDev &bd, const VocDev &vd, 
                 cur += inc;
             }
 #pragma unroll 4
-            for (int j = 32; j < bs; j++) {
+            for (int j = 32; j < blen; j++) {
                 counter += 1.0;
                 const bool fire = counter >= cur;
                 counter = fire ? counter - cur : counter;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     const int anti = (nlpf - 1) / 2;
     __shared__ double e[kExcBlock + kExcHalo];
     // taps of every frame the block and its history touch: (256 + 64) / fperiod + 2 frames; the
-    // smallest supported frame period is nlpf-1 >= 30 (block divisor rule), hence 13 rows
+    // launch_excite sends frame periods below 30 samples to k_excite_any, hence 13 rows
     __shared__ double taps[kExcMaxFrames][64];
     __shared__ int anyv;
     // frames touched by samples [n0 - halo, n0 + 255]
@@ -496,6 +497,81 @@ __global__ __launch_bounds__(kExcBlock) void k_excite(BatchDev bd, VocDev vd)
     if (vd.exc)
         vd.exc[base * (uint64_t)fp + n] = x;
     vd.xin[base * (uint64_t)fp + n] = x;
+}
+
+// The same sum for every shape k_excite's staging is not laid out for: more than 64 taps (its tap rows and its
+// 64-sample history), a frame period below 30 samples (more than 13 frames under a block and its history) or below
+// nlpf - 1 (a sample's window then reaches back over several frames).  The reference is generic in all three
+// (Vocoder::new, vocoder/mod.rs:45-70; RingBuffer::new(nlpf), excitation.rs:113-123).  e[] of the block and its
+// nlpf - 1 samples of history in dynamic LDS; the tap of source sample n - k is read where the LPF track has it
+// (row of that sample's frame, L1 / L2 hits: a wave's lanes are consecutive samples), the frame of the source
+// sample stepped back beside k.  Same order of additions as k_excite.
+constexpr int kExcAnyMaxNlpf = 2047; // (256 + 2046) doubles of LDS per workgroup
+__global__ __launch_bounds__(kExcBlock) void k_excite_any(BatchDev bd, VocDev vd)
+{
+    extern __shared__ double e_any[];
+    const int b = blockIdx.y;
+    const UttDev *u = bd.utt + b;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk, nlpf = vd.nlpf;
+    const uint64_t N = (uint64_t)u->T * (uint64_t)fp;
+    const uint64_t n0 = (uint64_t)blockIdx.x * kExcBlock;
+    if (n0 >= N)
+        return;
+    const uint64_t base = u->frame_off;
+    const int tid = threadIdx.x;
+    const int anti = (nlpf - 1) / 2, halo = nlpf - 1;
+    __shared__ int anyv;
+    if (tid == 0)
+        anyv = 0;
+    __syncthreads();
+    for (int j = tid; j < kExcBlock + halo; j += kExcBlock) {
+        const long m = (long)n0 - halo + j;
+        double ev = 0.0;
+        if (m >= 0 && (uint64_t)m < N) {
+            const uint32_t fr = (uint32_t)((uint64_t)m / (uint64_t)fp);
+            const int i = (int)((uint64_t)m - (uint64_t)fr * (uint64_t)fp);
+            const uint64_t f = base + fr;
+            if (vd.pitch[f] != 0.0) {
+                const unsigned long long pm = vd.pmask[f * (uint64_t)nblk + (uint64_t)(i / bs)];
+                double pulse = 0.0;
+                if ((pm >> (i % bs)) & 1ull)
+                    pulse = sqrt(fma((double)i, vd.pinc[f], vd.cur_start[f]));
+                ev = pulse - vd.noise[m];
+                anyv = 1;
+            }
+        }
+        e_any[j] = ev;
+    }
+    __syncthreads();
+    const uint64_t n = n0 + (uint64_t)tid;
+    if (n >= N)
+        return;
+    double x = n >= (uint64_t)anti ? vd.noise[n - (uint64_t)anti] : 0.0;
+    if (anyv) {
+        uint32_t fr = (uint32_t)(n / (uint64_t)fp);
+        int i = (int)(n - (uint64_t)fr * (uint64_t)fp);
+        const int kmax = n + 1 < (uint64_t)nlpf ? (int)n + 1 : nlpf;
+        const double *ep = e_any + halo + tid;
+        const double *tap = vd.lpf + (base + fr) * (uint64_t)nlpf; // taps of the SOURCE sample's frame (excitation.rs:48-64)
+        for (int k = 0; k < kmax; k++) {
+            x = fma(ep[-k], tap[k], x);
+            if (i == 0) {
+                i = fp - 1;
+                tap -= nlpf;
+            } else {
+                i--;
+            }
+        }
+    }
+    if (vd.exc)
+        vd.exc[base * (uint64_t)fp + n] = x;
+    vd.xin[base * (uint64_t)fp + n] = x;
+}
+int excite_max_nlpf() { return kExcAnyMaxNlpf; }
+// the shapes k_excite's LDS staging is laid out for (everything else: k_excite_any)
+static bool excite_fits_staged(const VocDev &vd)
+{
+    return vd.fperiod >= 30 && vd.nlpf <= 64 && vd.nlpf - 1 <= vd.fperiod;
 }
 
 // nlpf == 0: the ring-buffer-less branch of Excitation::get (excitation.rs:87-100), reachable through
@@ -1287,10 +1363,11 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
             const int i0 = q * bs; // first sample of block within frame
             const uint64_t n0 = (uint64_t)t * (uint64_t)fp + (uint64_t)i0; // within utterance
             // excitation (gain applied) of this block, lane = sample (k_excite)
-            const double xin = lane < bs ? exc_block_ptr(vd, base, t, exc_code(vd, base, t), q)[i0 + lane] : 0.0;
-            // =========== Phase B: bs serial filter steps ===========
+            const int blen = min(bs, fp - i0); // (a shorter last block where bs does not divide the frame period)
+            const double xin = lane < blen ? exc_block_ptr(vd, base, t, exc_code(vd, base, t), q)[i0 + lane] : 0.0;
+            // =========== Phase B: blen serial filter steps ===========
             double ob = 0.0;
-            for (int i = 0; i < bs; i++) {
+            for (int i = 0; i < blen; i++) {
                 double x = readlane_f64(xin, i) * gain;
                 gain *= gq;
                 // ---- V6 df1 (mlsa.rs:54-66), uniform across lanes ----
@@ -1353,7 +1430,7 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
                 c1 += c1inc;
                 ob = (lane == i) ? x * vol : ob;
             }
-            if (lane < bs && emit) {
+            if (lane < blen && emit) {
                 if (vd.pcm16)
                     vd.pcm16[base * (uint64_t)fp + n0 + (uint64_t)lane] = (int16_t)pcm_i16(ob);
                 else
@@ -1947,7 +2024,7 @@ bool excite_is_split(const VocDev &vd)
     // (fperiod = 4m with m <= 64: one of m, 2m, 4m is the block size, so a frame has at most four mask words --
     // what k_excite_fix holds per frame; checked all the same)
     return vd.fperiod % kExw == 0 && vd.fperiod <= 256 && vd.fperiod >= kExwHalo && (vd.nlpf == 31 || vd.nlpf == 15) &&
-           vd.nblk <= 4;
+           vd.nblk <= 4 && vd.fperiod % vd.bs == 0;
 }
 
 hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
@@ -2014,7 +2091,10 @@ hipError_t launch_excite(const BatchDev &bd, const VocDev &vd, hipStream_t strea
         hipLaunchKernelGGL(k_excite_nolpf, grid, block, 0, stream, bd, vd);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(k_excite, grid, block, 0, stream, bd, vd);
+    if (excite_fits_staged(vd))
+        hipLaunchKernelGGL(k_excite, grid, block, 0, stream, bd, vd);
+    else
+        hipLaunchKernelGGL(k_excite_any, grid, block, (size_t)(kExcBlock + vd.nlpf - 1) * sizeof(double), stream, bd, vd);
     return hipGetLastError();
 }
 

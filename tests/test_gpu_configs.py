@@ -322,15 +322,69 @@ def test_other_frame_periods_and_lpf_orders(ctx, fs, fp, alpha, nlpf):
         assert rel_rms(got[0], ref) <= 1e-9, (fs, fp, alpha, nlpf, kw)
 
 
-def test_unsupported_frame_period_fails_loudly(ctx):
-    """The vocoder works in blocks of a divisor of fperiod that is <= 64 and >= nlpf-1; a frame
-    period without one (75: divisors 25, 15, ...) is refused with JB_ERR_UNSUPPORTED, not mis-synthesised."""
+def lpf_taps_utterance(tab, vi, frames, seed, nlpf):
+    """The nitech utterance with its (static-only) LPF stream cut to its centre taps or widened with small flanks."""
+    import dataclasses
+
+    u = synth.synth_utterance(tab, frames, seed)
+    streams, ustreams = list(vi.streams), list(u.streams)
+    L = vi.streams[2].vector_length
+    if nlpf != L:
+        s2 = u.streams[2]
+        S = s2.mean.shape[0]
+        assert s2.mean.shape[1] == L  # one window
+        if nlpf < L:
+            lo = (L - nlpf) // 2
+            mean, var = s2.mean[:, lo:lo + nlpf].copy(), s2.var[:, lo:lo + nlpf].copy()
+        else:
+            rng = np.random.default_rng(seed + 7)
+            lo = (nlpf - L) // 2
+            mean = rng.normal(0.0, 2e-3, (S, nlpf))
+            var = np.full((S, nlpf), float(s2.var.mean()))
+            mean[:, lo:lo + L] = s2.mean
+            var[:, lo:lo + L] = s2.var
+        ustreams[2] = dataclasses.replace(s2, mean=mean, var=var)
+        streams[2] = dataclasses.replace(vi.streams[2], vector_length=nlpf)
+    return streams, J.Utterance(u.durations, ustreams)
+
+
+@pytest.mark.parametrize("fs,fp,nlpf", [(48000, 75, 31), (48000, 83, 31), (48000, 131, 15), (48000, 134, 31),
+                                        (48000, 307, 31), (16000, 20, 31), (16000, 25, 5), (8000, 7, 3),
+                                        (48000, 240, 127), (48000, 80, 65), (22050, 110, 255)])
+def test_frame_periods_and_lpf_orders_the_reference_is_generic_in(ctx, fs, fp, nlpf):
+    """Vocoder::new is generic in the frame period and the number of low-pass taps (vocoder/mod.rs:45-70; the ring
+    buffer of excitation.rs:113-123 has nlpf slots).  Frame periods without a useful divisor <= 64 (75 = 3 x 25 under
+    31 taps, primes) run on blocks with a shorter last block; more than 64 taps, frame periods below 30 samples and
+    below nlpf - 1 (a sample's window then spans several frames) take k_excite_any.  HIP vs oracle, default kernels,
+    the throughput kernel (even frame periods; the wave kernel otherwise) and the wave kernel."""
     import dataclasses
 
     eng, tab, vi = ctx
-    u = synth.synth_utterance(tab, 50, 1)
+    T = 300
+    streams, u2 = lpf_taps_utterance(tab, vi, T, 23, nlpf)
+    vi2 = dataclasses.replace(vi, sampling_frequency=fs, fperiod=fp, streams=streams)
+    ref, tr = oracle_pcm(vi2, u2)
+    assert len(ref) == T * fp and np.isfinite(ref).all() and np.abs(ref).max() > 0
+    for kw in (dict(), dict(chunk_frames=64, kernel="triple"), dict(chunk_frames=64, kernel="wave"), dict(serial=True)):
+        with J.Batch(vi2, [u2, u2], keep_tracks=True, **kw) as b:
+            b.run()
+            b.sync()
+            g0, g1, exc = b.pcm(0), b.pcm(1), b.excitation(0)
+        assert np.array_equal(g0, g1)
+        assert rel_rms(g0, ref) <= 1e-9, (fs, fp, nlpf, kw)
+    _, exc_ref, _ = O.vocoder(fs, fp, vi.alpha, 1.0, tr[1][:, 0], tr[0], tr[2], dumps=True)
+    assert np.abs(exc - exc_ref).max() <= 1e-9 * max(1.0, np.abs(exc_ref).max())
+
+
+def test_shape_limits_fail_loudly(ctx):
+    """What is still refused (JB_ERR_UNSUPPORTED, not mis-synthesised): more low-pass taps than k_excite_any keeps a
+    block's history for in LDS."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    streams, u = lpf_taps_utterance(tab, vi, 20, 1, 2049)
     with pytest.raises(J.JbError) as ei:
-        J.Batch(dataclasses.replace(vi, fperiod=75), [u])
+        J.Batch(dataclasses.replace(vi, streams=streams), [u])
     assert "UNSUPPORTED" in str(ei.value)
 
 

@@ -66,7 +66,7 @@ def oracle_stage_pcm(v2, u, stage, log_gain, beta):
                      stage=stage, use_log_gain=log_gain), tr
 
 
-def stable_utterance(tab, vi, v2, frames, seed, stage, log_gain, beta):
+def stable_utterance(tab, vi, v2, frames, seed, stage, log_gain, beta, bound=1e9):
     """Random LSP sets can make the filter the reference builds unstable (the post-filter sharpens the
     resonances; output ~1e240, identical on both sides but useless as a test): take the first seed
     whose reference output stays bounded."""
@@ -74,7 +74,7 @@ def stable_utterance(tab, vi, v2, frames, seed, stage, log_gain, beta):
         u = lsp_utterance(tab, vi, frames, seed + k, log_gain, jit=(0.02, 0.01) if beta > 0 else (0.06, 0.03))
         with np.errstate(all="ignore"):
             ref, _ = oracle_stage_pcm(v2, u, stage, log_gain, beta)
-        if np.all(np.isfinite(ref)) and np.abs(ref).max() < 1e9:
+        if np.all(np.isfinite(ref)) and np.abs(ref).max() < bound:
             return u
     raise AssertionError("no stable test utterance found")
 
@@ -136,9 +136,40 @@ def test_stage_nonzero_chunked_serial_and_redo(ctx):
     assert rel_rms(outs["serial"][0], ref) <= 1e-4  # end to end: the conversion's conditioning (above)
 
 
+@pytest.mark.parametrize("stage,log_gain", [(9, False), (12, True), (70, False), (150, False)])
+def test_stage_above_eight_generic_kernel(ctx, stage, log_gain):
+    """Stage::NonZero is generic in the number of stages (stage.rs:24-39, mglsa.rs:15-41): above eight the delay
+    lines of a chunk live in LDS instead of registers (four, two or one chunk per workgroup by their size).  The
+    filter kernel on the GPU's own coefficients against the oracle's loop on the same coefficients, and end to end;
+    chunked = serial.  (Every stage of the cascade multiplies the level of these synthetic LSP sets by ~25 -- the same
+    on both sides: 1e13 at nine stages, 1e210 at 150; the comparisons are relative.)"""
+    eng, tab, vi = ctx
+    v2 = stage_voice(vi, stage, log_gain, 0.0)
+    utts = [stable_utterance(tab, vi, v2, T, 1300 + 10 * k, stage, log_gain, 0.0, bound=1e280)
+            for k, T in enumerate((40, 150, 1))]
+    outs = {}
+    for name, kw in (("serial", dict(serial=True)), ("chunked", dict(chunk_frames=32))):
+        with J.Batch(v2, utts, keep_tracks=True, **kw) as b:
+            b.run()
+            b.sync()
+            outs[name] = [b.pcm(i) for i in range(len(utts))]
+            coef = [b.coefficients(i) for i in range(len(utts))]
+            first = [b.first_coefficients(i) for i in range(len(utts))]
+    for i, u in enumerate(utts):
+        ref, tr = oracle_stage_pcm(v2, u, stage, log_gain, 0.0)
+        same = O.vocoder(v2.sampling_frequency, v2.fperiod, v2.alpha, 1.0, tr[1][:, 0], tr[0], tr[2], beta=0.0,
+                         stage=stage, use_log_gain=log_gain, coef=coef[i], cfirst=first[i])
+        assert len(outs["serial"][i]) == len(ref) and np.all(np.isfinite(ref)) and np.max(np.abs(ref)) > 0
+        sc = 1.0 / np.max(np.abs(ref))  # (squares of 1e210 are not doubles)
+        assert rel_rms(outs["serial"][i] * sc, same * sc) <= 1e-9
+        assert rel_rms(outs["chunked"][i] * sc, outs["serial"][i] * sc) <= 1e-9
+        assert rel_rms(outs["serial"][i] * sc, ref * sc) <= 1e-4
+
+
 def test_stage_limits(ctx):
+    """The delay lines of a chunk's stages share one CU's LDS (64 taps x 8 B per stage): 256 stages at most."""
     eng, tab, vi = ctx
     u = lsp_utterance(tab, vi, 20, 960, False)
     with pytest.raises(J.JbError) as ei:
-        J.Batch(stage_voice(vi, 9, False), [u])
+        J.Batch(stage_voice(vi, 257, False), [u])
     assert ei.value.code == -2
