@@ -381,26 +381,34 @@ void parse_trees(Model &m, std::string_view text)
 
 Model parse_model(std::string_view data, Range tree, Range pdf, int pdf_len)
 {
-    if (tree.b >= data.size() || pdf.b >= data.size())
+    if (tree.b >= data.size() || pdf.b >= data.size() || tree.a > tree.b || pdf.a > pdf.b)
         throw ModelError("position out of range");
+    if (pdf_len <= 0)
+        throw ModelError("pdf length out of range");
     Model m;
     m.pdf_len = pdf_len;
     parse_trees(m, data.substr(tree.a, tree.b - tree.a + 1));
+    // (counts and lengths come from the file: every size is checked against the bytes that are LEFT, never by
+    // forming a pointer past them -- a count of 0xffffffff times a vector length wraps a pointer sum)
     const uint8_t *p = (const uint8_t *)data.data() + pdf.a;
     const uint8_t *end = (const uint8_t *)data.data() + pdf.b + 1;
+    auto left = [&]() { return (size_t)(end - p); };
     auto rd32 = [&](const uint8_t *q) {
         return (uint32_t)q[0] | (uint32_t)q[1] << 8 | (uint32_t)q[2] << 16 | (uint32_t)q[3] << 24;
     };
     for (size_t k = 0; k < m.trees.size(); k++) {
-        if (p + 4 > end)
+        if (left() < 4)
             throw ModelError("pdf blob truncated");
-        m.npdf.push_back((int)rd32(p));
+        const uint32_t np = rd32(p);
+        if (np > 0x7fffffffu)
+            throw ModelError("pdf count out of range");
+        m.npdf.push_back((int)np);
         p += 4;
     }
     for (size_t k = 0; k < m.trees.size(); k++) {
-        size_t cnt = (size_t)m.npdf[k] * (size_t)pdf_len;
-        if (p + 4 * cnt > end)
+        if ((size_t)m.npdf[k] > left() / 4 / (size_t)pdf_len)
             throw ModelError("pdf blob truncated");
+        size_t cnt = (size_t)m.npdf[k] * (size_t)pdf_len;
         std::vector<float> v(cnt);
         for (size_t i = 0; i < cnt; i++) {
             uint32_t u = rd32(p + 4 * i);
@@ -455,7 +463,7 @@ std::shared_ptr<Voice> parse_htsvoice(const uint8_t *bytes, size_t n)
         m.gv_off_patterns = quoted_list(it->second);
     v->gv_off.patterns = m.gv_off_patterns;
     v->gv_off.compile();
-    if ((int)m.stream_type.size() != m.num_streams || m.num_states <= 0)
+    if ((int)m.stream_type.size() != m.num_streams || m.num_states <= 0 || m.num_states > (1 << 20))
         throw ModelError("inconsistent global header");
 
     v->duration = parse_model(data, parse_range(need(P, "DURATION_TREE")),
@@ -466,6 +474,9 @@ std::shared_ptr<Voice> parse_htsvoice(const uint8_t *bytes, size_t n)
         auto key = [&](const char *k) { return std::string(k) + "[" + nm + "]"; };
         sm.vector_length = to_int(need(S, key("VECTOR_LENGTH")), "VECTOR_LENGTH");
         sm.num_windows = to_int(need(S, key("NUM_WINDOWS")), "NUM_WINDOWS");
+        // (pdf_len below is a product of the two: keep it an int)
+        if (sm.vector_length < 0 || sm.vector_length > (1 << 20) || sm.num_windows < 0 || sm.num_windows > 255)
+            throw ModelError("VECTOR_LENGTH / NUM_WINDOWS out of range");
         sm.is_msd = to_int(need(S, key("IS_MSD")), "IS_MSD") != 0;
         sm.use_gv = to_int(need(S, key("USE_GV")), "USE_GV") != 0;
         if (auto it = S.find(key("OPTION")); it != S.end())
@@ -476,7 +487,7 @@ std::shared_ptr<Voice> parse_htsvoice(const uint8_t *bytes, size_t n)
                 throw ModelError("window out of range");
             std::istringstream is(std::string(data.substr(wr.a, wr.b - wr.a + 1)));
             size_t cnt;
-            if (!(is >> cnt))
+            if (!(is >> cnt) || cnt > wr.b - wr.a + 1) // (a coefficient takes at least one byte of the row's text)
                 throw ModelError("bad window row");
             std::vector<double> w(cnt);
             for (double &c : w)
