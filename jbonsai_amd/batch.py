@@ -282,7 +282,8 @@ class Batch:
         return dict(chunk_frames=v[0].value, warmup_frames=v[1].value, n_items=v[2].value, n_redo=v[3].value)
 
     def kernel_info(self):
-        """(kernel name, waves per SIMD) of the vocoder kernel the work list was built for."""
+        """(kernel name, waves per SIMD) of the vocoder kernel the work list was built for ("k_vocoder" stands for
+        its two-wave form k_vocoder_pair as well, which launches of at most two chunks per CU take)."""
         lt, w = C.c_uint32(), C.c_uint32()
         F.check(self._L.jb_batch_kernel_info(self._h, C.byref(lt), C.byref(w)))
         return ("k_vocoder_lt" if lt.value else "k_vocoder"), w.value

@@ -1445,6 +1445,278 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
 }
 
 // --------------------------------------------------------------------------
+// The same recursion on TWO waves per work item, for launches that leave half of the device's SIMDs idle anyway
+// (n_items <= 2 per CU: a single sentence, the frames a streaming generator serves first, a redo round).
+// A lone wave runs k_vocoder at the issue rate of its SIMD -- 117 instructions per sample, one every four cycles --
+// and a third of them do not belong to the recursion's cross-lane part at all: the gain and df1 (mlsa.rs:54-66: five
+// one-tap sections, the same value in every lane), the read of the excitation sample, the collection of the output.
+// df1 feeds df2 and nothing comes back, so a PRODUCER wave runs excitation x gain -> df1 one block (bs samples) ahead
+// and leaves its outputs in LDS; the CONSUMER wave runs df2 (mlsa.rs:68-94) on them and leaves its outputs in LDS, which
+// the producer scales, converts and stores a block later.  Same operations in the same order as k_vocoder: same bits.
+// A workgroup = 4 waves = 2 items: waves 0, 1 the consumers, waves 2, 3 the producers -- one wave per SIMD of the CU;
+// one barrier per block keeps the two double buffers in step (a block is ~20,000 cycles of work).
+template <int TPL>
+__global__ __launch_bounds__(256) void k_vocoder_pair(BatchDev bd, VocDev vd, const VocWork *__restrict__ work,
+                                                      uint32_t n_items)
+{
+    __shared__ double xbuf[2][2][64]; // [item of the workgroup][block parity][sample]: df1 outputs
+    __shared__ double obuf[2][2][64]; // df2 outputs (before the volume)
+    __shared__ uint32_t nblocks_sh[2];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = wv & 1;
+    const bool producer = wv >= 2;
+    const uint32_t item = blockIdx.x * 2u + (uint32_t)slot;
+    const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk, nmcp = vd.nmcp;
+    VocWork wk{};
+    uint32_t t_begin = 0, t_end = 0, t_out = 0;
+    int b = 0;
+    if (item < n_items) {
+        wk = work[item];
+        b = (int)wk.utt;
+        t_begin = wk.t_start;
+        t_out = wk.t_out;
+        t_end = min(wk.t_end, bd.utt[b].T);
+        if (t_begin >= t_end)
+            t_begin = t_end = 0;
+    }
+    const uint32_t NB = (t_end - t_begin) * (uint32_t)nblk; // blocks of this item
+    if (!producer && lane == 0)
+        nblocks_sh[slot] = NB;
+    __syncthreads();
+    const uint32_t NBmax = max(nblocks_sh[0], nblocks_sh[1]);
+    const uint64_t base = NB ? bd.utt[b].frame_off : 0;
+    const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
+    double *const xb = &xbuf[slot][0][0];
+    double *const ob = &obuf[slot][0][0];
+
+    if (producer) {
+        // ================= producer: gain, df1, PCM stores =================
+        double e11[6], e12[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+            e11[i] = e12[i] = 0.0;
+        if (NB && wk.load_state) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                e11[i] = wk.load_state[64 * TPL + 64 + i];
+                e12[i] = wk.load_state[64 * TPL + 70 + i];
+            }
+        }
+        auto save_state = [&](double *sp) {
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    sp[64 * TPL + 64 + i] = e11[i];
+                    sp[64 * TPL + 70 + i] = e12[i];
+                }
+            }
+        };
+        uint32_t t = t_begin;
+        int q = 0;
+        double c1 = 0.0, c1inc = 0.0, gain = 0.0, gq = 0.0;
+        for (uint32_t st = 0; st < NBmax + 2; st++) {
+            // (1) the block the consumer finished in the previous step: scale, convert, store
+            if (st >= 2 && st - 2 < NB) {
+                const uint32_t gb = st - 2;
+                const uint32_t ts = t_begin + gb / (uint32_t)nblk;
+                const int qs = (int)(gb % (uint32_t)nblk), i0 = qs * bs;
+                const int blen = min(bs, fp - i0);
+                if (ts >= t_out && lane < blen) {
+                    const double v = ob[64 * (gb & 1u) + lane] * vol;
+                    const uint64_t o = base * (uint64_t)fp + (uint64_t)ts * (uint64_t)fp + (uint64_t)(i0 + lane);
+                    if (vd.pcm16)
+                        vd.pcm16[o] = (int16_t)pcm_i16(v);
+                    else
+                        vd.pcm[o] = v;
+                }
+            }
+            // (2) df1 of block st
+            if (st < NB) {
+                if (q == 0) {
+                    if (t == t_out && t_out > t_begin && wk.save_warm)
+                        save_state(wk.save_warm);
+                    if (t == t_out + vd.ckpt_frames && wk.save_ckpt)
+                        save_state(wk.save_ckpt);
+                    if (vd.ckpt2_frames && t == t_out + vd.ckpt2_frames && wk.save_ckpt2)
+                        save_state(wk.save_ckpt2);
+                    // frame setup (vocoder/mod.rs:116-131), as k_vocoder
+                    const double *bcur = vd.bcoef + (base + t) * (uint64_t)nmcp;
+                    const double *bprev =
+                        (t > 0) ? bcur - nmcp : (vd.bfirst ? vd.bfirst + (uint64_t)b * (uint64_t)nmcp : bcur);
+                    c1 = bprev[1];
+                    c1inc = (bcur[1] - c1) / (double)fp;
+                    gain = exp(bprev[0]);
+                    gq = exp((bcur[0] - bprev[0]) / (double)fp);
+                }
+                const int i0 = q * bs;
+                const int blen = min(bs, fp - i0);
+                const double xin = lane < blen ? exc_block_ptr(vd, base, t, exc_code(vd, base, t), q)[i0 + lane] : 0.0;
+                double xo = 0.0;
+                for (int i = 0; i < blen; i++) {
+                    double x = readlane_f64(xin, i) * gain;
+                    gain *= gq;
+                    // ---- V6 df1 (mlsa.rs:54-66), uniform across lanes ----
+                    double out = 0.0;
+#pragma unroll
+                    for (int ii = 5; ii >= 1; ii--) {
+                        e11[ii] = fma(iaa, e12[ii - 1], a * e11[ii]);
+                        e12[ii] = e11[ii] * c1;
+                        const double v = e12[ii] * kPPade[ii];
+                        x += (ii & 1) ? v : -v;
+                        out += v;
+                    }
+                    e12[0] = x;
+                    x += out;
+                    c1 += c1inc;
+                    xo = (lane == i) ? x : xo;
+                }
+                if (lane < blen)
+                    xb[64 * (st & 1u) + lane] = xo;
+                if (++q == nblk) {
+                    q = 0;
+                    t++;
+                }
+            }
+            __syncthreads();
+        }
+        if (NB && wk.save_end)
+            save_state(wk.save_end);
+        return;
+    }
+
+    // ================= consumer: df2 =================
+    const int M = nmcp - 1; // live taps 1..M
+    const int s = lane / kGroups, g = lane % kGroups;
+    const bool active = lane < kPade * kGroups;
+    const bool head = active && g == 0;
+    const double kappa = ipow(-a, TPL);
+    ScanCoef kc, ks; // weighted (carry) and unit (sum) coefficients
+    {
+        const int r16 = lane & 15;
+        auto ok = [&](int sh) { return active && g >= sh && r16 >= sh; };
+        kc.c1 = ok(1) ? ipow(kappa, 1) : 0.0;
+        kc.c2 = ok(2) ? ipow(kappa, 2) : 0.0;
+        kc.c4 = ok(4) ? ipow(kappa, 4) : 0.0;
+        kc.c8 = ok(8) ? ipow(kappa, 8) : 0.0;
+        const int rowstart = lane & ~15, segstart = s * kGroups;
+        const bool straddle = active && rowstart > 0 && segstart < rowstart;
+        kc.cb = straddle ? ipow(kappa, lane - rowstart + 1) : 0.0;
+        ks.c1 = kc.c1 != 0.0 ? 1.0 : 0.0;
+        ks.c2 = kc.c2 != 0.0 ? 1.0 : 0.0;
+        ks.c4 = kc.c4 != 0.0 ? 1.0 : 0.0;
+        ks.c8 = kc.c8 != 0.0 ? 1.0 : 0.0;
+        ks.cb = straddle ? 1.0 : 0.0;
+    }
+    const double nh = (active && !head) ? 1.0 : 0.0;  // takes carry from lane-1
+    const double hmask = (head && s > 0) ? 1.0 : 0.0; // stage input from previous stage
+    const double l0mask = (lane == 0) ? 1.0 : 0.0;    // stage-1 input = d22[0]
+    const double Pl = active ? kPPade[s + 1] : 0.0;
+    int tapj[TPL];
+    bool dotv[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+        tapj[k] = g * TPL + k + 1;
+        dotv[k] = active && tapj[k] >= 2 && tapj[k] <= M;
+    }
+    double d[TPL], cd[TPL], cdinc[TPL];
+#pragma unroll
+    for (int k = 0; k < TPL; k++)
+        d[k] = cd[k] = cdinc[k] = 0.0;
+    double ulane = 0.0;
+    if (NB && wk.load_state) {
+#pragma unroll
+        for (int k = 0; k < TPL; k++)
+            d[k] = wk.load_state[64 * k + lane];
+        ulane = wk.load_state[64 * TPL + lane];
+    }
+    auto save_state = [&](double *sp) {
+#pragma unroll
+        for (int k = 0; k < TPL; k++)
+            sp[64 * k + lane] = d[k];
+        sp[64 * TPL + lane] = ulane;
+    };
+    uint32_t t = t_begin;
+    int q = 0;
+    for (uint32_t st = 0; st < NBmax + 2; st++) {
+        if (st >= 1 && st - 1 < NB) {
+            const uint32_t gb = st - 1;
+            if (q == 0) {
+                if (t == t_out && t_out > t_begin && wk.save_warm)
+                    save_state(wk.save_warm);
+                if (t == t_out + vd.ckpt_frames && wk.save_ckpt)
+                    save_state(wk.save_ckpt);
+                if (vd.ckpt2_frames && t == t_out + vd.ckpt2_frames && wk.save_ckpt2)
+                    save_state(wk.save_ckpt2);
+                const double *bcur = vd.bcoef + (base + t) * (uint64_t)nmcp;
+                const double *bprev = (t > 0) ? bcur - nmcp : (vd.bfirst ? vd.bfirst + (uint64_t)b * (uint64_t)nmcp : bcur);
+#pragma unroll
+                for (int k = 0; k < TPL; k++) {
+                    const double c0v = dotv[k] ? bprev[tapj[k]] : 0.0;
+                    const double c1v = dotv[k] ? bcur[tapj[k]] : 0.0;
+                    cd[k] = c0v;
+                    cdinc[k] = (c1v - c0v) / (double)fp;
+                }
+            }
+            const int blen = min(bs, fp - q * bs);
+            const double *xs = xb + 64 * (gb & 1u);
+            double *os = ob + 64 * (gb & 1u);
+            double xn = xs[0]; // the df1 output of the next sample is requested a sample ahead of its use
+            for (int i = 0; i < blen; i++) {
+                double x = xn;
+                xn = xs[i + 1 < blen ? i + 1 : i];
+                // ---- V7 df2: five fir() calls at once (as k_vocoder) ----
+                double loc = d[0];
+#pragma unroll
+                for (int k = 1; k < TPL; k++)
+                    loc = fma(-a, loc, d[k]);
+                double I = fma(kappa, ulane, loc); // ulane != 0 only on head lanes
+                I = seg_scan(I, kc);
+                double r = fma(nh, dpp_f64<DPP_WAVE_SHR1>(I), ulane); // rem entering tap 0 of lane
+#pragma unroll
+                for (int k = 0; k < TPL; k++) {
+                    const double rn = fma(-a, r, d[k]);
+                    d[k] = fma(a, rn, r);
+                    r = rn;
+                }
+                double yl = cd[0] * d[0];
+#pragma unroll
+                for (int k = 1; k < TPL; k++)
+                    yl = fma(cd[k], d[k], yl);
+                const double Y = seg_scan(yl, ks); // stage sums at lanes 12*s+11
+                const double Yp = Y * Pl;
+                const double v1 = readlane_f64(Yp, 11), v2 = readlane_f64(Yp, 23), v3 = readlane_f64(Yp, 35),
+                             v4 = readlane_f64(Yp, 47), v5 = readlane_f64(Yp, 59);
+                // Pade combine in the reference's order (mlsa.rs:71-78)
+                x += v5;
+                x -= v4;
+                x += v3;
+                x -= v2;
+                x += v1;
+                double out = v5;
+                out += v4;
+                out += v3;
+                out += v2;
+                out += v1;
+                ulane = fma(hmask, dpp_f64<DPP_WAVE_SHR1>(Y), l0mask * x);
+                x += out;
+#pragma unroll
+                for (int k = 0; k < TPL; k++)
+                    cd[k] += cdinc[k];
+                if (lane == 0)
+                    os[i] = x;
+            }
+            if (++q == nblk) {
+                q = 0;
+                t++;
+            }
+        }
+        __syncthreads();
+    }
+    if (NB && wk.save_end)
+        save_state(wk.save_end);
+}
+
+// --------------------------------------------------------------------------
 // Lane-triple throughput kernel: ONE CHUNK PER THREE ADJACENT LANES.
 // With time-chunking there are tens of thousands of independent recursions per batch, so the
 // cross-lane machinery of k_vocoder (DPP scans, readlane combines: ~128 VALU instructions per
@@ -2183,6 +2455,37 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
     if (vd.stage > 0) // Stage::NonZero: the MGLSA cascade (jb_mglsa.hip)
         return launch_vocoder_mglsa(bd, vd, work_dev, n_items, stream);
     dim3 grid((n_items + 3) / 4), block(256);
+    // two waves per item while that still leaves every wave a SIMD of its own (k_vocoder_pair)
+    static int cus_of[64] = {0};
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && (cus = cus_of[dev]) == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 0;
+        cus_of[dev] = cus;
+    }
+    if (cus > 0 && n_items <= 2u * (uint32_t)cus && !getenv("JB_NO_PAIR_KERNEL")) {
+        const dim3 gp((n_items + 1) / 2);
+        switch (tpl_for(vd.nmcp)) {
+        case 1:
+            hipLaunchKernelGGL(k_vocoder_pair<1>, gp, block, 0, stream, bd, vd, work_dev, n_items);
+            break;
+        case 2:
+            hipLaunchKernelGGL(k_vocoder_pair<2>, gp, block, 0, stream, bd, vd, work_dev, n_items);
+            break;
+        case 3:
+            hipLaunchKernelGGL(k_vocoder_pair<3>, gp, block, 0, stream, bd, vd, work_dev, n_items);
+            break;
+        case 4:
+            hipLaunchKernelGGL(k_vocoder_pair<4>, gp, block, 0, stream, bd, vd, work_dev, n_items);
+            break;
+        case 5:
+            hipLaunchKernelGGL(k_vocoder_pair<5>, gp, block, 0, stream, bd, vd, work_dev, n_items);
+            break;
+        default:
+            return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
     switch (tpl_for(vd.nmcp)) {
     case 1:
         hipLaunchKernelGGL(k_vocoder<1>, grid, block, 0, stream, bd, vd, work_dev, n_items);

@@ -10,6 +10,7 @@ import pytest
 import jbonsai_amd as J
 from jbonsai_amd import synth
 from tests.conftest import VOICE
+from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
 from tests.helpers import rel_rms
 
 pytestmark = pytest.mark.gpu
@@ -78,3 +79,52 @@ def test_release_cached_memory_frees_the_pinned_chunks_and_batches_go_on(ctx):
         b.sync()
         for i, r in enumerate(ref):
             assert np.array_equal(b.pcm(i), r)
+
+
+def test_two_wave_vocoder_equals_the_wave_kernel_bit_for_bit(monkeypatch):
+    """Launches of at most two items per CU run k_vocoder_pair (a producer wave for gain + df1 and the PCM stores, a
+    consumer wave for df2, a block apart through LDS); JB_NO_PAIR_KERNEL=1 keeps k_vocoder.  Same operations in the
+    same order: the PCM must be the same BITS -- single sentences through the engine, a ragged batch chunked (with
+    its redo round), serial, with a 2-frame warm-up (dozens of chunks redone from saved states) and through the
+    16-bit sink; the streaming generator's serially served frames too."""
+    eng = J.Engine.load([VOICE])
+    tab = synth.VoiceTables(eng)
+    vi = eng.voice_info()
+
+    def both(fn):
+        monkeypatch.delenv("JB_NO_PAIR_KERNEL", raising=False)
+        a = fn()
+        monkeypatch.setenv("JB_NO_PAIR_KERNEL", "1")
+        b = fn()
+        monkeypatch.delenv("JB_NO_PAIR_KERNEL", raising=False)
+        return a, b
+
+    for lab in (SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2):
+        a, b = both(lambda: eng.synthesize(lab))
+        assert len(a) > 0 and np.array_equal(a, b)
+    utts = [synth.synth_utterance(tab, T, 40 + T) for T in (300, 1, 77, 512, 150)]
+    for kw in (dict(), dict(serial=True), dict(chunk_frames=24, warmup_frames=2, verify_tol=1e-9), dict(pcm_i16=True),
+               dict(chunk_frames=16, kernel="wave")):
+        def run():
+            with J.Batch(vi, utts, **kw) as bt:
+                bt.run()
+                bt.sync()
+                return [bt.pcm_i16(i) if kw.get("pcm_i16") else bt.pcm(i) for i in range(len(utts))], bt.info()
+        (a, ia), (b, ib) = both(run)
+        assert ia["n_redo"] == ib["n_redo"]
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), kw
+
+    def stream():
+        g = eng.generator(SAMPLE_SENTENCE_1)
+        fp = g.fperiod()
+        out = np.zeros(g.total_frames() * fp)
+        k = 0
+        while True:
+            n = g.generate_step(out[k:])
+            if n == 0:
+                break
+            k += n
+        return out[:k]
+    a, b = both(stream)
+    assert len(a) == 66480 and np.array_equal(a, b)
