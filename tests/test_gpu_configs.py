@@ -488,7 +488,7 @@ def test_device_pool_reuse_release_and_dirty_blocks(oracle_voice):
     assert np.array_equal(J.paramgen_vocode_batch(vi, [to_utt(d1, s1)])[0], fresh1)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_random_shape_combinations(ctx, seed):
     """Seeded random COMBINATIONS of what the tests above vary one at a time: mel-cepstral order,
     frame period, LPF order, warping alpha, volume, post-filter beta, a ragged batch with an empty
@@ -500,8 +500,12 @@ def test_random_shape_combinations(ctx, seed):
     L = vi.streams[0].vector_length
     W = len(vi.streams[0].windows)
     L2 = int(rng.choice([8, 13, 20, 25, 30, 35]))
-    fs, fp = [(16000, 80), (48000, 240), (44100, 220), (48000, 96), (22050, 100), (48000, 120)][seed - 1]
-    nlpf = int(rng.choice([7, 15, 23, 31]))
+    if seed <= 6:
+        fs, fp = [(16000, 80), (48000, 240), (44100, 220), (48000, 96), (22050, 100), (48000, 120)][seed - 1]
+        nlpf = int(rng.choice([7, 15, 23, 31]))
+    else:  # any frame period (blocks with a shorter last block, k_excite_any below 30 samples) and any odd tap count
+        fs, fp = [(48000, 77), (44100, 201), (16000, 27), (48000, 323)][seed - 7]
+        nlpf = 2 * int(rng.integers(0, 16)) + 1
     alpha = float(rng.choice([0.42, 0.5, 0.55]))
     beta = float(rng.choice([0.0, 0.0, 0.2, 0.5]))
     volume = float(rng.choice([1.0, 0.5, 1.7]))
