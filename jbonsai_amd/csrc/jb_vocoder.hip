@@ -1455,17 +1455,20 @@ __global__ __launch_bounds__(256) void k_vocoder(BatchDev bd, VocDev vd, const V
 // the producer scales, converts and stores a block later.  Same operations in the same order as k_vocoder: same bits.
 // A workgroup = 4 waves = 2 items: waves 0, 1 the consumers, waves 2, 3 the producers -- one wave per SIMD of the CU;
 // one barrier per block keeps the two double buffers in step (a block is ~20,000 cycles of work).
-template <int TPL>
-__global__ __launch_bounds__(256) void k_vocoder_pair(BatchDev bd, VocDev vd, const VocWork *__restrict__ work,
-                                                      uint32_t n_items)
+// ITEMS = 4 (eight waves, launches of up to four items per CU): waves w and w + 4 of a workgroup share a SIMD, so the
+// consumer of an item and its producer do -- the producer's 40 instructions per sample fit into the bubbles of the
+// consumer's dependent chain (78 instructions in ~470 cycles).
+template <int TPL, int ITEMS>
+__global__ __launch_bounds__(128 * ITEMS) void k_vocoder_pair(BatchDev bd, VocDev vd, const VocWork *__restrict__ work,
+                                                              uint32_t n_items)
 {
-    __shared__ double xbuf[2][2][64]; // [item of the workgroup][block parity][sample]: df1 outputs
-    __shared__ double obuf[2][2][64]; // df2 outputs (before the volume)
-    __shared__ uint32_t nblocks_sh[2];
+    __shared__ double xbuf[ITEMS][2][64]; // [item of the workgroup][block parity][sample]: df1 outputs
+    __shared__ double obuf[ITEMS][2][64]; // df2 outputs (before the volume)
+    __shared__ uint32_t nblocks_sh[ITEMS];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = wv & 1;
-    const bool producer = wv >= 2;
-    const uint32_t item = blockIdx.x * 2u + (uint32_t)slot;
+    const int slot = wv % ITEMS;
+    const bool producer = wv >= ITEMS;
+    const uint32_t item = blockIdx.x * (uint32_t)ITEMS + (uint32_t)slot;
     const int fp = vd.fperiod, bs = vd.bs, nblk = vd.nblk, nmcp = vd.nmcp;
     VocWork wk{};
     uint32_t t_begin = 0, t_end = 0, t_out = 0;
@@ -1483,7 +1486,10 @@ __global__ __launch_bounds__(256) void k_vocoder_pair(BatchDev bd, VocDev vd, co
     if (!producer && lane == 0)
         nblocks_sh[slot] = NB;
     __syncthreads();
-    const uint32_t NBmax = max(nblocks_sh[0], nblocks_sh[1]);
+    uint32_t NBmax = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++)
+        NBmax = max(NBmax, nblocks_sh[j]);
     const uint64_t base = NB ? bd.utt[b].frame_off : 0;
     const double a = vd.alpha, iaa = 1.0 - a * a, vol = vd.volume;
     double *const xb = &xbuf[slot][0][0];
@@ -2463,24 +2469,38 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
             cus = 0;
         cus_of[dev] = cus;
     }
-    if (cus > 0 && n_items <= 2u * (uint32_t)cus && !getenv("JB_NO_PAIR_KERNEL")) {
+    const char *nop = getenv("JB_NO_PAIR_KERNEL"); // (unset: both forms; "1": neither; "8": not the eight-wave form)
+    if (cus > 0 && n_items <= 2u * (uint32_t)cus && !(nop && nop[0] == '1')) {
         const dim3 gp((n_items + 1) / 2);
         switch (tpl_for(vd.nmcp)) {
-        case 1:
-            hipLaunchKernelGGL(k_vocoder_pair<1>, gp, block, 0, stream, bd, vd, work_dev, n_items);
-            break;
-        case 2:
-            hipLaunchKernelGGL(k_vocoder_pair<2>, gp, block, 0, stream, bd, vd, work_dev, n_items);
-            break;
-        case 3:
-            hipLaunchKernelGGL(k_vocoder_pair<3>, gp, block, 0, stream, bd, vd, work_dev, n_items);
-            break;
-        case 4:
-            hipLaunchKernelGGL(k_vocoder_pair<4>, gp, block, 0, stream, bd, vd, work_dev, n_items);
-            break;
-        case 5:
-            hipLaunchKernelGGL(k_vocoder_pair<5>, gp, block, 0, stream, bd, vd, work_dev, n_items);
-            break;
+#define JB_PAIR_CASE(T)                                                                                            \
+    case T:                                                                                                        \
+        hipLaunchKernelGGL((k_vocoder_pair<T, 2>), gp, dim3(256), 0, stream, bd, vd, work_dev, n_items);            \
+        break;
+            JB_PAIR_CASE(1)
+            JB_PAIR_CASE(2)
+            JB_PAIR_CASE(3)
+            JB_PAIR_CASE(4)
+            JB_PAIR_CASE(5)
+#undef JB_PAIR_CASE
+        default:
+            return hipErrorInvalidValue;
+        }
+        return hipGetLastError();
+    }
+    if (cus > 0 && n_items <= 4u * (uint32_t)cus && !nop) {
+        const dim3 gp((n_items + 3) / 4);
+        switch (tpl_for(vd.nmcp)) {
+#define JB_PAIR_CASE(T)                                                                                            \
+    case T:                                                                                                        \
+        hipLaunchKernelGGL((k_vocoder_pair<T, 4>), gp, dim3(512), 0, stream, bd, vd, work_dev, n_items);            \
+        break;
+            JB_PAIR_CASE(1)
+            JB_PAIR_CASE(2)
+            JB_PAIR_CASE(3)
+            JB_PAIR_CASE(4)
+            JB_PAIR_CASE(5)
+#undef JB_PAIR_CASE
         default:
             return hipErrorInvalidValue;
         }

@@ -82,8 +82,9 @@ def test_release_cached_memory_frees_the_pinned_chunks_and_batches_go_on(ctx):
 
 
 def test_two_wave_vocoder_equals_the_wave_kernel_bit_for_bit(monkeypatch):
-    """Launches of at most two items per CU run k_vocoder_pair (a producer wave for gain + df1 and the PCM stores, a
-    consumer wave for df2, a block apart through LDS); JB_NO_PAIR_KERNEL=1 keeps k_vocoder.  Same operations in the
+    """Launches of at most four items per CU run k_vocoder_pair (a producer wave for gain + df1 and the PCM stores, a
+    consumer wave for df2, a block apart through LDS; up to two items per CU every wave has a SIMD of its own, up to
+    four an item's two waves share one); JB_NO_PAIR_KERNEL=1 keeps k_vocoder.  Same operations in the
     same order: the PCM must be the same BITS -- single sentences through the engine, a ragged batch chunked (with
     its redo round), serial, with a 2-frame warm-up (dozens of chunks redone from saved states) and through the
     16-bit sink; the streaming generator's serially served frames too."""
@@ -114,6 +115,20 @@ def test_two_wave_vocoder_equals_the_wave_kernel_bit_for_bit(monkeypatch):
         assert ia["n_redo"] == ib["n_redo"]
         for x, y in zip(a, b):
             assert np.array_equal(x, y), kw
+
+    # 600-1000 chunks: the eight-wave form (four items per workgroup, an item's consumer and producer on one SIMD)
+    rng = np.random.default_rng(3)
+    utts8 = [synth.synth_utterance(tab, int(T), 900 + k) for k, T in enumerate(rng.integers(7, 1500, 36))]
+
+    def run8():
+        with J.Batch(vi, utts8) as bt:
+            bt.run()
+            bt.sync()
+            return [bt.pcm(i) for i in range(len(utts8))], bt.info()
+    (a, ia), (b, ib) = both(run8)
+    assert 512 < ia["n_items"] <= 1024 and ia["n_redo"] == ib["n_redo"]
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
 
     def stream():
         g = eng.generator(SAMPLE_SENTENCE_1)

@@ -44,6 +44,32 @@ for kw in (dict(), dict(serial=True), dict(chunk_frames=24, warmup_frames=2, ver
     same = all(np.array_equal(x, y) for x, y in zip(a, b))
     ok &= same
     print(f"batch {kw}: bits {'identical' if same else 'DIFFER'}; redo {ia['n_redo']} / {ib['n_redo']}")
+# 600-1000 items: the eight-wave form (consumer and producer of an item on one SIMD)
+rng = np.random.default_rng(3)
+utts8 = [synth.synth_utterance(tab, int(T), 900 + k) for k, T in enumerate(rng.integers(7, 1500, 36))]
+for kw in (dict(), dict(chunk_frames=24, warmup_frames=3, verify_tol=1e-9)):
+    def run8():
+        with J.Batch(vi, utts8, **kw) as bt:
+            bt.run()
+            bt.sync()
+            return [bt.pcm(i) for i in range(len(utts8))], bt.info()
+    (a, ia), (b, ib) = both(run8)
+    same = all(np.array_equal(x, y) for x, y in zip(a, b))
+    ok &= same
+    print(f"36 utterances {kw}: {ia['n_items']} items, bits {'identical' if same else 'DIFFER'}; redo {ia['n_redo']} / {ib['n_redo']}")
+    for k, env in enumerate((None, "8", "1")):
+        os.environ.pop("JB_NO_PAIR_KERNEL", None)
+        if env:
+            os.environ["JB_NO_PAIR_KERNEL"] = env
+        with J.Batch(vi, utts8, **kw) as bt:
+            ts = []
+            for _ in range(12):
+                t0 = time.perf_counter()
+                bt.run()
+                bt.sync()
+                ts.append(time.perf_counter() - t0)
+        print(f"   {('eight-wave pair', 'k_vocoder (JB_NO_PAIR_KERNEL=8)', 'k_vocoder (JB_NO_PAIR_KERNEL=1)')[k]}: run+sync median {np.median(ts[2:]) * 1e3:.3f} ms")
+    os.environ.pop("JB_NO_PAIR_KERNEL", None)
 for name, lab in (("sentence 1", SAMPLE_SENTENCE_1), ("sentence 2 x 5", list(SAMPLE_SENTENCE_2) * 5)):
     for k in range(2):
         if k:
