@@ -2296,6 +2296,21 @@ hipError_t launch_mc2b(const BatchDev &bd, const VocDev &vd, hipStream_t stream)
     return hipGetLastError();
 }
 
+// CUs of the calling thread's current device, asked once per process and device (0: unknown)
+static int current_device_cus()
+{
+    static int cus_of[64] = {0};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return 0;
+    if ((cus = cus_of[dev]) == 0) {
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 0;
+        cus_of[dev] = cus;
+    }
+    return cus;
+}
+
 // the split form (k_exc_* + k_excite_fix) is built for these shapes; everything else takes k_excite
 bool excite_is_split(const VocDev &vd)
 {
@@ -2323,16 +2338,9 @@ hipError_t launch_excite_noise(const BatchDev &bd, const VocDev &vd, hipStream_t
     // pass; it still does for a voice whose LPF taps differ from frame to frame).  Fixed grid: three
     // workgroups per CU of the device, each wave taking list entries in turn.
     constexpr size_t pad = 32 * 1024;
-    // (the CU count of a device is asked once per process, not once per step)
-    static int cus_of[64] = {0};
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+    int cus = current_device_cus();
+    if (cus <= 0)
         cus = 256;
-    else if ((cus = cus_of[dev]) == 0) {
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-        cus_of[dev] = cus;
-    }
     const dim3 ggen((unsigned)(3 * cus));
     if (vd.nlpf == 31) {
         hipLaunchKernelGGL(k_exc_classify<31>, gcls, block, 0, stream, bd, vd);
@@ -2462,13 +2470,7 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
         return launch_vocoder_mglsa(bd, vd, work_dev, n_items, stream);
     dim3 grid((n_items + 3) / 4), block(256);
     // two waves per item while that still leaves every wave a SIMD of its own (k_vocoder_pair)
-    static int cus_of[64] = {0};
-    int cus = 0, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && (cus = cus_of[dev]) == 0) {
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 0;
-        cus_of[dev] = cus;
-    }
+    const int cus = current_device_cus();
     const char *nop = getenv("JB_NO_PAIR_KERNEL"); // (unset: both forms; "1": neither; "8": not the eight-wave form)
     if (cus > 0 && n_items <= 2u * (uint32_t)cus && !(nop && nop[0] == '1')) {
         const dim3 gp((n_items + 1) / 2);
