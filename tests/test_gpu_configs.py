@@ -351,7 +351,7 @@ def lpf_taps_utterance(tab, vi, frames, seed, nlpf):
 @pytest.mark.parametrize("fs,fp,nlpf", [(48000, 75, 31), (48000, 83, 31), (48000, 131, 15), (48000, 134, 31),
                                         (48000, 166, 31), (48000, 254, 15), (48000, 307, 31), (16000, 20, 31),
                                         (16000, 25, 5), (8000, 7, 3), (48000, 240, 127), (48000, 80, 65),
-                                        (22050, 110, 255)])
+                                        (22050, 110, 255), (48000, 50, 1023), (48000, 240, 2047)])
 def test_frame_periods_and_lpf_orders_the_reference_is_generic_in(ctx, fs, fp, nlpf):
     """Vocoder::new is generic in the frame period and the number of low-pass taps (vocoder/mod.rs:45-70; the ring
     buffer of excitation.rs:113-123 has nlpf slots).  Frame periods without a useful divisor <= 64 (75 = 3 x 25 under
