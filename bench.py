@@ -957,6 +957,38 @@ def extras_single_gpu(J, eng, tab, vi, args, batch, batch_utts, frames, ms_per_s
         eng2.close()
     except Exception as e:
         ex["config5"] = {"error": repr(e)}
+    # (5) another mel-cepstral order at the same shape (round 6): the reference is generic in the order
+    #     (vocoder/mod.rs:45-70, mlsa.rs:38-45), the throughput kernel was built for nitech's two until round 6.  An
+    #     order-49 voice (vector length 50: nitech's MCP stream widened by seeded small dimensions, synth.with_order),
+    #     1024 x 6,386 frames as 64 distinct utterances x 16 copies, state-level (the widened Gaussians are not rows
+    #     of a voice file), resident like the headline.  The order-34 figure beside it is config 4's.
+    try:
+        ex["order49"] = order_record(J, vi, R, tab, 50, 1024, 64)
+        c4 = ex.get("config4", {}).get("ms_per_step")
+        if c4:
+            ex["order49"]["vs_config4_scaled_by_order"] = ex["order49"]["ms_per_step"] / (c4 * 49.0 / 34.0)
+    except Exception as e:
+        ex["order49"] = {"error": repr(e)}
+    # (6) what the reference's bitwise-stability claim costs here (README.md:65,124; VERDICT r5 "next" 5): config 2 with
+    #     jb_engine_set_batch_invariant's flags (JB_BATCH_SERIAL | JB_BATCH_SERIAL_GV) -- every utterance one unchunked
+    #     recursion on one wave, GV sums in the reference's serial order: the same bits alone, in any batch, on any
+    #     device count.  One warm-up step and two timed ones (a step is seconds, not milliseconds).
+    try:
+        with J.Batch(vi, batch_utts, device=R.local_rank, serial=True, serial_gv=True) as bi:
+            bi.run()
+            bi.sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                bi.run()
+                bi.sync()
+            ms = (time.perf_counter() - t0) / 2 * 1e3
+            ex["batch_invariant"] = {"ms_per_step": ms, "value": bi.total_samples / (ms * 1e-3), "unit": "samples/s",
+                                     "realtime_factor": bi.total_samples / (ms * 1e-3) / vi.sampling_frequency,
+                                     "vs_headline": ms / ms_per_step, "steps": 2,
+                                     "how": "JB_BATCH_SERIAL | JB_BATCH_SERIAL_GV on the headline's batch: one wave per "
+                                            "utterance, no time-chunks; bits independent of the batch"}
+    except Exception as e:
+        ex["batch_invariant"] = {"error": repr(e)}
     return ex
 
 
@@ -1006,6 +1038,42 @@ def resident_record(J, vi, R, n_utts, tabs, weights, id0, workload, steps=6):
             "chunks_redone_last_step": info["n_redo"], "settled_at_checkpoint": redo[0], "redone_to_end": redo[1],
             "roofline": {"bound": "valu_f64", "kernel_ms": voc_ms, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS}}
+
+
+def order_record(J, vi, R, tab, nmcp, n_utts, distinct, steps=6):
+    """One resident batch of `n_utts` state-level utterances of ANOTHER mel-cepstral order (vector length nmcp),
+    `distinct` different ones tiled over the batch, timed like the headline."""
+    from jbonsai_amd import synth
+
+    pairs = [synth.with_order(vi, synth.synth_utterance(tab, CONFIG45_FRAMES, 6000 + i), nmcp, seed=300 + i)
+             for i in range(distinct)]
+    vi2 = pairs[0][0]
+    with J.Batch(vi2, [pairs[i % distinct][1] for i in range(n_utts)], device=R.local_rank) as b:
+        for _ in range(2):
+            b.run()
+            b.sync()
+        voc = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            b.run()
+            b.sync()
+            voc.append(b.last_timing()[1])
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        info, redo, ns = b.info(), b.redo_stats(), b.total_samples
+        kern, waves = b.kernel_info()
+    voc_ms = sum(voc) / len(voc)
+    # flops of V5-V9 scale with the taps: 1.35 kflop at 34 taps (SURVEY 8a) -> x (nmcp - 1) / 34
+    tflops = FLOP_PER_SAMPLE * (nmcp - 1) / 34.0 * ns / (voc_ms * 1e-3) / 1e12
+    return {"workload": f"order-{nmcp - 1} voice (nitech's MCP stream widened to {nmcp} dims): batch={n_utts} x "
+                        f"{CONFIG45_FRAMES} frames, {distinct} distinct utterances tiled, state-level, resident",
+            "batch": n_utts, "frames_per_utterance": CONFIG45_FRAMES, "nmcp": nmcp, "kernel": kern,
+            "waves_per_simd": waves, "ms_per_step": ms, "value": ns / (ms * 1e-3), "unit": "samples/s", "steps": steps,
+            "realtime_factor": ns / (ms * 1e-3) / vi.sampling_frequency, "samples_per_step": ns,
+            "vocoder_chunk_frames": info["chunk_frames"], "vocoder_work_items": info["n_items"],
+            "chunks_redone_last_step": info["n_redo"], "settled_at_checkpoint": redo[0], "redone_to_end": redo[1],
+            "roofline": {"bound": "valu_f64", "kernel_ms": voc_ms, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                         "flop_per_sample": FLOP_PER_SAMPLE * (nmcp - 1) / 34.0}}
 
 
 def run_rank(args):

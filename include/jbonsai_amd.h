@@ -497,6 +497,9 @@ int jb_device_count(void);
 /* "gfx950" etc. of device `dev` into buf. */
 int jb_device_arch(int dev, char *buf, size_t cap);
 const char *jb_version(void);
+/* The tolerance of the chunk hand-off check a batch runs with when jb_batch_opts.verify_tol is 0 (1e-9 of the largest
+ * state value): the ONE number the PCM gates of the tests and sweeps are derived from (tests/helpers.py). */
+double jb_default_verify_tol(void);
 
 #ifdef __cplusplus
 }

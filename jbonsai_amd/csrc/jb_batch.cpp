@@ -1323,7 +1323,7 @@ int Batch::build_work(const jb_batch_opts *opts)
     // that none of them fails at 18 frames is then under 0.1 %), else 18 -- small requests keep the geometry they had.
     const bool warmup_given = opts && opts->warmup_frames;
     warmup_frames = warmup_given ? opts->warmup_frames : 18;
-    verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : 1e-9;
+    verify_tol = (opts && opts->verify_tol > 0.0) ? opts->verify_tol : kDefaultVerifyTol;
     uint32_t ch = opts ? opts->chunk_frames : 0;
     // lane-triple throughput kernel: worth it once the batch holds enough frames to give every SIMD two
     // waves of 21 chunks that are long against the warm-up (measured crossover against the wave kernel at
@@ -1342,7 +1342,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         // chunk-with-warm-up at the rate a wave gets: a lone wave issues an instruction every 6-6.7 cycles, one of a
         // pair every 8.9-9.7 (tools/lt_clocks.sh); compare the two at the chunk length each would get (floor below).
         constexpr uint64_t cfloor = 16;
-        const uint64_t slots1 = 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave();
+        const uint64_t slots1 = 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave(vd.nmcp);
         auto launch_cost = [&](uint64_t slots, double us_per_sample) {
             return (double)(std::max<uint64_t>((sumT + slots - 1) / slots, cfloor) + warmup_frames) * us_per_sample;
         };
@@ -1425,7 +1425,7 @@ int Batch::build_work(const jb_batch_opts *opts)
         for (int i = 0; i < B; i++)
             it += (T[(size_t)i] + ch - 1) / ch;
         if (opts && opts->chunk_frames)
-            lt_waves_per_simd = it <= 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave() ? 1 : 2;
+            lt_waves_per_simd = it <= 64ull * 16 * (uint64_t)vocoder_ls_chunks_per_wave(vd.nmcp) ? 1 : 2;
     }
     // the checkpoint a failed chunk is first recomputed to (finish_verify): 48 frames into chunks of 96 and more, 24 into
     // chunks of 36 and more, 16 into chunks of 24 and more (a single 128 s utterance, 799 chunks of 32 frames: all six
@@ -2290,6 +2290,8 @@ using jb::PdfSet;
 extern "C" {
 
 const char *jb_last_error(void) { return jb::g_err.c_str(); }
+
+double jb_default_verify_tol(void) { return jb::kDefaultVerifyTol; }
 
 const char *jb_version(void) { return "jbonsai_amd 0.1.0 (gfx950; reference jbonsai 0.4.2)"; }
 

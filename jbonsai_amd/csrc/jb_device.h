@@ -255,6 +255,8 @@ struct VocWork {
 // per step with the first checkpoint at 32 / 40 / 48 / 56).
 // Chunks of 144 frames and more leave a SECOND checkpoint 96 frames in: the rare chunk that has not converged at
 // the first one is recomputed 48 frames further and compared again, instead of to its end (105 frames = 6.4 ms).
+// chunk hand-off check: max|state diff| <= tol * max|state| (jb_batch_opts.verify_tol = 0; jb_default_verify_tol())
+constexpr double kDefaultVerifyTol = 1e-9;
 constexpr uint32_t kVocCkptFrames = 48, kVocCkptFramesShort = 24, kVocCkptFramesTiny = 16, kVocCkpt2Frames = 96;
 
 // Timing experiments only (library built with -DJB_DBG_GATES, never the product): JB_DBG_SKIP is a bit mask of
@@ -349,7 +351,7 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
                           hipStream_t stream);
 // lane-serial throughput kernel (one chunk per lane); order_dev = launch permutation of items
 bool vocoder_ls_supported(int nmcp);
-int vocoder_ls_chunks_per_wave(); // 21 (lane triples)
+int vocoder_ls_chunks_per_wave(int nmcp); // 21 (lane triples: orders up to 34) or 12 (one stage per lane)
 // waves_per_simd: 2 = eight-wave workgroups (a whole CU), 1 = four-wave workgroups
 hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
                              const uint32_t *order_dev, uint32_t n_items, int waves_per_simd, hipStream_t stream);

@@ -817,10 +817,13 @@ static int gv_gang_capacity(int device)
     int cus = 0, per_cu = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0)
         return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mlpg_gv_gang, kGgNT, 0) != hipSuccess || per_cu <= 0)
-        return 0;
     constexpr int want = JB_GG_WPS * 256 / kGgNT; // workgroups per CU the launch bounds are for
-    if (per_cu > want)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_mlpg_gv_gang, kGgNT, 0) != hipSuccess)
+        return 0;
+    // (a process that holds TWO HIP runtimes -- this library's loaded before torch's own -- was seen to answer 0 here for
+    // every kernel, with hipSuccess, and every batch then ran the multi-launch sweeps without a word: round 6.  The
+    // launch bounds are what guarantees `want` workgroups per CU; the query is only allowed to lower that.)
+    if (per_cu <= 0 || per_cu > want)
         per_cu = want;
     cap[device] = per_cu * cus;
     return cap[device];

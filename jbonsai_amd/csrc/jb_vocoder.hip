@@ -1742,7 +1742,15 @@ __global__ __launch_bounds__(128 * ITEMS) void k_vocoder_pair(BatchDev bd, VocDe
 // per 16-lane DPP row; single-instruction asm statements; the excitation load behind a per-lane test --
 // are recorded in tools/experiments/README.md.)
 constexpr int DPP_WAVE_SHL1 = 0x130;
-constexpr int kLtChunks = 21;
+constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104;
+// sum of five adjacent lanes of a DPP row, valid on the first of them: (s0 + s1) + (s2 + s3) + s4
+__device__ __forceinline__ double fold5(double s)
+{
+    const double t1 = s + dpp_f64<DPP_ROW_SHL1>(s);
+    const double t2 = t1 + dpp_f64<DPP_ROW_SHL2>(t1);
+    return t2 + dpp_f64<DPP_ROW_SHL4>(s);
+}
+__host__ __device__ constexpr int lt_chunks(int lpc) { return lpc == 3 ? 21 : 12; } // chunks per wave
 constexpr int kLtPf = 4; // coefficient reads in flight ahead of their use (2, 3 or 4 measure the same)
 // Waves per workgroup.  EIGHT = a whole CU (two waves of 256 VGPRs per SIMD): waves w and w + 4 of a workgroup land on
 // the same SIMD, so the two waves that share a SIMD can see each other's progress in LDS.  The issue arbiter serves
@@ -1760,20 +1768,35 @@ constexpr int kLtBalance = 8;
 __device__ unsigned long long g_lt_clk[8];
 #endif
 
-template <int NM, int TPLW, int kLtWaves>
+// Every order the reference takes (round 6).  NM is the order + 1 the CODE is built for: EXACT instantiations run voices
+// of exactly that order (nitech's 35 and 25: the tuned forms, unchanged); the others run any order up to NM with the
+// taps above the voice's own held at coefficient zero (the all-pass chain goes on through them and nothing reads it:
+// same sums), the voice's order, its coefficient stride and its state layout read from `vd` at run time.
+// LPC = lanes per chunk: 3 (two stage slots per lane, 21 chunks per wave: orders up to 35, whose 2 x 34 state doubles
+// per lane fill the 256 VGPRs) or 5 (ONE stage per lane, 12 chunks per wave on lanes 0..14 of every 16-lane DPP row:
+// up to 60 state doubles per lane, orders 36..61).  Per tap a lane then issues 3 FMAs + 1 interpolation for one
+// stage where the triple issues 6 + 1 for two: the same 15 stage-taps per instruction, without the inert sixth slot
+// and with five-lane folds (row_shl 1, 2, 4) instead of three-lane ones.
+template <int NM, int TPLW_, int kLtWaves, bool EXACT = true, int LPC = 3>
 __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, VocDev vd,
                                                        const VocWork *__restrict__ work,
                                                        const uint32_t *__restrict__ order,
                                                        uint32_t n_items)
 {
-    constexpr int M = NM - 1; // live taps 1..M
-    constexpr int NS = 2;     // stage slots per lane
+    static_assert(LPC == 3 || LPC == 5, "three lanes x two stage slots, or five lanes x one");
+    constexpr int M = NM - 1;            // taps 1..M of the code
+    constexpr int NS = LPC == 3 ? 2 : 1; // stage slots per lane
+    constexpr int kLtChunks = lt_chunks(LPC);
+    const int nm = EXACT ? NM : vd.nmcp; // the voice's order + 1 (<= NM)
+    const int mreal = nm - 1;
+    const int TPLW = EXACT ? TPLW_ : (mreal + kGroups - 1) / kGroups; // taps per lane of k_vocoder's state layout
     const int lane = threadIdx.x % 64;
     const int wv = threadIdx.x / 64; // wave of the workgroup (uniform)
-    const bool idle = lane == 63;
-    // pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 63 behaves like pos 2)
-    const int pos = idle ? 2 : lane % 3;
-    const int ci = idle ? 20 : lane / 3; // chunk slot of this lane within the wave
+    // LPC 3 -- pos 0: stages 0,1; 1: stages 2,3; 2: stage 4 + inert slot (the idle lane 63 behaves like pos 2)
+    // LPC 5 -- pos = stage; lane 15 of every row idles (behaves like pos 4 of the row's last chunk)
+    const bool idle = LPC == 3 ? lane == 63 : (lane & 15) == 15;
+    const int pos = LPC == 3 ? (idle ? 2 : lane % 3) : (idle ? 4 : (lane & 15) % 5);
+    const int ci = LPC == 3 ? (idle ? 20 : lane / 3) : (lane >> 4) * 3 + (idle ? 2 : (lane & 15) / 5); // chunk slot
     const uint32_t slot = (blockIdx.x * (uint32_t)kLtWaves + (uint32_t)wv) * (uint32_t)kLtChunks + (uint32_t)ci;
     const bool has = !idle && slot < n_items;
     const bool lead = has && pos == 0;
@@ -1813,11 +1836,13 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
     const uint64_t base = has ? bd.utt[wk.utt].frame_off : 0;
     const int fp = vd.fperiod;
     const double a = vd.alpha, na = -a, iaa = 1.0 - a * a, vol = vd.volume;
-    const int s0 = 2 * pos; // first stage of this lane
+    const int s0 = NS * pos; // first stage of this lane
     // Pade weights of the two slots: stage s -> PPADE[s+1]; slot 0 (odd i) enters the
     // alternating sum with +, slot 1 (even i) with -; the inert slot has weight 0
     const double w0 = kPPade[s0 + 1];
-    const double w1 = (s0 + 1 < kPade) ? kPPade[s0 + 2] : 0.0;
+    const double w1 = (NS == 2 && s0 + 1 < kPade) ? kPPade[s0 + 2] : 0.0;
+    // (one stage per lane: stages 0, 2, 4 enter the alternating sum with +, stages 1, 3 with -)
+    const double wa = (NS == 1 && (pos & 1)) ? -w0 : w0;
 
     __shared__ double2 cc_[kLtWaves][NM - 1][kLtChunks]; // row k-1: (c_k at frame start, per-sample increment)
     __shared__ double gqs_[kLtWaves][kLtChunks];         // per-sample gain ratio exp(cinc0) of the current frame
@@ -1827,14 +1852,18 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
     // that the compiler keeps the stores of a frame's set-up between the asm-issued reads of the two frames
 #define JB_LT_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+    if (!EXACT && has) // the taps above the voice's own: coefficient zero, once
+        for (int k = nm + pos; k < NM; k += LPC)
+            cc[k - 1][ci] = make_double2(0.0, 0.0);
     double d[NS][M + 1];
     double u[NS]; // slot inputs (d22[stage])
     double gain = 1.0;
     // df1 state, spread over the triple like df2's: this lane's two stages (d11, pt1 of stages s0+1, s0+2) and the
     // input of its first one (pt1[s0]: the lead lane's is pt1[0], the others' comes from the lane before)
-    double e11[NS] = {0.0, 0.0}, e12[NS] = {0.0, 0.0}, ein = 0.0;
+    double e11[NS], e12[NS], ein = 0.0;
 #pragma unroll
     for (int q = 0; q < NS; q++) {
+        e11[q] = e12[q] = 0.0;
         u[q] = 0.0;
 #pragma unroll
         for (int j = 0; j <= M; j++)
@@ -1842,50 +1871,78 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
     }
 
     // k_vocoder state layout: tap j of stage s at [64*k + 12*s + g], j-1 = g*TPLW + k
+    // (run-time layout: the slot of a tap is walked, not divided out, behind an opaque copy of the layout's width --
+    // seen as loop invariants the 2 x M slot offsets were hoisted out of the frame loop and cost a hundred registers)
+    auto layout_tpl = [&]() {
+        int tp = TPLW;
+        if (!EXACT)
+            asm volatile("" : "+s"(tp));
+        return tp;
+    };
     if (wk.load_state) {
         const double *sp = wk.load_state;
+        const int tpl = layout_tpl();
 #pragma unroll
         for (int q = 0; q < NS; q++) {
             const int st = s0 + q;
             if (st < kPade) {
-                u[q] = sp[64 * TPLW + kGroups * st];
+                u[q] = sp[64 * tpl + kGroups * st];
+                int kk = 0, gg = 0; // (j - 1) % tpl, (j - 1) / tpl
 #pragma unroll
-                for (int j = 1; j <= M; j++)
-                    d[q][j] = sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW];
+                for (int j = 1; j <= M; j++) {
+                    if (EXACT)
+                        d[q][j] = sp[64 * ((j - 1) % TPLW_) + kGroups * st + (j - 1) / TPLW_];
+                    else if (j <= mreal)
+                        d[q][j] = sp[64 * kk + kGroups * st + gg];
+                    if (++kk == tpl) {
+                        kk = 0;
+                        gg++;
+                    }
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < NS; q++) {
             const int st = s0 + 1 + q; // df1 stage 1..5 (k_vocoder's dump: d11[i] at +64+i, pt1[i] at +70+i)
             if (st <= kPade) {
-                e11[q] = sp[64 * TPLW + 64 + st];
-                e12[q] = sp[64 * TPLW + 70 + st];
+                e11[q] = sp[64 * tpl + 64 + st];
+                e12[q] = sp[64 * tpl + 70 + st];
             }
         }
-        ein = sp[64 * TPLW + 70 + s0];
+        ein = sp[64 * tpl + 70 + s0];
     }
     auto save_state = [&](double *sp) {
+        const int tpl = layout_tpl();
 #pragma unroll
         for (int q = 0; q < NS; q++) {
             const int st = s0 + q;
             if (st < kPade) {
-                sp[64 * TPLW + kGroups * st] = u[q];
+                sp[64 * tpl + kGroups * st] = u[q];
+                int kk = 0, gg = 0;
 #pragma unroll
-                for (int j = 1; j <= M; j++)
-                    sp[64 * ((j - 1) % TPLW) + kGroups * st + (j - 1) / TPLW] = d[q][j];
+                for (int j = 1; j <= M; j++) {
+                    if (EXACT)
+                        sp[64 * ((j - 1) % TPLW_) + kGroups * st + (j - 1) / TPLW_] = d[q][j];
+                    else if (j <= mreal)
+                        sp[64 * kk + kGroups * st + gg] = d[q][j];
+                    if (++kk == tpl) {
+                        kk = 0;
+                        gg++;
+                    }
+                }
             }
         }
 #pragma unroll
         for (int q = 0; q < NS; q++) {
             const int st = s0 + 1 + q;
             if (st <= kPade) {
-                sp[64 * TPLW + 64 + st] = e11[q];
-                sp[64 * TPLW + 70 + st] = e12[q];
+                sp[64 * tpl + 64 + st] = e11[q];
+                sp[64 * tpl + 70 + st] = e12[q];
             }
         }
         if (pos == 0) {
-            sp[64 * TPLW + 64] = 0.0; // d11[0] is never written by the recursion
-            sp[64 * TPLW + 70] = ein; // pt1[0]
+            sp[64 * tpl + 64] = 0.0; // d11[0] is never written by the recursion
+            sp[64 * tpl + 70] = ein; // pt1[0]
         }
     };
 
@@ -1913,9 +1970,9 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
         // the three lanes of a triple fill every third tap
         JB_LT_FENCE();
         if (has) {
-            const double *bcur = vd.bcoef + f * (uint64_t)NM;
-            const double *bprev = (t > 0) ? bcur - NM : (vd.bfirst ? vd.bfirst + (uint64_t)wk.utt * NM : bcur);
-            for (int k = 1 + pos; k < NM; k += 3) {
+            const double *bcur = vd.bcoef + f * (uint64_t)nm;
+            const double *bprev = (t > 0) ? bcur - nm : (vd.bfirst ? vd.bfirst + (uint64_t)wk.utt * nm : bcur);
+            for (int k = 1 + pos; k < nm; k += LPC) {
                 const double c0v = bprev[k], c1v = bcur[k];
                 cc[k - 1][ci] = make_double2(c0v, (c1v - c0v) / (double)fp);
             }
@@ -1991,17 +2048,24 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
             {
                 const double2 c1p = cc[0][ci];
                 const double c1 = fma(fi, c1p.y, c1p.x);
-                e11[1] = fma(iaa, e12[0], a * e11[1]);
-                e11[0] = fma(iaa, ein, a * e11[0]);
-                e12[1] = e11[1] * c1;
-                e12[0] = e11[0] * c1;
-                // w0*pt1[s0+1] -/+ w1*pt1[s0+2], each as one product and one FMA (an instruction less than two
-                // products, a difference and a sum)
-                const double dv1 = w1 * e12[1];
-                const double da = fma(w0, e12[0], -dv1);
-                db1 = fma(w0, e12[0], dv1);
-                x += da + dpp_f64<DPP_WAVE_SHL1>(da + dpp_f64<DPP_WAVE_SHL1>(da)); // pt1[0] (valid on the lead lane)
-                const double eprev = dpp_f64<DPP_WAVE_SHR1>(e12[1]);
+                if constexpr (NS == 2) {
+                    e11[1] = fma(iaa, e12[0], a * e11[1]);
+                    e11[0] = fma(iaa, ein, a * e11[0]);
+                    e12[1] = e11[1] * c1;
+                    e12[0] = e11[0] * c1;
+                    // w0*pt1[s0+1] -/+ w1*pt1[s0+2], each as one product and one FMA (an instruction less than two
+                    // products, a difference and a sum)
+                    const double dv1 = w1 * e12[1];
+                    const double da = fma(w0, e12[0], -dv1);
+                    db1 = fma(w0, e12[0], dv1);
+                    x += da + dpp_f64<DPP_WAVE_SHL1>(da + dpp_f64<DPP_WAVE_SHL1>(da)); // pt1[0] (valid on the lead lane)
+                } else {
+                    e11[0] = fma(iaa, ein, a * e11[0]);
+                    e12[0] = e11[0] * c1;
+                    db1 = w0 * e12[0];
+                    x += fold5(wa * e12[0]); // pt1[0] (valid on the lead lane)
+                }
+                const double eprev = dpp_f64<DPP_WAVE_SHR1>(e12[NS - 1]);
                 ein = pos == 0 ? x : eprev;
             }
             // ---- V7 df2: fir() of this lane's stage slots, taps outermost (mlsa.rs:127-163) ----
@@ -2066,8 +2130,33 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
                 // loop-carried d[] (69 moves per sample, ~19 % of the VALU work); (b) around
                 // single-instruction asm statements its hazard recogniser pads with s_nop (47 per
                 // sample), inside one block the two slots are interleaved by hand instead.
-                static_assert(NS == 2, "the block below is written for two stage slots per lane");
-                {
+                if constexpr (NS == 1) {
+                    // ONE stage slot: the block of tap j is  rem' = d_j - a*rem ; y += c_(j-1) * d'_(j-1) ; d'_j = rem + a*rem'
+                    // -- the dot-product term of the tap BEFORE stands between the two dependent FMAs of this one
+                    // (a lone chain: nothing else in the lane to put there), and the last tap's term follows the loop
+                    double rn0;
+                    if (j <= 2) {
+                        asm volatile("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                            "v_fma_f64 %[d0], %[a], %[rn0], %[r0]"
+                            : [rn0] "=&v"(rn0), [d0] "+v"(d[0][j])
+                            : [na] "s"(na), [a] "s"(a), [r0] "v"(r[0]));
+                    } else if (j == 3) {
+                        asm volatile("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                            "v_mul_f64 %[y0], %[c], %[dp]\n\t"
+                            "v_fma_f64 %[d0], %[a], %[rn0], %[r0]"
+                            : [rn0] "=&v"(rn0), [d0] "+v"(d[0][j]), [y0] "=&v"(y[0])
+                            : [na] "s"(na), [a] "s"(a), [r0] "v"(r[0]), [c] "v"(cv[j - 1]), [dp] "v"(d[0][j - 1]));
+                    } else {
+                        asm volatile("v_fma_f64 %[rn0], %[na], %[r0], %[d0]\n\t"
+                            "v_fma_f64 %[y0], %[c], %[dp], %[y0]\n\t"
+                            "v_fma_f64 %[d0], %[a], %[rn0], %[r0]"
+                            : [rn0] "=&v"(rn0), [d0] "+v"(d[0][j]), [y0] "+v"(y[0])
+                            : [na] "s"(na), [a] "s"(a), [r0] "v"(r[0]), [c] "v"(cv[j - 1]), [dp] "v"(d[0][j - 1]));
+                    }
+                    r[0] = rn0;
+                    if (j == M)
+                        y[0] = fma(cj, d[0][M], y[0]);
+                } else {
                     double rn0, rn1;
                     if (j == 2) {
                         // the first term of the dot products: a product, not an FMA onto a zero that a
@@ -2107,16 +2196,23 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
             }
 #undef JB_LDS_RD
             // ---- Pade combine (mlsa.rs:71-78): partial sums per lane, gathered on the lead lane ----
-            const double v1 = w1 * y[1];
-            const double sb = fma(w0, y[0], v1), sa = fma(w0, y[0], db1 - v1); // (df1's plain sum rides on df2's alternating one)
-            // fold position 2 into 1, then 1 into 0: sum(pos 0) = s0 + (s1 + s2)
-            const double ssum = sa + dpp_f64<DPP_WAVE_SHL1>(sa + dpp_f64<DPP_WAVE_SHL1>(sa));
-            const double psum = sb + dpp_f64<DPP_WAVE_SHL1>(sb + dpp_f64<DPP_WAVE_SHL1>(sb));
-            const double yprev = dpp_f64<DPP_WAVE_SHR1>(y[1]); // previous lane's second stage
+            double ssum, psum;
+            if constexpr (NS == 2) {
+                const double v1 = w1 * y[1];
+                const double sb = fma(w0, y[0], v1), sa = fma(w0, y[0], db1 - v1); // (df1's plain sum rides on df2's alternating one)
+                // fold position 2 into 1, then 1 into 0: sum(pos 0) = s0 + (s1 + s2)
+                ssum = sa + dpp_f64<DPP_WAVE_SHL1>(sa + dpp_f64<DPP_WAVE_SHL1>(sa));
+                psum = sb + dpp_f64<DPP_WAVE_SHL1>(sb + dpp_f64<DPP_WAVE_SHL1>(sb));
+            } else {
+                ssum = fold5(fma(wa, y[0], db1));
+                psum = fold5(w0 * y[0]);
+            }
+            const double yprev = dpp_f64<DPP_WAVE_SHR1>(y[NS - 1]); // previous lane's last stage
             const double xmid = x + ssum; // d22[0] (valid on the lead lane)
             x = xmid + psum;
             // next-sample slot inputs: stage s+1 <- y of stage s; stage 0 <- xmid
-            u[1] = y[0];
+            if constexpr (NS == 2)
+                u[1] = y[0];
             u[0] = pos == 0 ? xmid : yprev;
             const double pv = x * vol;
             if (ODD)
@@ -2415,37 +2511,58 @@ hipError_t launch_voc_verify_pairs(const double *const *pairs_dev, uint32_t n_pa
     return hipGetLastError();
 }
 
-bool vocoder_ls_supported(int nmcp) { return nmcp == 35 || nmcp == 25; }
+// The code an order runs on: its own for nitech's two (35, 25: the EXACT instantiations), else the next of
+// {25, 31, 35} as lane triples or of {41, 51, 61} with one stage per lane, the taps above the voice's own at coefficient
+// zero (an order-39 voice pays for 40 taps, an order-49 voice for 50).  Orders below 6 stay with the wave kernels.
+static int lt_code_nm(int nmcp)
+{
+    for (int c : {25, 31, 35, 41, 51, 61})
+        if (nmcp <= c)
+            return c;
+    return 0;
+}
+bool vocoder_ls_supported(int nmcp) { return nmcp >= 7 && lt_code_nm(nmcp) != 0; }
 
-int vocoder_ls_chunks_per_wave() { return kLtChunks; }
+int vocoder_ls_chunks_per_wave(int nmcp) { return lt_chunks(lt_code_nm(nmcp) <= 35 ? 3 : 5); }
 
 hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork *work_dev,
                              const uint32_t *order_dev, uint32_t n_items, int waves_per_simd, hipStream_t stream)
 {
     if (n_items == 0)
         return hipSuccess;
-    if (waves_per_simd != 1 && waves_per_simd != 2)
+    if ((waves_per_simd != 1 && waves_per_simd != 2) || !vocoder_ls_supported(vd.nmcp))
         return hipErrorInvalidValue;
     const int wv = 4 * waves_per_simd;
-    const uint32_t per_wg = (uint32_t)(kLtChunks * wv);
+    const int code = lt_code_nm(vd.nmcp);
+    const bool exact = vd.nmcp == 35 || vd.nmcp == 25;
+    const uint32_t per_wg = (uint32_t)(vocoder_ls_chunks_per_wave(vd.nmcp) * wv);
     dim3 grid((n_items + per_wg - 1) / per_wg), block(64 * wv);
-    const int key = vd.nmcp * 10 + wv;
-    switch (key) {
-    case 358:
-        hipLaunchKernelGGL((k_vocoder_lt<35, 3, 8>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-        break;
-    case 354:
-        hipLaunchKernelGGL((k_vocoder_lt<35, 3, 4>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-        break;
-    case 258:
-        hipLaunchKernelGGL((k_vocoder_lt<25, 2, 8>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-        break;
-    case 254:
-        hipLaunchKernelGGL((k_vocoder_lt<25, 2, 4>), grid, block, 0, stream, bd, vd, work_dev, order_dev, n_items);
-        break;
-    default:
-        return hipErrorInvalidValue;
-    }
+#define JB_LT_LAUNCH(NMc, TPLc, EX, LPCc)                                                                              \
+    do {                                                                                                           \
+        if (wv == 8)                                                                                               \
+            hipLaunchKernelGGL((k_vocoder_lt<NMc, TPLc, 8, EX, LPCc>), grid, block, 0, stream, bd, vd, work_dev,      \
+                               order_dev, n_items);                                                                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_vocoder_lt<NMc, TPLc, 4, EX, LPCc>), grid, block, 0, stream, bd, vd, work_dev,      \
+                               order_dev, n_items);                                                                \
+    } while (0)
+    if (exact && code == 35)
+        JB_LT_LAUNCH(35, 3, true, 3);
+    else if (exact && code == 25)
+        JB_LT_LAUNCH(25, 2, true, 3);
+    else if (code == 25)
+        JB_LT_LAUNCH(25, 2, false, 3);
+    else if (code == 31)
+        JB_LT_LAUNCH(31, 3, false, 3);
+    else if (code == 35)
+        JB_LT_LAUNCH(35, 3, false, 3);
+    else if (code == 41)
+        JB_LT_LAUNCH(41, 4, false, 5);
+    else if (code == 51)
+        JB_LT_LAUNCH(51, 5, false, 5);
+    else
+        JB_LT_LAUNCH(61, 5, false, 5);
+#undef JB_LT_LAUNCH
 #ifdef JB_LT_CLOCKS
     {
         unsigned long long c[8];

@@ -181,3 +181,30 @@ def mixed_lengths(n: int, lo: int = 400, hi: int = T_128S, seed: int = 3) -> Lis
     """Config 3 lengths: T_b ~ round(U[lo, hi]) frames, seed-fixed."""
     rng = SplitMix64(SEED ^ (seed << 32))
     return [lo + rng.below(hi - lo + 1) for _ in range(n)]
+
+
+def with_order(vi, u: Utterance, nmcp: int, seed: int = 7):
+    """(voice info, utterance) of ANOTHER mel-cepstral order (vector length `nmcp` = order + 1): the MCP stream of a
+    state-level utterance cut to `nmcp` dimensions per window, or widened by small seeded dimensions -- the
+    reference is generic in the order (vocoder/mod.rs:45-70, mlsa.rs:38-45), the voices at hand are not (nitech: 35).
+    What tests and bench.py's `order49` record run the other instantiations of the throughput kernel on."""
+    import dataclasses
+
+    rng = np.random.default_rng(seed)
+    L, W = vi.streams[0].vector_length, len(vi.streams[0].windows)
+    m0, S = u.streams[0], len(u.durations)
+
+    def reshape(a, fill):
+        a = np.asarray(a).reshape(S, W, L)
+        if nmcp <= L:
+            return a[:, :, :nmcp].reshape(S, W * nmcp).copy()
+        return np.concatenate([a, fill((S, W, nmcp - L))], axis=2).reshape(S, W * nmcp)
+
+    mean = reshape(m0.mean, lambda sh: 0.02 * rng.standard_normal(sh))
+    var = reshape(m0.var, lambda sh: 0.01 + 0.01 * rng.random(sh))
+    gvm = m0.gv_mean[:nmcp] if nmcp <= L else np.concatenate([m0.gv_mean, np.full(nmcp - L, 4e-4)])
+    gvv = m0.gv_var[:nmcp] if nmcp <= L else np.concatenate([m0.gv_var, np.full(nmcp - L, 1e-8)])
+    s0 = dataclasses.replace(m0, mean=mean, var=var, gv_mean=gvm, gv_var=gvv)
+    st0 = dataclasses.replace(vi.streams[0], vector_length=nmcp)
+    return (dataclasses.replace(vi, streams=[st0] + list(vi.streams[1:])),
+            Utterance(u.durations, [s0] + list(u.streams[1:])))

@@ -32,6 +32,10 @@ def test_binding_lists_every_symbol():
 def test_version_and_no_gpu_error_path():
     L = J.lib()
     assert b"gfx950" in L.jb_version()
+    from tests.helpers import PCM_TOL, VERIFY_TOL
+
+    # the ONE tolerance of the PCM gates (tests/helpers.py) is the library's own hand-off tolerance
+    assert L.jb_default_verify_tol() == VERIFY_TOL and PCM_TOL == 2 * VERIFY_TOL
     assert L.jb_device_count() >= 0
 
 

@@ -24,11 +24,10 @@ from oracle import oracle as O
 from tests.conftest import VOICE
 from tests.golden.labels import BENCH_LETTER, GENJI, label_pool_utterances
 from tests.golden.make_permuted_voice import permuted_voice_path
-from tests.helpers import rel_rms
+from tests.helpers import rel_rms, PCM_TOL
 from tests.test_gpu_configs import oracle_pcm
 
 pytestmark = pytest.mark.gpu
-PCM_TOL = 1e-9
 B = 1024
 W_REF = {"duration": [0.7, 0.3], "parameter": [[0.7, 0.3], [0.7, 0.3], [1.0, 0.0]],
          "gv": [[0.7, 0.3], [0.7, 0.3], [1.0, 0.0]]}

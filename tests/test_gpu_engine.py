@@ -9,7 +9,7 @@ import pytest
 import jbonsai_amd as J
 from tests.conftest import VOICE
 from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
-from tests.helpers import rel_rms
+from tests.helpers import PCM_TOL, rel_rms
 
 pytestmark = pytest.mark.gpu
 EPS = 1e-8
@@ -254,7 +254,7 @@ def test_engine_beta_postfilter(oracle_voice):
     want = oracle_voice.synthesize(SAMPLE_SENTENCE_1, beta=0.3)
     assert len(got) == len(want) == 66480
     den = np.sqrt(np.mean(want * want))
-    assert np.sqrt(np.mean((got - want) ** 2)) / den <= 1e-9
+    assert np.sqrt(np.mean((got - want) ** 2)) / den <= PCM_TOL
 
 
 def test_synthesize_batch_i16_and_staged_readback(engine):

@@ -10,10 +10,9 @@ import pytest
 import jbonsai_amd as J
 from oracle import oracle as O
 from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
-from tests.helpers import oracle_run, oracle_states, rel_rms, to_utt, voice_info
+from tests.helpers import oracle_run, oracle_states, rel_rms, to_utt, voice_info, PCM_TOL
 
 pytestmark = pytest.mark.gpu
-PCM_TOL = 1e-9
 
 
 def _perturbed(sts, mode, seed=5):

@@ -13,12 +13,11 @@ import pytest
 import jbonsai_amd as J
 from oracle import oracle as O
 from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
-from tests.helpers import oracle_run, oracle_states, rel_rms, to_utt, voice_info
+from tests.helpers import oracle_run, oracle_states, rel_rms, to_utt, voice_info, PCM_TOL
 
 pytestmark = pytest.mark.gpu
 
 COEF_TOL = 1e-12
-PCM_TOL = 1e-9
 
 
 def mc2b(c, a):

@@ -12,11 +12,10 @@ from jbonsai_amd import synth
 from oracle import oracle as O
 from tests.conftest import VOICE
 from tests.golden.labels import ALIGNED_1, SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
-from tests.helpers import rel_rms
+from tests.helpers import rel_rms, PCM_TOL, VERIFY_TOL
 from tests.test_gpu_configs import oracle_pcm
 
 pytestmark = pytest.mark.gpu
-PCM_TOL = 1e-9
 
 
 @pytest.fixture(scope="module")
@@ -220,9 +219,9 @@ def test_recertification_after_full_redo(long_utt, kern):
     assert info["n_redo"] >= 50
     assert err <= 1e-12
     # the default tolerance bounds it as well, at its own level
-    with J.Batch(vi, [u], chunk_frames=16, warmup_frames=6, verify_tol=1e-9, kernel=kern) as b:
+    with J.Batch(vi, [u], chunk_frames=16, warmup_frames=6, verify_tol=VERIFY_TOL, kernel=kern) as b:
         b.run()
-        assert rel_rms(b.pcm(0), ser) <= 1e-9
+        assert rel_rms(b.pcm(0), ser) <= PCM_TOL
 
 
 def test_repeated_runs_of_a_batch_with_failing_handoffs(ctx, long_utt):
@@ -233,7 +232,7 @@ def test_repeated_runs_of_a_batch_with_failing_handoffs(ctx, long_utt):
     _, u0 = long_utt
     utts = [u0] + [synth.synth_utterance(tab, 3000, 60 + i) for i in range(3)]
     for cf, wf in ((16, 6), (160, 6)):
-        with J.Batch(vi, utts, chunk_frames=cf, warmup_frames=wf, verify_tol=1e-9, kernel="triple") as b:
+        with J.Batch(vi, utts, chunk_frames=cf, warmup_frames=wf, verify_tol=VERIFY_TOL, kernel="triple") as b:
             seen = []
             for _ in range(3):
                 b.run()
@@ -250,7 +249,7 @@ def test_read_entries_order_behind_the_run(ctx):
     streams and for the certification + redo, so it returns the finished result."""
     eng, tab, vi = ctx
     utts = [synth.synth_utterance(tab, 4000, 90 + i) for i in range(8)]
-    with J.Batch(vi, utts, chunk_frames=64, warmup_frames=4, verify_tol=1e-9) as b:
+    with J.Batch(vi, utts, chunk_frames=64, warmup_frames=4, verify_tol=VERIFY_TOL) as b:
         b.run()
         first = b.pcm(7)  # no sync() before
         assert b.info()["n_redo"] > 0

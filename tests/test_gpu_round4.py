@@ -14,7 +14,7 @@ import jbonsai_amd as J
 from oracle import oracle as O
 from tests.conftest import VOICE
 from tests.golden.labels import BENCH_LETTER, SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
-from tests.helpers import rel_rms, voice_info
+from tests.helpers import rel_rms, voice_info, PCM_TOL
 
 pytestmark = pytest.mark.gpu
 NODATA = -1e10
@@ -52,7 +52,7 @@ def test_generator_from_tracks_streams_the_oracles_audio(oracle_voice, vi):
     rest = g.generate_all()
     out[n * fp:] = rest
     assert g.generate_step(buf) == 0 and g.synthesized_frames() == g.total_frames()
-    assert rel_rms(out, ref) <= 1e-9
+    assert rel_rms(out, ref) <= PCM_TOL
     with pytest.raises(J.JbError):  # "The length of speech buffer must be larger than fperiod."
         J.generator_from_tracks(vi, tu).generate_step(np.zeros(fp - 1))
     g.close()
@@ -99,7 +99,7 @@ def test_vocoder_level_entry_without_ring_buffer(oracle_voice, vi):
     got = J.vocoder_synthesize_batch(v0, utts)
     for (name, lf0), g in zip(pats.items(), got):
         ref = O.vocoder(vi.sampling_frequency, vi.fperiod, vi.alpha, 1.0, lf0, tu.spectrum, None)
-        assert len(g) == len(ref) and rel_rms(g, ref) <= 1e-9, name
+        assert len(g) == len(ref) and rel_rms(g, ref) <= PCM_TOL, name
     # with a ring buffer the same entry equals the SpeechGenerator one
     a = J.vocoder_synthesize_batch(vi, [tu])[0]
     b = J.vocode_tracks_batch(vi, [tu])[0]
@@ -116,7 +116,7 @@ def test_vocoder_level_entry_without_ring_buffer(oracle_voice, vi):
         te = J.TrackUtterance(tu.spectrum, tu.lf0, np.ascontiguousarray(tu.lpf[:, :ne]))
         g = J.vocoder_synthesize_batch(ve, [te])[0]
         ref = O.vocoder(vi.sampling_frequency, vi.fperiod, vi.alpha, 1.0, tu.lf0[:, 0], tu.spectrum, te.lpf)
-        assert len(g) == len(ref) and rel_rms(g, ref) <= 1e-9, ne
+        assert len(g) == len(ref) and rel_rms(g, ref) <= PCM_TOL, ne
         with pytest.raises(J.JbError) as ei:
             J.vocode_tracks_batch(ve, [te])
         assert ei.value.code == -1 and "odd numbers" in str(ei.value)
@@ -139,5 +139,5 @@ def test_generator_serves_no_frame_of_a_timed_out_gv(oracle_voice):
         assert g.generate_step(buf) == fp
         out[k * fp:(k + 1) * fp] = buf
     out[6 * fp:] = g.generate_all()
-    assert rel_rms(out, ref) <= 1e-9
+    assert rel_rms(out, ref) <= PCM_TOL
     assert rel_rms(out[:6 * fp], ref[:6 * fp]) <= 1e-8

@@ -11,7 +11,7 @@ import jbonsai_amd as J
 from jbonsai_amd import synth
 from tests.conftest import VOICE
 from tests.golden.labels import SAMPLE_SENTENCE_1, SAMPLE_SENTENCE_2
-from tests.helpers import rel_rms
+from tests.helpers import rel_rms, VERIFY_TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -104,7 +104,7 @@ def test_two_wave_vocoder_equals_the_wave_kernel_bit_for_bit(monkeypatch):
         a, b = both(lambda: eng.synthesize(lab))
         assert len(a) > 0 and np.array_equal(a, b)
     utts = [synth.synth_utterance(tab, T, 40 + T) for T in (300, 1, 77, 512, 150)]
-    for kw in (dict(), dict(serial=True), dict(chunk_frames=24, warmup_frames=2, verify_tol=1e-9), dict(pcm_i16=True),
+    for kw in (dict(), dict(serial=True), dict(chunk_frames=24, warmup_frames=2, verify_tol=VERIFY_TOL), dict(pcm_i16=True),
                dict(chunk_frames=16, kernel="wave")):
         def run():
             with J.Batch(vi, utts, **kw) as bt:

@@ -9,7 +9,7 @@ import jbonsai_amd as J
 from jbonsai_amd import synth
 from oracle import oracle as O
 from tests.conftest import VOICE
-from tests.helpers import rel_rms
+from tests.helpers import rel_rms, PCM_TOL, VERIFY_TOL
 
 pytestmark = pytest.mark.gpu
 DMAX = 1.7976931348623157e308
@@ -110,7 +110,7 @@ def test_stage_nonzero_vs_oracle(ctx, stage, log_gain, beta):
         e3 = rel_rms(got[i], ref)
         print("stage", stage, "log gain", log_gain, "beta", beta, "utt", i, "filter on same coefficients", e1,
               "coefficients", e2, "end to end", e3)
-        assert e1 <= 1e-9
+        assert e1 <= PCM_TOL
         assert e2 <= 1e-6 and np.abs(first[i] - w0).max() <= 1e-6 * np.abs(w0).max()
         assert e3 <= 1e-4
 
@@ -123,7 +123,7 @@ def test_stage_nonzero_chunked_serial_and_redo(ctx):
     u = stable_utterance(tab, vi, v2, 1500, 950, 2, False, 0.0)
     outs = {}
     for name, kw in (("serial", dict(serial=True)), ("default", dict()),
-                     ("redo", dict(chunk_frames=64, warmup_frames=1, verify_tol=1e-9))):
+                     ("redo", dict(chunk_frames=64, warmup_frames=1, verify_tol=VERIFY_TOL))):
         with J.Batch(v2, [u, u], **kw) as b:
             b.run()
             b.sync()
@@ -131,7 +131,7 @@ def test_stage_nonzero_chunked_serial_and_redo(ctx):
     assert outs["redo"][2]["n_redo"] > 10
     for name in ("default", "redo"):
         assert np.array_equal(outs[name][0], outs[name][1])
-        assert rel_rms(outs[name][0], outs["serial"][0]) <= 1e-9, name
+        assert rel_rms(outs[name][0], outs["serial"][0]) <= PCM_TOL, name
     ref, _ = oracle_stage_pcm(v2, u, 2, False, 0.0)
     assert rel_rms(outs["serial"][0], ref) <= 1e-4  # end to end: the conversion's conditioning (above)
 
@@ -161,8 +161,8 @@ def test_stage_above_eight_generic_kernel(ctx, stage, log_gain):
                          stage=stage, use_log_gain=log_gain, coef=coef[i], cfirst=first[i])
         assert len(outs["serial"][i]) == len(ref) and np.all(np.isfinite(ref)) and np.max(np.abs(ref)) > 0
         sc = 1.0 / np.max(np.abs(ref))  # (squares of 1e210 are not doubles)
-        assert rel_rms(outs["serial"][i] * sc, same * sc) <= 1e-9
-        assert rel_rms(outs["chunked"][i] * sc, outs["serial"][i] * sc) <= 1e-9
+        assert rel_rms(outs["serial"][i] * sc, same * sc) <= PCM_TOL
+        assert rel_rms(outs["chunked"][i] * sc, outs["serial"][i] * sc) <= PCM_TOL
         assert rel_rms(outs["serial"][i] * sc, ref * sc) <= 1e-4
 
 

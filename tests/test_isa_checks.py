@@ -56,7 +56,9 @@ def test_vocoder_lt_asm_loads_are_untouched_until_their_wait(tmp_path):
                     "--cuda-device-only", "-S", str(src), "-o", str(out)], check=True, capture_output=True,
                    cwd=src.parent)
     res = _checker().check(out.read_text())
-    assert len(res) == 4, list(res)  # k_vocoder_lt<35,3,W> and <25,2,W>, W = 8 and 4 waves per workgroup
+    # the two exact forms (35, 25) + the three lane-triple codes (25, 31, 35) and the three one-stage-per-lane codes
+    # (41, 51, 61) that run every other order, each at W = 8 and 4 waves per workgroup
+    assert len(res) == 16, list(res)
     for k, (n, viol) in res.items():
         assert n == 3, (k, n)       # the first odd request, then one request per even / odd sample
         assert not viol, (k, viol)

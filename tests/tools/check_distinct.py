@@ -10,6 +10,7 @@ import jbonsai_amd as J  # noqa: E402
 from jbonsai_amd import synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from tests.conftest import VOICE  # noqa: E402
+from tests.helpers import PCM_TOL  # noqa: E402
 from tests.test_gpu_configs import oracle_pcm  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -25,5 +26,5 @@ with J.Batch(vi, utts) as b:
         got = b.pcm(i)
         e = float(np.sqrt(np.mean((got - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))
         print(f"utterance {i}: rel RMS vs oracle {e:.3e}")
-        assert e <= 1e-9
+        assert e <= PCM_TOL
 print("ok")

@@ -41,6 +41,7 @@ def main():
     import jbonsai_amd as J
     from jbonsai_amd import synth
     from tests.conftest import VOICE
+    from tests.helpers import EXC_TOL, PCM_TOL
 
     eng = J.Engine.load([VOICE])
     tab = synth.VoiceTables(eng)
@@ -80,12 +81,12 @@ def main():
     print(f"{a.n} utterances of {min(lens)}..{max(lens)} frames ({sum(lens)} frames, {sum(lens) * vi.fperiod / vi.sampling_frequency:.0f} s of"
           f" audio) as one ragged batch: {kern[0]}, chunk {info['chunk_frames']} frames,"
           f" {info['n_items']} chunks, {info['n_redo']} redone; oracle on {a.procs} processes; {t1 - t0:.1f} s wall")
-    print(f"PCM relative RMS vs oracle: max {rel.max():.3e}  median {np.median(rel):.3e}  (gate 1e-9; north_star 1e-4)")
-    print(f"excitation max |delta|:     max {exc_abs.max():.3e}  median {np.median(exc_abs):.3e}  (gate 1e-9)")
+    print(f"PCM relative RMS vs oracle: max {rel.max():.3e}  median {np.median(rel):.3e}  (gate {PCM_TOL:g}; north_star 1e-4)")
+    print(f"excitation max |delta|:     max {exc_abs.max():.3e}  median {np.median(exc_abs):.3e}  (gate {EXC_TOL:g})")
     print(f"pulses: {pulses} on the oracle's samples, {bad_pulse} off")
     worst = int(np.argmax(rel))
     print(f"worst utterance: #{worst}, {lens[worst]} frames, rel RMS {rel[worst]:.3e}")
-    ok = rel.max() <= 1e-9 and exc_abs.max() <= 1e-9 and bad_pulse == 0
+    ok = rel.max() <= PCM_TOL and exc_abs.max() <= EXC_TOL and bad_pulse == 0
     print("PARITY GREEN" if ok else "PARITY RED")
     sys.exit(0 if ok else 1)
 

@@ -28,6 +28,7 @@ def main():
     from jbonsai_amd import synth
     from oracle import oracle as O
     from tests.conftest import VOICE
+    from tests.helpers import PCM_TOL, VERIFY_TOL
 
     eng = J.Engine.load([VOICE])
     tab = synth.VoiceTables(eng)
@@ -46,7 +47,7 @@ def main():
         beta = float(rng.choice([0.0, 0.0, 0.0, 0.2, 0.5]))
         volume = float(rng.choice([1.0, 0.5, 1.7]))
         kw = [dict(), dict(), dict(serial=True), dict(chunk_frames=32, kernel="triple"), dict(chunk_frames=16, kernel="wave"),
-              dict(chunk_frames=24, warmup_frames=6, verify_tol=1e-9)][int(rng.integers(0, 6))]
+              dict(chunk_frames=24, warmup_frames=6, verify_tol=VERIFY_TOL)][int(rng.integers(0, 6))]
         lens = [int(x) for x in rng.integers(1, 500, size=3)]
         utts = []
         for k, T in enumerate(lens):
@@ -106,14 +107,14 @@ def main():
                 continue  # (an unstable filter on both sides says nothing)
             if e > worst[0]:
                 worst = (e, desc)
-            above += e > 1e-9
-            # what the certification bounds is the filter STATE at a hand-off (verify_tol = 1e-9 relative); the PCM behind
-            # it can carry a few times that while the difference decays (strong post-filter, high order): gate 1e-8,
-            # and the count above the tests' 1e-9 is printed
-            if not e <= 1e-8:
+            above += e > VERIFY_TOL
+            # what the certification bounds is the filter STATE at a hand-off (VERIFY_TOL, relative); the PCM behind it
+            # can carry a little more while the difference decays (strong post-filter, high order): the gate is the
+            # tests' own, PCM_TOL = 2 x VERIFY_TOL (tests/helpers.py); the count above VERIFY_TOL itself is printed
+            if not e <= PCM_TOL:
                 fails.append((case, desc, f"rel RMS {e:.3e} at {T} frames"))
     print(f"{a.n} random shape combinations x 3 utterances against the oracle in {time.perf_counter() - t0:.0f} s; kernels: {hist}")
-    print(f"worst relative RMS {worst[0]:.3e}  ({worst[1]})   gate 1e-8; {above} of {3 * a.n} utterances above 1e-9")
+    print(f"worst relative RMS {worst[0]:.3e}  ({worst[1]})   gate {PCM_TOL:g} (tests/helpers.py); {above} of {3 * a.n} utterances above {VERIFY_TOL:g}")
     for f in fails[:20]:
         print("FAIL", f)
     print("PARITY GREEN" if not fails else f"PARITY RED: {len(fails)} failures")
