@@ -82,7 +82,7 @@ def parse_args():
                     help="after the timed steps, gather every rank's PCM slab to rank 0 with RCCL "
                          "(point-to-point over xGMI): the 16-bit slab (a quarter of the bytes: at N = 8 the f64 "
                          "slabs are 88 GB into the root per step, more than its seven links carry in a step), alone "
-                         "(gather_ms) and beside the next step on two alternating batches "
+                         "(gather_i16_ms / gather_f64_ms) and beside the next step on two alternating batches "
                          "(gather_overlapped_ms_per_step); never part of `value` (SURVEY 8e)")
     ap.add_argument("--gather-f64", action="store_true", help="gather the f64 slabs instead (link-bound at N = 8)")
     ap.add_argument("--beta", type=float, default=0.0,
@@ -538,7 +538,8 @@ def roofline_block(samples_per_launch, voc_ms, info, batch, frames):
         "kernel_ms": voc_ms, "alg_flop_per_sample": FLOP_PER_SAMPLE, "path_flop_per_sample": PATH_FLOP_PER_SAMPLE,
         "note": "recursive IIR: bound by FP64 VALU issue, not by HBM (DESIGN.md section 4); achieved = useful f64 "
                 "flops of what this kernel computes (V5-V9 of SURVEY 8a: 1.35 kflop per output sample; the whole "
-                "path is 1.39) / kernel time",
+                "path is 1.39) / kernel time.  Flop basis: rounds 1-4 priced this figure with 1.39 kflop (the path's), "
+                "round 5 on with 1.35 (the kernel's): 3 % lower at the same kernel time",
         "sq_counters": sqrec,
         "traffic": traffic, "traffic_source": tr_src,
         "traffic_fetch_raw": tr.get("fetch_bytes_raw") if tr is not None else None,
@@ -1206,7 +1207,9 @@ def run_rank(args):
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
             "realtime_factor": value / vi.sampling_frequency,
-            **({"gather_ms": gather_ms, "gather_overlapped_ms_per_step": gather_ovl, "gather_dtype": gather_dtype,
+            # (the key carries the slab's type since round 6: rounds 1-4 reported the f64 slab of the timed batch as
+            #  `gather_ms`, round 5 the 16-bit slab of a fresh pair under the same key -- not comparable: ADVICE r5)
+            **({f"gather_{gather_dtype}_ms": gather_ms, "gather_overlapped_ms_per_step": gather_ovl, "gather_dtype": gather_dtype,
                 "gather_bytes_into_root": (R.world - 1) * samples_per_step * (8 if gather_dtype == "f64" else 2)}
                if gather_ms is not None else {}),
             "roofline": roofline_block(samples_per_step, voc_avg_ms, info, args.batch, frames),

@@ -449,6 +449,10 @@ typedef struct jb_states jb_states;
 int jb_engine_states(const jb_engine *e, const char *const *label_lines, size_t n_lines,
                      jb_states **out);
 const jb_state_utt *jb_states_utt(const jb_states *s);
+/* Models::duration() (src/model/mod.rs:80-92): the (mean, variance) pairs the durations were estimated from, blended
+ * over the voices with the duration weights -- [num_states][2] doubles owned by the handle (NULL for no states).
+ * What the reference's `multiple_models` test pins for two voices (src/model/mod.rs:395-428). */
+const double *jb_states_duration_params(const jb_states *s);
 const jb_voice_desc *jb_engine_voice_desc(const jb_engine *e);
 void jb_states_free(jb_states *s);
 

@@ -152,7 +152,7 @@ SYMBOLS = [
     "jb_comm_unique_id", "jb_comm_init", "jb_comm_rank", "jb_comm_size", "jb_comm_free", "jb_gather_pcm",
     "jb_gathered_samples", "jb_gathered_sample_bytes", "jb_gathered_device", "jb_gathered_read", "jb_gathered_free",
     "jb_lpt_partition", "jb_paramgen_vocode_batch_multi", "jb_synthesize_batch_multi", "jb_synthesize_batch_i16_multi",
-    "jb_last_error", "jb_device_count", "jb_device_arch", "jb_version", "jb_default_verify_tol",
+    "jb_states_duration_params", "jb_last_error", "jb_device_count", "jb_device_arch", "jb_version", "jb_default_verify_tol",
 ]
 
 

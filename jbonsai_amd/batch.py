@@ -143,10 +143,9 @@ class IndexStreamStates:
         self.gv_switch = f(self.gv_switch, np.uint8)
 
     def __setattr__(self, name, value):
-        # every assignment bumps a version: an IndexUtterance that has marshalled this stream marshals it again
-        # (replacing an ELEMENT of `rows` in place is not seen: assign the list)
+        # (an IndexUtterance that has marshalled this stream keys its cached struct on the identity of every array it
+        # points into: any replacement, of a field or of an element of `rows`, makes it marshal again)
         object.__setattr__(self, name, value)
-        object.__setattr__(self, "_version", self.__dict__.get("_version", 0) + 1)
 
 
 @dataclass
@@ -162,10 +161,17 @@ class IndexUtterance:
         # marshalled once per object (the struct only points into arrays this object owns; an utterance is not
         # edited after its first use): a job that creates its batches again every pass -- bench.py's config-3
         # job -- spent 12 of the 27 ms of a 512-utterance creation building these
-        # -- until one is: assigning a field of the utterance or of one of its streams drops the cached struct
-        ver = sum(st.__dict__.get("_version", 0) for st in self.streams)
+        # -- until one is.  The cached struct is valid for exactly the arrays it points into: the key is the identity
+        # of every array (and the value of every scalar) placed in it, and the arrays are kept referenced beside it,
+        # so that replacing an element in place (u.streams[i] = other, st.rows[v] = new) can neither leave the struct
+        # pointing into freed memory nor go unseen (a sum of version counters missed both)
+        arrays = [self.durations]
+        for s in self.streams:
+            arrays += list(s.rows) + [s.weights, s.gv_mean, s.gv_var, s.gv_switch]
+        key = (tuple(id(a) for a in arrays), self.lf0_offset,
+               tuple((s.gv_weight, s.msd_threshold) for s in self.streams))
         c = self.__dict__.get("_c")
-        if c is not None and self.__dict__.get("_c_ver") == ver:
+        if c is not None and self.__dict__.get("_c_key") == key:
             return c
         u = F.IndexUtt()
         u.num_states = len(self.durations)
@@ -180,7 +186,8 @@ class IndexUtterance:
             d.gv_switch = s.gv_switch.ctypes.data_as(C.POINTER(C.c_uint8)) if s.gv_switch is not None else None
             d.gv_weight, d.msd_threshold = s.gv_weight, s.msd_threshold
         self.__dict__["_c"] = u
-        self.__dict__["_c_ver"] = ver
+        self.__dict__["_c_key"] = key
+        self.__dict__["_c_arrays"] = arrays  # what the struct points into stays alive as long as the struct
         return u
 
     def __setattr__(self, name, value):

@@ -490,7 +490,7 @@ int Batch::upload(const void *host, size_t bytes, const void **dev)
             return hip_fail(e, "hipMemcpy(H2D)");
     } else {
         const size_t need = (bytes + 255) / 256 * 256;
-        if (up_chunks.empty() || up_chunks.back().used + need > kChunk) {
+        if (up_chunks.empty() || !up_chunks.back().host.get() || up_chunks.back().used + need > kChunk) {
             UploadChunk c;
             if ((rc = dalloc(&c.dev, kChunk, false)))
                 return rc;
@@ -528,7 +528,8 @@ template <class T> int Batch::stage(const T *host, size_t n, T **dev)
         return JB_OK;
     }
     const size_t need = (bytes + 255) / 256 * 256;
-    if (up_chunks.empty() || up_chunks.back().used + need > kChunk) {
+    // (a chunk whose host buffer create() has already given back takes no more bytes: ADVICE r5)
+    if (up_chunks.empty() || !up_chunks.back().host.get() || up_chunks.back().used + need > kChunk) {
         UploadChunk c;
         int rc = dalloc(&c.dev, kChunk, false);
         if (rc)
@@ -551,6 +552,10 @@ int Batch::flush_uploads()
 {
     for (UploadChunk &c : up_chunks) {
         if (c.used > c.sent) {
+            if (!c.host.get()) {
+                set_error("upload arena: bytes queued in a chunk without a host buffer");
+                return JB_ERR_DEVICE;
+            }
             hipError_t e = hipMemcpy(c.dev + c.sent, c.host.get() + c.sent, c.used - c.sent, hipMemcpyHostToDevice);
             if (e != hipSuccess)
                 return hip_fail(e, "hipMemcpy(H2D arena)");
@@ -2062,7 +2067,7 @@ int Batch::sync()
                         "%.0f) step %.0f store %.0f\n",
                         c.prof[0] / nb, c.prof[1] / nb, c.prof[2] / nb, c.prof[3] / nb, c.prof[6] / nb, c.prof[4] / nb,
                         c.prof[5] / nb);
-#ifdef JB_GG_PROFILE
+#if JB_GG_PROFILE
                 // who a gang waits for: per exchange of gangs 0, 9, 18 the arrival of each tile (its sums ready) behind the
                 // gang's first arrival, and how long after the LAST arrival the last tile had the exchange over (100 MHz clock)
                 const int nt = std::min(sd[si].gv_gang_tiles, 8);

@@ -122,6 +122,11 @@ struct GvBinEntry {
     uint8_t k, t0, nt, flags;
 };
 // Control block of one launch of k_mlpg_gv_gang (zeroed before the launch) and per-gang records.
+// measurement aid of the resident GV kernel (tools/gg_prof.sh builds EVERY translation unit with -DJB_GG_PROFILE=1):
+// defined here, once, and tested with #if everywhere, so that the layout of GvGang cannot differ between units
+#ifndef JB_GG_PROFILE
+#define JB_GG_PROFILE 0
+#endif
 constexpr int kGvGangMaxTiles = 64; // workgroups per gang (one poller lane each): rows of up to 64 tiles
 struct GvGangCtl {
     uint32_t tickets;  // next workgroup to start -> (gang, tile)
@@ -135,13 +140,16 @@ struct GvGang {
     uint32_t pad[31];
     // {S1, S2, H, next row} per tile as four 16-byte granules {value, value ^ tag}, two alternating slots
     unsigned long long rec[2][kGvGangMaxTiles][8];
-#ifdef JB_GG_PROFILE
+#if JB_GG_PROFILE
     // measurement aid (-DJB_GG_PROFILE builds of every translation unit): the 100 MHz real-time clock of thread 0 of
     // each of the gang's first 8 tiles at its first 96 exchanges -- [0]: its sums are ready (arrival), [1]: the
     // exchange is over
     unsigned long long stamp[2][8][96];
 #endif
 };
+static_assert(sizeof(GvGang) == 128 + sizeof(unsigned long long) * 2 * kGvGangMaxTiles * 8 +
+                                    (JB_GG_PROFILE ? sizeof(unsigned long long) * 2 * 8 * 96 : 0),
+              "GvGang layout (host offsets in jb_batch.cpp and the kernel must agree)");
 
 struct VocDev {
     int fs, fperiod, nmcp, nlpf, bs, nblk; // bs = samples per block (divides fperiod, <=64)

@@ -339,6 +339,7 @@ struct States {
     std::vector<uint32_t> rows[kMaxStream][JB_MAX_VOICES];
     std::vector<double> weights[kMaxStream];
     std::vector<uint32_t> dur;
+    std::vector<double> dur_pdf; // [S][2]: Models::duration (model/mod.rs:80-92), the blended (mean, variance) the durations come from
     std::vector<double> mean[kMaxStream], var[kMaxStream], msd[kMaxStream], gvm[kMaxStream],
         gvv[kMaxStream];
     std::vector<uint8_t> gsw[kMaxStream];
@@ -484,6 +485,11 @@ static int build_states(const Engine &e, const char *const *lines, size_t n, Sta
             }
         });
         fmark("pdfs of all models");
+        st.dur_pdf.resize(2 * S);
+        for (size_t s = 0; s < S; s++) {
+            st.dur_pdf[2 * s] = dp[s].mean;
+            st.dur_pdf[2 * s + 1] = dp[s].vari;
+        }
         if (S) {
             if (c.phoneme_alignment) {
                 // create_with_alignment (duration.rs:41-65)
@@ -887,6 +893,10 @@ int jb_engine_states(const jb_engine *e, const char *const *lines, size_t n, jb_
     return JB_OK;
 }
 const jb_state_utt *jb_states_utt(const jb_states *s) { return s ? &((const jb::States *)s)->utt : nullptr; }
+const double *jb_states_duration_params(const jb_states *s)
+{
+    return s && !((const jb::States *)s)->dur_pdf.empty() ? ((const jb::States *)s)->dur_pdf.data() : nullptr;
+}
 const jb_voice_desc *jb_engine_voice_desc(const jb_engine *e) { return e ? &CENG(e)->desc : nullptr; }
 void jb_states_free(jb_states *s) { delete (jb::States *)s; }
 

@@ -69,9 +69,7 @@ namespace jb {
 #ifndef JB_GG_A0_LDS
 #define JB_GG_A0_LDS 0 // 1: A0 stays in a second LDS image per wave as well (16 VGPRs less)
 #endif
-#ifndef JB_GG_PROFILE
-#define JB_GG_PROFILE 0 // 1: thread 0 of every workgroup adds its shader-clock ticks per section to ctl->prof
-#endif
+// JB_GG_PROFILE (jb_device.h; 0 in the product) = 1: thread 0 of every workgroup adds its shader-clock ticks per section to ctl->prof
 #if JB_GG_PROFILE
 #define GG_T(k)                                                                                    \
     do {                                                                                           \

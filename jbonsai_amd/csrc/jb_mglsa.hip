@@ -16,6 +16,7 @@
 // linear recurrence with the constant ratio -alpha -- a weighted scan over the wave (DPP row_shr
 // 1/2/4/8, row_bcast 15/31: the sums are re-associated w.r.t. the reference, ~1e-14 relative).  The dot
 // product with c[i+1] is a DPP sum; the stages are sequential (each subtracts its y from x).
+#include <atomic>
 #include "jb_device.h"
 
 #include <algorithm>
@@ -398,10 +399,19 @@ hipError_t launch_vocoder_mglsa(const BatchDev &bd, const VocDev &vd, const VocW
         uint32_t wpb = (uint32_t)std::min<size_t>(4, (128u << 10) / per_wave);
         if (wpb == 3)
             wpb = 2;
-        static const hipError_t attr = hipFuncSetAttribute((const void *)k_vocoder_mglsa<0>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
-        if (attr != hipSuccess)
-            return attr;
+        // function attributes are per DEVICE and jb_multi drives several devices from one process: asked once per
+        // device, and a failure is not remembered
+        static std::atomic<bool> attr_set[64];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+            return hipErrorInvalidDevice;
+        if (!attr_set[dev].load(std::memory_order_acquire)) {
+            const hipError_t attr = hipFuncSetAttribute((const void *)k_vocoder_mglsa<0>,
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 << 10);
+            if (attr != hipSuccess)
+                return attr;
+            attr_set[dev].store(true, std::memory_order_release);
+        }
         hipLaunchKernelGGL(k_vocoder_mglsa<0>, dim3((n_items + wpb - 1) / wpb), dim3(64 * wpb), per_wave * wpb, stream, bd,
                            vd, work_dev, n_items, wpb);
         return hipGetLastError();

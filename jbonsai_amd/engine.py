@@ -71,6 +71,8 @@ def _bind(L):
     L.jb_states_utt.restype = C.POINTER(F.StateUtt)
     L.jb_engine_voice_desc.argtypes = [vp]
     L.jb_engine_voice_desc.restype = C.POINTER(F.VoiceDesc)
+    L.jb_states_duration_params.argtypes = [vp]
+    L.jb_states_duration_params.restype = C.POINTER(C.c_double)
     L.jb_states_free.argtypes = [vp]
     L.jb_states_free.restype = None
     L.jb_generator_new.argtypes = [vp, cpp, sz, C.POINTER(vp)]
@@ -262,6 +264,17 @@ class Engine:
                 gs = (np.ctypeslib.as_array(s.gv_switch, shape=(S,)).copy() if s.gv_switch and S else None)
                 sts.append(StreamStates(mean, var, msd, gm, gv, gs, s.gv_weight, s.msd_threshold))
             return Utterance(dur, sts)
+        finally:
+            self._L.jb_states_free(h)
+
+    def duration_params(self, labels: Sequence[str]) -> np.ndarray:
+        """Models::duration() (src/model/mod.rs:80-92): [S][2] blended (mean, variance) of the duration pdfs."""
+        h = C.c_void_p()
+        F.check(self._L.jb_engine_states(self._h, _lines(labels), len(labels), C.byref(h)))
+        try:
+            S = self._L.jb_states_utt(h).contents.num_states
+            p = self._L.jb_states_duration_params(h)
+            return np.ctypeslib.as_array(p, shape=(S, 2)).copy() if S and p else np.zeros((0, 2))
         finally:
             self._L.jb_states_free(h)
 

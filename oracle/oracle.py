@@ -176,6 +176,8 @@ def lib():
                                         C.POINTER(C.POINTER(C.c_double)),
                                         C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.c_size_t)]
         vpp, dpp = C.POINTER(C.c_void_p), C.POINTER(C.c_double)
+        L.jbo_duration_params_multi.restype = C.c_int
+        L.jbo_duration_params_multi.argtypes = [vpp, C.c_int, dpp, C.POINTER(C.c_char_p), C.c_int, C.c_void_p]
         L.jbo_durations_multi.restype = C.c_int
         L.jbo_durations_multi.argtypes = [vpp, C.c_int, dpp, C.POINTER(C.c_char_p), C.c_int, C.c_double,
                                           C.c_void_p, C.c_void_p]
@@ -405,6 +407,14 @@ class VoiceSet:
             w.parameter[i] = _ptr(self.w_parameter[i], C.c_double)
             w.gv[i] = _ptr(self.w_gv[i], C.c_double)
         return w
+
+    def duration_params(self, labels):
+        """Models::duration() over the set (src/model/mod.rs:80-92): [S][2] blended (mean, variance)."""
+        out = np.zeros((len(labels) * self.v0.nstate, 2))
+        if self.L.jbo_duration_params_multi(self._h, len(self.voices), _ptr(self.w_duration, C.c_double), _strs(labels),
+                                            len(labels), out.ctypes.data):
+            raise RuntimeError("duration_params_multi")
+        return out
 
     def durations(self, labels, speed=1.0, times=None):
         out = np.zeros(len(labels) * self.v0.nstate, dtype=np.uint32)

@@ -40,4 +40,12 @@ def tohoku_voices():
 # Engine::load([neutral, happy]) + the weights of src/lib.rs:80-84 (GV weights stay at InterporationWeight::new's
 # equal split, src/model/interporation_weight.rs:48-60)
 BONSAI_MULTI_WEIGHTS = {"duration": [0.7, 0.3], "parameter": [[0.7, 0.3], [0.7, 0.3], [1.0, 0.0]]}
+# src/model/mod.rs:395-428 `multiple_models`: neutral + happy, set_duration([0.7, 0.3]), set_parameter(1, [0.7, 0.3]),
+# label SAMPLE_SENTENCE_1[2]: Models::duration() and Models::stream(1)[0], compared with assert_eq! (exact)
+MULTIPLE_MODELS_WEIGHTS = {"duration": [0.7, 0.3], "parameter": [[0.5, 0.5], [0.7, 0.3], [0.5, 0.5]]}
+MULTIPLE_MODELS_DURATION = [(3.345043873786926, 6.943870377540589), (9.866290760040282, 59.23959312438964),
+                            (5.616884994506836, 16.154539680480955), (1.7678393721580503, 0.9487730085849762),
+                            (1.3566675186157227, 1.2509666562080382)]
+MULTIPLE_MODELS_LF0_STATE0 = ([(5.354794883728027, 0.00590993594378233), (-0.004957371624186635, 0.00017984867736231536),
+                               (0.010301648452877997, 0.00044686400215141473)], 0.9955164790153503)
 BONSAI_MULTI_GOLDEN = {"len": 74880, 2000: 2.3158134981607754e-5, 30000: 6459.375032316974}  # src/lib.rs:88-90

@@ -178,6 +178,35 @@ def test_two_voice_blend_matches_reference_formula(oracle_voice):
     assert np.array_equal(u.streams[0].mean, want)
 
 
+def test_multiple_models():
+    """src/model/mod.rs:395-428 through the product's host front half (jb_engine_states, jb_states_duration_params):
+    the blended duration pdfs and the first LF0 state of two DIFFERENT voices, exact.  Needs no GPU.  Skipped until
+    the tohoku-f01 files are supplied (tests/conftest.py: JB_TOHOKU_DIR)."""
+    from tests.conftest import (MULTIPLE_MODELS_DURATION, MULTIPLE_MODELS_LF0_STATE0, MULTIPLE_MODELS_WEIGHTS,
+                                tohoku_voices)
+
+    e = J.Engine.load(tohoku_voices())
+    e.condition.set_interpolation_duration(MULTIPLE_MODELS_WEIGHTS["duration"])
+    e.condition.set_interpolation_parameter(1, MULTIPLE_MODELS_WEIGHTS["parameter"][1])
+    lab = [SAMPLE_SENTENCE_1[2]]
+    assert e.duration_params(lab).tolist() == [list(x) for x in MULTIPLE_MODELS_DURATION]
+    st = e.states(lab).streams[1]
+    (w0, w1, w2), msd = MULTIPLE_MODELS_LF0_STATE0
+    for w, (m, v) in enumerate((w0, w1, w2)):
+        assert st.mean[0, w] == m and st.var[0, w] == v
+    assert st.msd[0] == msd
+
+
+def test_duration_params_equal_oracle(engine, oracle_voice):
+    """jb_states_duration_params = Models::duration(): the nitech pins of src/model/mod.rs:234-262 through the product,
+    and the whole table against the oracle."""
+    d = engine.duration_params(SAMPLE_SENTENCE_1)
+    assert d.shape == (40, 2)
+    assert d[0].tolist() == [7.939206123352051, 145.76211547851563]
+    assert d[14].tolist() == [2.7264480590820313, 3.725647211074829]
+    assert np.array_equal(d, oracle_voice.duration_params(SAMPLE_SENTENCE_1))
+
+
 def test_label_errors(engine):
     with pytest.raises(J.JbError) as ei:
         engine.states(["0 100"])

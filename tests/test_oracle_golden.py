@@ -176,6 +176,24 @@ def test_bonsai_multi():
     assert abs(s[30000] - BONSAI_MULTI_GOLDEN[30000]) <= EPS
 
 
+def test_multiple_models():
+    """src/model/mod.rs:395-428 -- the reference's second two-voice pin: blended duration pdfs and the first LF0 state
+    of `Models` for tohoku neutral + happy, weights 0.7 / 0.3 on durations and on stream 1 (InterporationWeight::new's
+    equal split elsewhere), BEFORE any arithmetic of the hot path.  assert_eq! in the reference: exact equality here.
+    Skipped until the tohoku-f01 files are supplied (tests/conftest.py: JB_TOHOKU_DIR)."""
+    from tests.conftest import (MULTIPLE_MODELS_DURATION, MULTIPLE_MODELS_LF0_STATE0, MULTIPLE_MODELS_WEIGHTS,
+                                tohoku_voices)
+
+    vs = O.VoiceSet(tohoku_voices(), MULTIPLE_MODELS_WEIGHTS)
+    lab = [SAMPLE_SENTENCE_1[2]]
+    assert vs.duration_params(lab).tolist() == [list(x) for x in MULTIPLE_MODELS_DURATION]
+    st = vs.stream_states(1, lab)
+    (w0, w1, w2), msd = MULTIPLE_MODELS_LF0_STATE0
+    for w, (m, v) in enumerate((w0, w1, w2)):
+        assert st.mean[0, w] == m and st.var[0, w] == v
+    assert st.msd[0] == msd
+
+
 def test_empty(oracle_voice):
     assert len(oracle_voice.synthesize([])) == 0
     assert len(oracle_voice.synthesize([], speed=1.2)) == 0
