@@ -468,10 +468,67 @@ class Ranks:
         c.close()
         return ms, overlapped
 
+    def identities(self, J):
+        """What makes an N-rank line self-verifying (VERDICT r5 "next" 7): for every rank the PCI bus id of the card
+        it runs on (hipDeviceGetPCIBusId through jb_device_pci_bus_id) and the size RCCL itself reports for a
+        communicator formed by the LIBRARY over all ranks (ncclCommCount through jb_comm_size) -- `n_gpus` of the line
+        is WORLD_SIZE from the environment, which proves neither.  Two ranks on one card outside the one-GPU
+        rehearsal (JB_BENCH_REHEARSE) end the run.  Returns (list of per-rank records, number of distinct cards)."""
+        import ctypes
+
+        buf = ctypes.create_string_buffer(64)
+        bus = buf.value.decode() if J.lib().jb_device_pci_bus_id(self.local_rank, buf, 64) == 0 else None
+        size, cerr = None, None
+        if self.dist is not None and (not self.rehearse or os.environ.get("JB_RCCL_LIBRARY")):
+            ids = [None]
+            try:
+                ids = [J.comm.unique_id() if self.rank == 0 else None]
+            except Exception as e:  # noqa: BLE001  (every rank must still reach the broadcast)
+                cerr = repr(e)
+            self.dist.broadcast_object_list(ids, src=0)
+            if ids[0] is not None:
+                try:
+                    c = J.comm.Comm(ids[0], self.world, self.rank, device=self.local_rank)
+                    size = c.size()
+                    c.close()
+                except Exception as e:  # noqa: BLE001
+                    cerr = repr(e)
+        elif self.dist is None:
+            size = 1
+        me = {"rank": self.rank, "local_rank": self.local_rank, "pci_bus_id": bus, "comm_size_from_rccl": size}
+        if cerr:
+            me["comm_error"] = cerr
+        recs = [me]
+        if self.dist is not None:
+            recs = [None] * self.world
+            self.dist.all_gather_object(recs, me)
+        cards = {r["pci_bus_id"] for r in recs}
+        if len(cards) != len(recs) and not self.rehearse:
+            raise SystemExit(f"bench.py --gpus {self.world}: ranks share a GPU ({[r['pci_bus_id'] for r in recs]}); "
+                             "one process per GPU is the contract (JB_BENCH_REHEARSE=1 for the one-GPU rehearsal)")
+        return recs, len(cards)
+
     def close(self):
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+class Solo:
+    """Rank 0 on its own, the other ranks idle at the next barrier: the N = 1 reference of a strong-scaling job,
+    measured in the SAME run on the same box (run_config3 takes this in place of Ranks)."""
+
+    def __init__(self, R):
+        self.rank, self.world, self.local_rank, self.dry, self._t = 0, 1, R.local_rank, False, R.torch
+
+    def barrier(self):
+        self._t.cuda.synchronize()
+
+    def max(self, x):
+        return x
+
+    def all_gather_floats(self, xs):
+        return [list(xs)]
 
 
 PROFILE_ROUND = "r05"  # profiles/<round>_* are what this line may quote
@@ -1077,6 +1134,23 @@ def order_record(J, vi, R, tab, nmcp, n_utts, distinct, steps=6):
                          "flop_per_sample": FLOP_PER_SAMPLE * (nmcp - 1) / 34.0}}
 
 
+def config3_n1_reference(R, J, tab, vi, pset, args):
+    """At N > 1: the SAME 4096-utterance job on rank 0 alone (one warm-up pass, two timed), the other ranks idle --
+    so that the strong-scaling figure of a line is one division of two numbers of the same run and box."""
+    if R.world == 1 or R.dry:
+        return None
+    rec = None
+    if R.rank == 0:
+        try:
+            rec = run_config3(Solo(R), J, tab, vi, pset, args, 2, 1)
+            rec = {k: rec.get(k) for k in ("value", "unit", "ms_per_step", "steps", "error") if k in rec}
+            rec["how"] = "rank 0 alone right after the N-rank passes, the other ranks idle at a barrier"
+        except Exception as e:  # noqa: BLE001
+            rec = {"error": repr(e)}
+    R.barrier()
+    return rec
+
+
 def run_rank(args):
     # the config-3 job keeps two sub-batches alive (one running, the next being created): let the
     # library's device-memory pool hold both sets of blocks between passes (default cap 64 GB).  Not for
@@ -1101,13 +1175,17 @@ def run_rank(args):
         time.sleep(float(os.environ.get("JB_BENCH_DRYRUN_SLEEP_S", "0")))  # launcher tests: a rank that hangs
         rec = run_config3(R, J, tab, vi, None, args, 1, 0)
         gms = R.gather_slabs(torch.arange(1000 * (R.rank + 1), dtype=torch.float64))
+        ranks, n_cards = R.identities(J)  # (no GPU here: bus ids are None, no communicator is formed -- the plumbing)
         if R.rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": R.world, "gather_ms": gms, "config3_plan": rec}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": R.world, "gather_ms": gms, "config3_plan": rec, "ranks": ranks,
+                              "distinct_gpus": n_cards}), flush=True)
         R.close()
         return
     if args.job == "config3":
         pset = tab.pdf_set(R.local_rank)
+        ranks, n_cards = R.identities(J)
         rec = run_config3(R, J, tab, vi, pset, args, args.steps, args.warmup)
+        n1 = config3_n1_reference(R, J, tab, vi, pset, args)
         if R.rank == 0:
             out = {
                 "metric": "48 kHz PCM samples/sec (whole node), batched utterances",
@@ -1120,7 +1198,12 @@ def run_rank(args):
                 "per_rank_ms": rec["per_rank_ms"], "per_rank_frames": rec["per_rank_frames"],
                 "per_rank_sub_batches": rec["per_rank_sub_batches"],
                 "imbalance_max_over_mean_frames": rec["imbalance_max_over_mean_frames"],
+                "ranks": ranks, "distinct_gpus": n_cards,
             }
+            if n1 is not None:
+                out["config3_job_n1"] = n1
+                if n1.get("value") and rec.get("value"):
+                    out["strong_scaling_speedup"] = rec["value"] / n1["value"]
             print(json.dumps(out), flush=True)
         pset.close()
         R.close()
@@ -1174,6 +1257,7 @@ def run_rank(args):
                 for b_ in pair:
                     b_.close()
 
+    ranks, n_cards = R.identities(J)
     info = batch.info()
     info["kernel"], info["waves_per_simd"] = batch.kernel_info()
     redo_stats = batch.redo_stats()
@@ -1207,6 +1291,7 @@ def run_rank(args):
                 "vocoder_work_items": info["n_items"], "chunks_redone_last_step": info["n_redo"],
             },
             "realtime_factor": value / vi.sampling_frequency,
+            "ranks": ranks, "distinct_gpus": n_cards,
             # (the key carries the slab's type since round 6: rounds 1-4 reported the f64 slab of the timed batch as
             #  `gather_ms`, round 5 the 16-bit slab of a fresh pair under the same key -- not comparable: ADVICE r5)
             **({f"gather_{gather_dtype}_ms": gather_ms, "gather_overlapped_ms_per_step": gather_ovl, "gather_dtype": gather_dtype,
@@ -1244,10 +1329,16 @@ def run_rank(args):
         except Exception:
             pass  # run_config3 reports it: creating a batch over a missing set fails on this rank only
         rec = run_config3(R, J, tab, vi, pset, args, 2, 1)
+        n1 = config3_n1_reference(R, J, tab, vi, pset, args) if pset is not None else None
         if pset is not None:
             pset.close()
         if out is not None:
             out["config3_strong" if R.world > 1 else "config3_job"] = rec
+            if n1 is not None:
+                # the N = 1 value of the same job beside the N-rank one: strong scaling is one division
+                out["config3_job_n1"] = n1
+                if n1.get("value") and rec.get("value"):
+                    out["config3_strong"]["speedup_over_n1"] = rec["value"] / n1["value"]
     if R.rank == 0:
         if R.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(utt, vi, args.batch, gpu_out)

@@ -500,6 +500,9 @@ const char *jb_last_error(void);
 int jb_device_count(void);
 /* "gfx950" etc. of device `dev` into buf. */
 int jb_device_arch(int dev, char *buf, size_t cap);
+/* hipDeviceGetPCIBusId of device `dev` ("0000:05:00.0") into buf: which CARD a rank really runs on -- two ranks that
+ * report the same id share one GPU, whatever WORLD_SIZE says (bench.py --gpus N puts it into its line). */
+int jb_device_pci_bus_id(int dev, char *buf, size_t cap);
 const char *jb_version(void);
 /* The tolerance of the chunk hand-off check a batch runs with when jb_batch_opts.verify_tol is 0 (1e-9 of the largest
  * state value): the ONE number the PCM gates of the tests and sweeps are derived from (tests/helpers.py). */

@@ -152,7 +152,7 @@ SYMBOLS = [
     "jb_comm_unique_id", "jb_comm_init", "jb_comm_rank", "jb_comm_size", "jb_comm_free", "jb_gather_pcm",
     "jb_gathered_samples", "jb_gathered_sample_bytes", "jb_gathered_device", "jb_gathered_read", "jb_gathered_free",
     "jb_lpt_partition", "jb_paramgen_vocode_batch_multi", "jb_synthesize_batch_multi", "jb_synthesize_batch_i16_multi",
-    "jb_states_duration_params", "jb_last_error", "jb_device_count", "jb_device_arch", "jb_version", "jb_default_verify_tol",
+    "jb_states_duration_params", "jb_last_error", "jb_device_count", "jb_device_arch", "jb_device_pci_bus_id", "jb_version", "jb_default_verify_tol",
 ]
 
 
@@ -186,6 +186,7 @@ def lib():
     L.jb_default_verify_tol.restype = C.c_double
     L.jb_device_count.restype = C.c_int
     L.jb_device_arch.argtypes = [C.c_int, C.c_char_p, sz]
+    L.jb_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, sz]
     L.jb_batch_create.argtypes = [C.POINTER(VoiceDesc), C.POINTER(StateUtt), sz, C.POINTER(BatchOpts),
                                   C.POINTER(vp)]
     L.jb_pdf_set_create.argtypes = [C.POINTER(PdfTable), C.c_uint32, C.c_uint32, C.c_int32, C.POINTER(vp)]

@@ -56,6 +56,10 @@ class Comm:
         F.check(L.jb_comm_init(comm_id, n_ranks, rank, device, C.byref(h)))
         self._h, self._L, self.n_ranks, self.rank = h, L, n_ranks, rank
 
+    def size(self) -> int:
+        """Ranks of the communicator as RCCL reports them (ncclCommCount through jb_comm_size)."""
+        return int(self._L.jb_comm_size(self._h))
+
     def gather_pcm(self, batch, root: int = 0):
         """Collective.  Returns (Gathered on the root / None elsewhere, milliseconds of the exchange)."""
         out, ms = C.c_void_p(), C.c_float()

@@ -2318,6 +2318,16 @@ int jb_device_arch(int dev, char *buf, size_t cap)
     return JB_OK;
 }
 
+int jb_device_pci_bus_id(int dev, char *buf, size_t cap)
+{
+    if (!buf || cap < 13)
+        return JB_ERR_BUFFER;
+    hipError_t e = hipDeviceGetPCIBusId(buf, (int)cap, dev);
+    if (e != hipSuccess)
+        return jb::hip_fail(e, "hipDeviceGetPCIBusId");
+    return JB_OK;
+}
+
 int jb_batch_create(const jb_voice_desc *voice, const jb_state_utt *utts, size_t n_utts,
                     const jb_batch_opts *opts, jb_batch **out)
 {

@@ -259,6 +259,7 @@ struct Rccl {
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr; // optional: jb_comm_size asks the communicator itself
 };
 
 const Rccl *rccl()
@@ -290,6 +291,7 @@ const Rccl *rccl()
         x.Recv = (decltype(x.Recv))sym("ncclRecv");
         x.AllGather = (decltype(x.AllGather))sym("ncclAllGather");
         x.GetErrorString = (decltype(x.GetErrorString))sym("ncclGetErrorString");
+        x.CommCount = (decltype(x.CommCount))sym("ncclCommCount");
         if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.GroupStart || !x.GroupEnd || !x.Send || !x.Recv ||
             !x.AllGather || !x.GetErrorString)
             x.h = nullptr;
@@ -405,7 +407,22 @@ int jb_comm_init(const uint8_t *id, int n_ranks, int rank, int32_t device, jb_co
 
 void jb_comm_free(jb_comm *c) { delete (jb::Comm *)c; }
 int jb_comm_rank(const jb_comm *c) { return c ? ((const jb::Comm *)c)->rank : -1; }
-int jb_comm_size(const jb_comm *c) { return c ? ((const jb::Comm *)c)->n_ranks : 0; }
+// the size RCCL itself reports for the communicator (ncclCommCount), not the number the caller passed in: what a
+// multi-GPU bench line quotes as proof that its ranks really formed ONE communicator of N (a one-rank communicator
+// never loads RCCL: its size is 1 by construction)
+int jb_comm_size(const jb_comm *c)
+{
+    if (!c)
+        return 0;
+    const jb::Comm *cm = (const jb::Comm *)c;
+    if (cm->comm) {
+        const jb::Rccl *r = jb::rccl();
+        int n = 0;
+        if (r && r->CommCount && r->CommCount(cm->comm, &n) == ncclSuccess)
+            return n;
+    }
+    return cm->n_ranks;
+}
 
 // Failure is COLLECTIVE: a rank that cannot contribute (no batch, a batch on another device, a run that failed)
 // still joins the exchange of the counts with a sentinel, and a root that cannot allocate its receive slabs

@@ -192,6 +192,16 @@ ncclResult_t ncclCommInitRank(ncclComm_t *out, int nranks, ncclUniqueId id, int 
     return ncclSuccess;
 }
 
+// the number of ranks that ARRIVED in the shared segment, not the number this rank asked for
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count)
+{
+    const Comm *c = (const Comm *)comm;
+    if (!c || !count)
+        return ncclInvalidArgument;
+    *count = (int)c->shm->arrived.load(std::memory_order_acquire);
+    return ncclSuccess;
+}
+
 ncclResult_t ncclCommDestroy(ncclComm_t comm)
 {
     Comm *c = (Comm *)comm;

@@ -60,6 +60,8 @@ def test_bench_launcher_spawns_ranks_and_plans_config3():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["dry_run"] and d["n_gpus"] == 2 and d["gather_ms"] is not None
+    # one identity record per rank (PCI bus id and RCCL-reported communicator size are None without a GPU)
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all("pci_bus_id" in r and "comm_size_from_rccl" in r for r in d["ranks"])
     plan = d["config3_plan"]
     lens = synth.mixed_lengths(96)
     assert sum(plan["per_rank_frames"]) == sum(lens)
