@@ -1762,6 +1762,12 @@ constexpr int kLtPf = 4; // coefficient reads in flight ahead of their use (2, 3
 // FOUR waves per workgroup = one wave per SIMD, for batches that cannot give every SIMD two waves of chunks that
 // are long against their warm-up: a lone wave issues an instruction every 6.7 cycles, one of a pair every 8.9.
 constexpr int kLtBalance = 8;
+#ifdef JB_LT_STAMPS
+// occupancy aid (tools/lt_occupancy.sh; round 6): every wave of the kernel leaves the 100 MHz clock at its start and at
+// its end, where it ran (HW_ID: SIMD, CU, SE; XCC_ID) and how many frames it walked -- which SIMD held two waves when
+constexpr unsigned kLtStampWaves = 4096;
+__device__ unsigned long long g_lt_stamp[kLtStampWaves][4];
+#endif
 #ifdef JB_LT_CLOCKS
 // timing aid (tools/lt_clocks.sh): shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at the
 // start and end of two waves of the kernel: the clock the chip holds under this kernel
@@ -1826,6 +1832,17 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
         prog[wv] = maxfr == 0 ? 0xffffffffu : 0u;
     if (maxfr == 0)
         return;
+#ifdef JB_LT_STAMPS
+    const unsigned stamp_w = blockIdx.x * (unsigned)kLtWaves + (unsigned)wv;
+    if (lane == 0 && stamp_w < kLtStampWaves) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+        g_lt_stamp[stamp_w][0] = wall_clock64();
+        g_lt_stamp[stamp_w][2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        g_lt_stamp[stamp_w][3] = maxfr;
+    }
+#endif
 #ifdef JB_LT_CLOCKS
     const int clk_slot = wv != 0 ? -1 : blockIdx.x == 0 ? 0 : blockIdx.x == gridDim.x / 2 ? 4 : -1;
     if (clk_slot >= 0 && lane == 0) {
@@ -2263,6 +2280,10 @@ __global__ __launch_bounds__(64 * kLtWaves, 2) void k_vocoder_lt(BatchDev bd, Vo
     }
     if (kLtWaves == 8 && lane == 0)
         prog[wv] = 0xffffffffu;
+#ifdef JB_LT_STAMPS
+    if (lane == 0 && stamp_w < kLtStampWaves)
+        g_lt_stamp[stamp_w][1] = wall_clock64();
+#endif
 #ifdef JB_LT_CLOCKS
     if (clk_slot >= 0 && lane == 0) {
         g_lt_clk[clk_slot + 2] = clock64();
@@ -2563,6 +2584,32 @@ hipError_t launch_vocoder_ls(const BatchDev &bd, const VocDev &vd, const VocWork
     else
         JB_LT_LAUNCH(61, 5, false, 5);
 #undef JB_LT_LAUNCH
+#ifdef JB_LT_STAMPS
+    if (const char *path = getenv("JB_LT_STAMPS_FILE")) { // the LAST launch of the process is what the file holds
+        static unsigned long long st[kLtStampWaves][4];
+        hipStreamSynchronize(stream);
+        const unsigned nw = std::min<unsigned>(kLtStampWaves, grid.x * (unsigned)wv);
+        if (hipMemcpyFromSymbol(st, HIP_SYMBOL(g_lt_stamp), sizeof st) == hipSuccess)
+            if (FILE *f = fopen(path, "w")) {
+                fprintf(f, "# wave start_10ns end_10ns hw_id xcc frames   (k_vocoder_lt, %u waves, %d per workgroup)\n", nw, wv);
+                for (unsigned w = 0; w < nw; w++)
+                    fprintf(f, "%u %llu %llu %llu %llu %llu\n", w, st[w][0], st[w][1], st[w][2] & 0xffffffffull,
+                            st[w][2] >> 32, st[w][3]);
+                fclose(f);
+            }
+        // per launch: when the last wave of every XCD ended, ms behind the kernel's first wave start
+        unsigned long long t0 = ~0ull, last[16] = {0};
+        for (unsigned w = 0; w < nw; w++)
+            if (st[w][0] && st[w][0] < t0)
+                t0 = st[w][0];
+        for (unsigned w = 0; w < nw; w++)
+            last[(st[w][2] >> 32) & 15] = std::max(last[(st[w][2] >> 32) & 15], st[w][1]);
+        fprintf(stderr, "k_vocoder_lt last wave end per XCD, ms:");
+        for (int x = 0; x < 8; x++)
+            fprintf(stderr, " %.2f", last[x] ? (double)(last[x] - t0) / 1e5 : 0.0);
+        fprintf(stderr, "\n");
+    }
+#endif
 #ifdef JB_LT_CLOCKS
     {
         unsigned long long c[8];
