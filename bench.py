@@ -531,7 +531,7 @@ class Solo:
         return [list(xs)]
 
 
-PROFILE_ROUND = "r05"  # profiles/<round>_* are what this line may quote
+PROFILE_ROUND = "r06"  # profiles/<round>_* are what this line may quote
 
 
 def kernel_sources_sha16():
