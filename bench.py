@@ -421,6 +421,7 @@ class Ranks:
         ids = [J.comm.unique_id() if self.rank == 0 else None]
         self.dist.broadcast_object_list(ids, src=0)
         c = J.comm.Comm(ids[0], self.world, self.rank, device=self.local_rank)
+        self.gather_comm_size = c.size()  # ncclCommCount of the communicator the library formed for the gather
         self.barrier()
         g, ms = c.gather_pcm(batch, root=0)
         ms = self.max(ms)
@@ -478,8 +479,18 @@ class Ranks:
 
         buf = ctypes.create_string_buffer(64)
         bus = buf.value.decode() if J.lib().jb_device_pci_bus_id(self.local_rank, buf, 64) == 0 else None
-        size, cerr = None, None
-        if self.dist is not None and (not self.rehearse or os.environ.get("JB_RCCL_LIBRARY")):
+        size, cerr, source = None, None, None
+        lib_comm = bool(os.environ.get("JB_RCCL_LIBRARY")) or os.environ.get("JB_BENCH_VERIFY_COMM", "0") != "0"
+        if self.dist is not None and not self.rehearse and not lib_comm:
+            # the ranks that took part in an RCCL collective, counted BY the collective: a sum of ones over the process
+            # group's communicator (backend nccl = RCCL).  The library's own communicator (ncclCommCount through
+            # jb_comm_size) is asked with --gather, which forms one anyway, or with JB_BENCH_VERIFY_COMM=1: a second
+            # communicator that failed to form would cost the driver's one multi-GPU run its line.
+            one = self.torch.ones(1, dtype=self.torch.float64, device="cuda")
+            self.dist.all_reduce(one)
+            size, source = int(round(float(one.item()))), "all_reduce of ones over the process group's RCCL communicator"
+        elif self.dist is not None and lib_comm:
+            source = "ncclCommCount of a communicator formed by the library (jb_comm_size)"
             ids = [None]
             try:
                 ids = [J.comm.unique_id() if self.rank == 0 else None]
@@ -494,8 +505,9 @@ class Ranks:
                 except Exception as e:  # noqa: BLE001
                     cerr = repr(e)
         elif self.dist is None:
-            size = 1
-        me = {"rank": self.rank, "local_rank": self.local_rank, "pci_bus_id": bus, "comm_size_from_rccl": size}
+            size, source = 1, "one rank: no communicator"
+        me = {"rank": self.rank, "local_rank": self.local_rank, "pci_bus_id": bus, "comm_size_from_rccl": size,
+              "comm_size_source": source}
         if cerr:
             me["comm_error"] = cerr
         recs = [me]
@@ -1295,7 +1307,8 @@ def run_rank(args):
             # (the key carries the slab's type since round 6: rounds 1-4 reported the f64 slab of the timed batch as
             #  `gather_ms`, round 5 the 16-bit slab of a fresh pair under the same key -- not comparable: ADVICE r5)
             **({f"gather_{gather_dtype}_ms": gather_ms, "gather_overlapped_ms_per_step": gather_ovl, "gather_dtype": gather_dtype,
-                "gather_bytes_into_root": (R.world - 1) * samples_per_step * (8 if gather_dtype == "f64" else 2)}
+                "gather_bytes_into_root": (R.world - 1) * samples_per_step * (8 if gather_dtype == "f64" else 2),
+                "gather_comm_size_from_rccl": getattr(R, "gather_comm_size", None)}
                if gather_ms is not None else {}),
             "roofline": roofline_block(samples_per_step, voc_avg_ms, info, args.batch, frames),
             "kernel_sources_sha16": kernel_sources_sha16(),

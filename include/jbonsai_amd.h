@@ -39,7 +39,7 @@ extern "C" {
 typedef enum jb_status {
     JB_OK = 0,
     JB_ERR_INVALID = -1,     /* bad argument / shape (reference: panics in src/speech.rs:32-40) */
-    JB_ERR_UNSUPPORTED = -2, /* shapes no kernel is built for: nmcp > 61, window widths above 5, stages above 256, nlpf > 2047, other
+    JB_ERR_UNSUPPORTED = -2, /* shapes no kernel is built for: nmcp > 64, window widths above 9, stages above 256, nlpf > 2047, other
                                 than three streams (frame periods, stages and low-pass orders are otherwise free: rounds 1-4 refused
                                 stages above 8, nlpf > 63 and frame periods without a divisor <= 64 that is >= nlpf - 1) */
     JB_ERR_DEVICE = -3,      /* HIP error or no gfx950 device: the product never falls back to CPU */

@@ -771,8 +771,8 @@ static int check_voice(const jb_voice_desc *v, bool need_windows = true, bool vo
         set_error("nlpf > " + std::to_string(excite_max_nlpf()) + " is not supported");
         return JB_ERR_UNSUPPORTED;
     }
-    if (m.vector_length < 2 || m.vector_length - 1 > (uint32_t)(kGroups * kMaxTPL)) {
-        set_error("nmcp must be in [2, 61]");
+    if (m.vector_length < 2 || m.vector_length - 1 > (uint32_t)(kGroups * kMaxTPL) || m.vector_length > (uint32_t)kMaxNmcp) {
+        set_error("nmcp must be in [2, 64]");
         return JB_ERR_UNSUPPORTED;
     }
     if (v->stage != 0 && m.vector_length < 3) {
@@ -787,8 +787,8 @@ static int check_voice(const jb_voice_desc *v, bool need_windows = true, bool vo
         }
         uint32_t tot = 0;
         for (uint32_t w = 0; w < s.num_windows; w++) {
-            if (s.win_width[w] == 0 || s.win_width[w] > 5) {
-                set_error("window widths must be in 1..5");
+            if (s.win_width[w] == 0 || s.win_width[w] > (uint32_t)kMaxBand) {
+                set_error("window widths must be in 1..9");
                 return JB_ERR_UNSUPPORTED;
             }
             tot += s.win_width[w];

@@ -17,9 +17,11 @@ namespace jb {
 constexpr int kMaxStream = 3;
 constexpr int kMaxWin = 8;
 constexpr int kMaxCoef = 32;
+constexpr int kMaxBand = 9;  // band width 2 * max_width + 1 of the generic MLPG kernels: windows of up to nine taps
 constexpr int kPade = 5;          // MelLogSpectrumApproximation<6>: 5 stages (src/vocoder/mlsa.rs:31)
 constexpr int kGroups = 12;       // lane groups per Pade stage: 5*12 = 60 lanes of a wave64
-constexpr int kMaxTPL = 5;        // taps per lane => nmcp-1 <= 60
+constexpr int kMaxTPL = 6;        // taps per lane of the wave kernels => nmcp-1 <= 72
+constexpr int kMaxNmcp = 64;      // ... and the 64-lane kernels (mc2b tile, post-filter, MGLSA): nmcp <= 64
 constexpr double kNoData = -1e10; // src/constants.rs:13
 
 struct StreamStatesDev {
@@ -98,9 +100,9 @@ struct StreamDev {
     uint32_t *Tv;       // [B] number of voiced frames
     uint32_t *gvlen;    // [B] number of switched-on voiced frames
     // ---- MLPG workspace, each [sumT][L] ----
-    double *A[5];       // un-factored W'U^-1W band (needed again by GV)
+    double *A[kMaxBand]; // un-factored W'U^-1W band (needed again by GV)
     double *bvec;       // W'U^-1 mu
-    double *F[5];       // LDL^T factors
+    double *F[kMaxBand]; // LDL^T factors
     double *g;          // forward-substitution result / GV gradient
     double *par;        // compacted solution
     double *out;        // [sumT][L] scattered parameter track (NODATA in unvoiced frames)

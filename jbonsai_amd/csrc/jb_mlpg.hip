@@ -2550,6 +2550,10 @@ static hipError_t launch_mlpg_inner(const BatchDev &bd, const StreamDev &sd, int
         return launch_mlpg_bw<3>(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
     case 5:
         return launch_mlpg_bw<5>(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
+    case 7: // (round 6: the reference takes any window width, window.rs:19-56; HTS voices use 3, a few 5)
+        return launch_mlpg_bw<7>(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
+    case 9:
+        return launch_mlpg_bw<9>(bd, sd, si, stream, after_build, between, between_ctx, after_ivar);
     default:
         return hipErrorInvalidValue;
     }

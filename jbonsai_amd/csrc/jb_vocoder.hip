@@ -2648,6 +2648,7 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
             JB_PAIR_CASE(3)
             JB_PAIR_CASE(4)
             JB_PAIR_CASE(5)
+            JB_PAIR_CASE(6)
 #undef JB_PAIR_CASE
         default:
             return hipErrorInvalidValue;
@@ -2666,6 +2667,7 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
             JB_PAIR_CASE(3)
             JB_PAIR_CASE(4)
             JB_PAIR_CASE(5)
+            JB_PAIR_CASE(6)
 #undef JB_PAIR_CASE
         default:
             return hipErrorInvalidValue;
@@ -2687,6 +2689,9 @@ hipError_t launch_vocoder(const BatchDev &bd, const VocDev &vd, const VocWork *w
         break;
     case 5:
         hipLaunchKernelGGL(k_vocoder<5>, grid, block, 0, stream, bd, vd, work_dev, n_items);
+        break;
+    case 6: // (orders 61..63: round 6)
+        hipLaunchKernelGGL(k_vocoder<6>, grid, block, 0, stream, bd, vd, work_dev, n_items);
         break;
     default:
         return hipErrorInvalidValue;

@@ -293,6 +293,42 @@ def test_five_point_delta_windows(ctx):
     assert np.array_equal(g0, g1) and rel_rms(g0, ref) <= PCM_TOL
 
 
+@pytest.mark.parametrize("width", [7, 9])
+def test_seven_and_nine_point_delta_windows(ctx, width):
+    """Round 6: windows of up to nine taps (band width 9; the reference takes any width, `model/voice/window.rs:19-56`):
+    the generic build and band solve instantiated for band widths 7 and 9, all three streams' shapes against the
+    oracle; ten taps are refused loudly."""
+    import dataclasses
+
+    eng, tab, vi = ctx
+    u = synth.synth_utterance(tab, 700, 12)
+    h = width // 2
+    k = np.arange(-h, h + 1, dtype=np.float64)
+    d1 = (k / np.sum(k * k)).tolist()                      # least-squares slope over the window
+    d2 = (k * k - np.mean(k * k))
+    d2 = (2.0 * d2 / np.sum(d2 * d2 * 1.0) * np.sum(np.abs(d2)) / width).tolist()  # a curvature-like zero-sum window
+    wn = [[1.0], d1, d2]
+    streams = [dataclasses.replace(vi.streams[0], windows=wn), dataclasses.replace(vi.streams[1], windows=wn),
+               vi.streams[2]]
+    viw = dataclasses.replace(vi, streams=streams)
+    ref, tr = oracle_pcm(viw, u)
+    assert np.isfinite(ref).all()
+    with J.Batch(viw, [u, u], keep_tracks=True) as b:
+        b.run()
+        b.sync()
+        for si in range(3):
+            got = b.track(0, si)
+            assert np.array_equal(got == O.NODATA, tr[si] == O.NODATA)
+            np.testing.assert_allclose(got, tr[si], rtol=1e-12, atol=1e-13)
+        g0, g1 = b.pcm(0), b.pcm(1)
+    assert np.array_equal(g0, g1) and rel_rms(g0, ref) <= PCM_TOL
+    if width == 9:
+        w11 = [[1.0], [0.0] * 11, d2]
+        with pytest.raises(J.JbError) as ei:
+            J.Batch(dataclasses.replace(vi, streams=[dataclasses.replace(vi.streams[0], windows=w11)] + streams[1:]), [u])
+        assert "UNSUPPORTED" in str(ei.value)
+
+
 @pytest.mark.parametrize("fs,fp,alpha,nlpf", [(16000, 80, 0.42, 31), (48000, 90, 0.55, 31), (48000, 240, 0.55, 15),
                                               (22050, 100, 0.45, 31)])
 def test_other_frame_periods_and_lpf_orders(ctx, fs, fp, alpha, nlpf):

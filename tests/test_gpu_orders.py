@@ -62,3 +62,30 @@ def test_lane_kernel_full_batch(ctx, nmcp):
     for i in range(distinct):
         ref, _ = oracle_pcm(vi2, pairs[i][1])
         assert len(first[i]) == len(ref) and rel_rms(first[i], ref) <= PCM_TOL, (nmcp, i)
+
+
+@pytest.mark.parametrize("nmcp", [62, 63, 64])
+def test_orders_above_sixty(ctx, nmcp):
+    """Round 6: nmcp up to 64 (six taps per lane in the wave kernels, the generic MLPG kernels, the 64-wide mc2b tile);
+    the reference has no limit (`vocoder/mod.rs:45-70`), this library's is now 64 -- the width of the lane-per-tap
+    kernels (post-filter, MGLSA).  Chunked and unchunked runs against the oracle, and the refusal behind the limit."""
+    eng, tab, vi = ctx
+    vi2, u2 = synth.with_order(vi, synth.synth_utterance(tab, 600, 5), nmcp)
+    ref, tr = oracle_pcm(vi2, u2)
+    assert np.isfinite(ref).all()
+    for kw in (dict(keep_tracks=True), dict(serial=True), dict(chunk_frames=48)):
+        with J.Batch(vi2, [u2, u2], **kw) as b:
+            b.run()
+            b.sync()
+            g0, g1 = b.pcm(0), b.pcm(1)
+            if kw.get("keep_tracks"):
+                np.testing.assert_allclose(b.track(0, 0), tr[0], rtol=1e-12, atol=1e-13)
+        assert np.array_equal(g0, g1) and rel_rms(g0, ref) <= PCM_TOL, (nmcp, kw)
+
+
+def test_order_limit_fails_loudly(ctx):
+    eng, tab, vi = ctx
+    vi2, u2 = synth.with_order(vi, synth.synth_utterance(tab, 100, 5), 65)
+    with pytest.raises(J.JbError) as ei:
+        J.Batch(vi2, [u2])
+    assert "UNSUPPORTED" in str(ei.value)

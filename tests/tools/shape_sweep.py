@@ -1,4 +1,4 @@
-"""Shape sweep on the GPU box: seeded random COMBINATIONS of mel-cepstral order (2..61: every taps-per-lane form of
+"""Shape sweep on the GPU box: seeded random COMBINATIONS of mel-cepstral order (2..64: every taps-per-lane form of
 the vocoder kernels), frame period (5..400, any), low-pass order (odd, 1..127), warping alpha, post-filter beta,
 volume, kernel choice and chunk length, each on a small ragged batch -- every utterance against the oracle.  The
 tests hold ten such combinations (test_random_shape_combinations); this is the wide version.
@@ -38,7 +38,7 @@ def main():
     hist = {}
     for case in range(a.n):
         rng = np.random.default_rng(50_000 + 1000 * a.seed + case)
-        L2 = int(rng.choice([2, 3, 5, 8, 12, 13, 20, 24, 25, 30, 35, 36, 37, 40, 48, 49, 50, 60, 61]))
+        L2 = int(rng.choice([2, 3, 5, 8, 12, 13, 20, 24, 25, 30, 35, 36, 37, 40, 48, 49, 50, 60, 61, 62, 64]))
         fp = int(rng.choice([5, 16, 27, 30, 31, 40, 64, 65, 75, 80, 83, 96, 100, 110, 120, 127, 128, 131, 160, 200, 220,
                              240, 241, 254, 256, 257, 320, 331, 400]))
         fs = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
